@@ -1,0 +1,51 @@
+"""Oracle: the DDIM scheduler as the pipeline uses it.
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  ``DDIMScheduler`` belongs to the absent
+dependency ``diffusers==0.11.1``; restated from its published algorithm
+with the SD-v1-4 scheduler config -- PARITY UNPINNED by the reference, anchored on:
+
+* the reference's call sites ``EEG2Video/pipelines/pipeline_tuneeeg2video.py:287,314,325``
+  and its config patches ``:59-84`` (``steps_offset = 1``, ``clip_sample = False``);
+* the in-repo restatement of the same update ``EEG2Video_New/Generation/tuneavideo/util.py:56-66``
+  (``alphas_cumprod``, ``final_alpha_cumprod``, ``num_train_timesteps // num_inference_steps``);
+* closed forms: n=50 -> 981, 961, ..., 21, 1; n=4 -> 751, 501, 251, 1.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+class DDIMOracle:
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+        self.num_train_timesteps = num_train_timesteps
+        self.steps_offset = steps_offset
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = self.alphas_cumprod[0]          # set_alpha_to_one = False
+        self.init_noise_sigma = 1.0
+        self.timesteps = None
+        self.num_inference_steps = None
+
+    def set_timesteps(self, n: int) -> np.ndarray:
+        self.num_inference_steps = n
+        ratio = self.num_train_timesteps // n
+        ts = (np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64)
+        ts += self.steps_offset
+        self.timesteps = ts
+        return ts
+
+    def scale_model_input(self, x, t):
+        return x
+
+    def step(self, eps: torch.Tensor, t: int, x: torch.Tensor, eta: float = 0.0) -> torch.Tensor:
+        t = int(t)
+        prev = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+        beta_t = 1 - a_t
+        x0 = (x - beta_t ** 0.5 * eps) / a_t ** 0.5
+        var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+        std = eta * var ** 0.5
+        direction = (1 - a_p - std ** 2) ** 0.5 * eps
+        return a_p ** 0.5 * x0 + direction

@@ -1,0 +1,228 @@
+"""Oracle: ``UNet3DConditionModel.forward`` restated with plain torch CPU ops.
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  Layout and op order are the
+reference's (NCFHW tensors, ``(b f)`` folding for 2-D ops); weights come from a state
+dict keyed exactly like the reference's.  Citations are
+``/root/reference/EEG2Video/models/<file>:<line>``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+
+# ---------------------------------------------------------------- primitives ----------
+def inflated_conv3d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], stride=1, padding=1):
+    """resnet.py:10-18 -- Conv2d applied to ``(b f) c h w``."""
+    n, c, f, h, ww = x.shape
+    x2 = x.permute(0, 2, 1, 3, 4).reshape(n * f, c, h, ww)
+    y = F.conv2d(x2, w, b, stride=stride, padding=padding)
+    return y.reshape(n, f, y.shape[1], y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)
+
+
+def timestep_sinusoid(t: torch.Tensor, dim: int, flip_sin_to_cos=True, freq_shift=0) -> torch.Tensor:
+    """[dep diffusers 0.11.1 ``get_timestep_embedding``; SURVEY C.3] -- unet.py:88,339."""
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32)
+    exponent = exponent / (half - freq_shift)
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+def _heads_to_batch(x: torch.Tensor, heads: int) -> torch.Tensor:
+    """[dep ``CrossAttention.reshape_heads_to_batch_dim``; SURVEY C.1]."""
+    b, s, c = x.shape
+    return x.reshape(b, s, heads, c // heads).permute(0, 2, 1, 3).reshape(b * heads, s, c // heads)
+
+
+def _batch_to_heads(x: torch.Tensor, heads: int) -> torch.Tensor:
+    bh, s, d = x.shape
+    return x.reshape(bh // heads, heads, s, d).permute(0, 2, 1, 3).reshape(bh // heads, s, heads * d)
+
+
+def _attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
+    """[dep ``CrossAttention._attention``; SURVEY C.1] baddbmm(alpha=scale) -> softmax -> bmm."""
+    scores = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype),
+                           q, k.transpose(-1, -2), beta=0, alpha=scale)
+    probs = scores.softmax(dim=-1)
+    return torch.bmm(probs, v)
+
+
+def cross_attention(sd: SD, p: str, x: torch.Tensor, ctx: Optional[torch.Tensor], heads: int) -> torch.Tensor:
+    """[dep ``CrossAttention.forward``; SURVEY C.1] used for attn2 and attn_temp
+    (attention.py:171-179,193-200,250-255,266)."""
+    q = F.linear(x, sd[p + ".to_q.weight"])
+    src = x if ctx is None else ctx
+    k = F.linear(src, sd[p + ".to_k.weight"])
+    v = F.linear(src, sd[p + ".to_v.weight"])
+    d = q.shape[-1] // heads
+    o = _attention(_heads_to_batch(q, heads), _heads_to_batch(k, heads), _heads_to_batch(v, heads), d ** -0.5)
+    o = _batch_to_heads(o, heads)
+    return F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
+
+
+def sparse_causal_attention(sd: SD, p: str, x: torch.Tensor, heads: int, video_length: int) -> torch.Tensor:
+    """attention.py:272-328 -- keys/values = [frame 0 ; frame max(i-1, 0)]."""
+    q = F.linear(x, sd[p + ".to_q.weight"])                               # :281
+    k = F.linear(x, sd[p + ".to_k.weight"])                               # :289
+    v = F.linear(x, sd[p + ".to_v.weight"])                               # :290
+    former = torch.arange(video_length) - 1                               # :292-293
+    former[0] = 0
+    bf, n, c = k.shape
+    b = bf // video_length
+
+    def gather(t):                                                        # :295-301
+        t = t.reshape(b, video_length, n, c)
+        t = torch.cat([t[:, [0] * video_length], t[:, former]], dim=2)
+        return t.reshape(bf, 2 * n, c)
+
+    k, v = gather(k), gather(v)
+    d = c // heads
+    o = _attention(_heads_to_batch(q, heads), _heads_to_batch(k, heads), _heads_to_batch(v, heads), d ** -0.5)
+    o = _batch_to_heads(o, heads)                                         # :319
+    return F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])   # :324
+
+
+def feed_forward(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """[dep ``FeedForward``/``GEGLU``; SURVEY C.2] attention.py:189,258."""
+    h = F.linear(x, sd[p + ".net.0.proj.weight"], sd[p + ".net.0.proj.bias"])
+    a, gate = h.chunk(2, dim=-1)
+    h = a * F.gelu(gate)
+    return F.linear(h, sd[p + ".net.2.weight"], sd[p + ".net.2.bias"])
+
+
+def _ln(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+
+# ---------------------------------------------------------------- blocks --------------
+def basic_transformer_block(sd: SD, p: str, x: torch.Tensor, ctx: torch.Tensor, heads: int, f: int):
+    """attention.py:232-269."""
+    x = sparse_causal_attention(sd, p + ".attn1", _ln(sd, p + ".norm1", x), heads, f) + x       # :234-243
+    x = cross_attention(sd, p + ".attn2", _ln(sd, p + ".norm2", x), ctx, heads) + x             # :245-255
+    x = feed_forward(sd, p + ".ff", _ln(sd, p + ".norm3", x)) + x                               # :258
+    bf, d, c = x.shape                                                                          # :261-267
+    b = bf // f
+    x = x.reshape(b, f, d, c).permute(0, 2, 1, 3).reshape(b * d, f, c)
+    x = cross_attention(sd, p + ".attn_temp", _ln(sd, p + ".norm_temp", x), None, heads) + x
+    x = x.reshape(b, d, f, c).permute(0, 2, 1, 3).reshape(bf, d, c)
+    return x
+
+
+def transformer3d(sd: SD, p: str, x: torch.Tensor, ctx: torch.Tensor, heads: int, groups: int):
+    """attention.py:89-136 (``use_linear_projection=False`` branch)."""
+    n, c, f, h, w = x.shape
+    x2 = x.permute(0, 2, 1, 3, 4).reshape(n * f, c, h, w)                                      # :93
+    ctx_r = ctx.repeat_interleave(f, dim=0)                                                     # :94
+    res = x2
+    y = F.group_norm(x2, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)            # :58,99
+    y = F.conv2d(y, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])                         # :101
+    y = y.permute(0, 2, 3, 1).reshape(n * f, h * w, c)                                          # :103
+    y = basic_transformer_block(sd, p + ".transformer_blocks.0", y, ctx_r, heads, f)            # :110-116
+    y = y.reshape(n * f, h, w, c).permute(0, 3, 1, 2).contiguous()                              # :120-122
+    y = F.conv2d(y, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])                       # :123
+    y = y + res                                                                                 # :130
+    return y.reshape(n, f, c, h, w).permute(0, 2, 1, 3, 4)                                      # :132
+
+
+def resnet_block3d(sd: SD, p: str, x: torch.Tensor, temb: Optional[torch.Tensor], groups: int, eps: float):
+    """resnet.py:174-204 (time_embedding_norm="default", output_scale_factor=1)."""
+    h = F.group_norm(x, groups, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps)            # :177 (5-D!)
+    h = F.silu(h)                                                                               # :178
+    h = inflated_conv3d(h, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"])                      # :180
+    if temb is not None:                                                                        # :182-186
+        t = F.linear(F.silu(temb), sd[p + ".time_emb_proj.weight"], sd[p + ".time_emb_proj.bias"])
+        h = h + t[:, :, None, None, None]
+    h = F.group_norm(h, groups, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps)            # :188
+    h = F.silu(h)                                                                               # :194
+    h = inflated_conv3d(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"])                      # :197
+    if (p + ".conv_shortcut.weight") in sd:                                                     # :199-200
+        x = inflated_conv3d(x, sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"], padding=0)
+    return x + h                                                                                # :202
+
+
+def upsample3d(sd: SD, p: str, x: torch.Tensor, output_size=None):
+    """resnet.py:41-73."""
+    if output_size is None:
+        x = F.interpolate(x, scale_factor=[1.0, 2.0, 2.0], mode="nearest")                      # :59
+    else:
+        x = F.interpolate(x, size=tuple(output_size), mode="nearest")                           # :61
+    return inflated_conv3d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"])                     # :69
+
+
+def downsample3d(sd: SD, p: str, x: torch.Tensor):
+    """resnet.py:99-107 (stride 2, padding 1)."""
+    return inflated_conv3d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], stride=2, padding=1)
+
+
+# ---------------------------------------------------------------- model ---------------
+def unet3d_forward(sd: SD, cfg, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor,
+                   taps: Optional[dict] = None) -> torch.Tensor:
+    """unet.py:278-413.  ``cfg`` is an ``eeg2video_amd.weights.UNetConfig``-like object.
+    ``taps`` (optional dict) receives named intermediates for per-block parity tests."""
+    boc = cfg.block_out_channels
+    heads, groups, eps = cfg.attention_head_dim, cfg.norm_num_groups, cfg.norm_eps
+    n_up = len(boc) - 1
+    forward_upsample_size = any(s % (2 ** n_up) != 0 for s in sample.shape[-2:])                # :304-312
+
+    t = timestep                                                                                # :324-337
+    if not torch.is_tensor(t):
+        t = torch.tensor([t], dtype=torch.int64)
+    elif t.dim() == 0:
+        t = t[None]
+    t = t.expand(sample.shape[0])
+    t_emb = timestep_sinusoid(t, boc[0], cfg.flip_sin_to_cos, cfg.freq_shift)                   # :339
+    emb = F.linear(t_emb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])   # :345
+    emb = F.linear(F.silu(emb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+    if taps is not None:
+        taps["emb"] = emb
+
+    x = inflated_conv3d(sample, sd["conv_in.weight"], sd["conv_in.bias"])                       # :358
+    skips: List[torch.Tensor] = [x]                                                             # :361
+    for i, typ in enumerate(cfg.down_block_types):                                              # :362-373
+        for j in range(cfg.layers_per_block):
+            x = resnet_block3d(sd, f"down_blocks.{i}.resnets.{j}", x, emb, groups, eps)         # unet_blocks.py:307
+            if typ == "CrossAttnDownBlock3D":
+                x = transformer3d(sd, f"down_blocks.{i}.attentions.{j}", x, encoder_hidden_states, heads, groups)
+            skips.append(x)                                                                     # unet_blocks.py:310
+        if i != len(boc) - 1:
+            x = downsample3d(sd, f"down_blocks.{i}.downsamplers.0", x)                          # unet_blocks.py:312-316
+            skips.append(x)
+        if taps is not None:
+            taps[f"down{i}"] = x
+
+    x = resnet_block3d(sd, "mid_block.resnets.0", x, emb, groups, eps)                          # unet_blocks.py:199-205
+    x = transformer3d(sd, "mid_block.attentions.0", x, encoder_hidden_states, heads, groups)
+    x = resnet_block3d(sd, "mid_block.resnets.1", x, emb, groups, eps)
+    if taps is not None:
+        taps["mid"] = x
+
+    for i, typ in enumerate(cfg.up_block_types):                                                # :381-404
+        n_res = cfg.layers_per_block + 1
+        res, skips = skips[-n_res:], skips[:-n_res]                                             # :384-385
+        is_final = i == len(cfg.up_block_types) - 1
+        up_size = None
+        if not is_final and forward_upsample_size:
+            up_size = skips[-1].shape[2:]                                                       # :389-390
+        for j in range(n_res):
+            x = torch.cat([x, res[-1]], dim=1)                                                  # unet_blocks.py:485-487
+            res = res[:-1]
+            x = resnet_block3d(sd, f"up_blocks.{i}.resnets.{j}", x, emb, groups, eps)
+            if typ == "CrossAttnUpBlock3D":
+                x = transformer3d(sd, f"up_blocks.{i}.attentions.{j}", x, encoder_hidden_states, heads, groups)
+        if not is_final:
+            x = upsample3d(sd, f"up_blocks.{i}.upsamplers.0", x, up_size)                       # unet_blocks.py:510-512
+        if taps is not None:
+            taps[f"up{i}"] = x
+
+    x = F.group_norm(x, groups, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], eps)      # :406
+    x = F.silu(x)                                                                               # :407
+    return inflated_conv3d(x, sd["conv_out.weight"], sd["conv_out.bias"])                       # :408
