@@ -1,0 +1,476 @@
+// extern "C" surface of libeeg2video_hip.so (include/eeg2video_hip.h, include/eeg2video_hip_ops.h).
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/eeg2video_hip_ops.h"
+#include "model.h"
+#include "prof.h"
+
+using namespace e2v;
+
+namespace {
+
+std::string g_create_error;
+
+template <typename Fn>
+e2v_status guarded(e2v_ctx* ctx, Fn&& fn) {
+    try {
+        if (ctx) {
+            E2V_REQUIRE(ctx->device >= 0, E2V_ESTATE, "host-only context (device = -1): no GPU work possible");
+            E2V_HIP(hipSetDevice(ctx->device));
+        }
+        fn();
+        return E2V_OK;
+    } catch (const Error& e) {
+        if (ctx) ctx->err = e.what(); else g_create_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->err = e.what(); else g_create_error = e.what();
+        return E2V_EINVAL;
+    }
+}
+
+float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000) << 16;
+    uint32_t exp = (h >> 10) & 0x1F, man = h & 0x3FF, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {
+            exp = 127 - 15 + 1;
+            while (!(man & 0x400)) { man <<= 1; --exp; }
+            bits = sign | (exp << 23) | ((man & 0x3FF) << 13);
+        }
+    } else if (exp == 31) bits = sign | 0x7F800000u | (man << 13);
+    else bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+void make_alphas(e2v_ctx* c) {
+    const int T = c->cfg.num_train_timesteps;
+    c->alphas.resize(T);
+    const float start = (float)std::sqrt(c->cfg.beta_start), end = (float)std::sqrt(c->cfg.beta_end);
+    const float step = (end - start) / (float)(T - 1);
+    float prod = 1.0f;
+    for (int i = 0; i < T; ++i) {
+        const float b = (i < T / 2) ? start + step * (float)i : end - step * (float)(T - i - 1);
+        prod *= 1.0f - b * b;
+        c->alphas[i] = prod;
+    }
+}
+
+hipStream_t S(e2v_stream s) { return static_cast<hipStream_t>(s); }
+
+}  // namespace
+
+extern "C" {
+
+void e2v_default_config(e2v_config* c) {
+    std::memset(c, 0, sizeof(*c));
+    c->in_channels = 4; c->out_channels = 4;
+    const int boc[4] = {320, 640, 1280, 1280};
+    std::memcpy(c->block_out_channels, boc, sizeof(boc));
+    c->layers_per_block = 2; c->cross_attention_dim = 768; c->attention_heads = 8;
+    c->norm_num_groups = 32; c->norm_eps = 1e-5f; c->flip_sin_to_cos = 1; c->freq_shift = 0.f;
+    c->vae_in_channels = 3; c->vae_latent_channels = 4;
+    const int vb[4] = {128, 256, 512, 512};
+    std::memcpy(c->vae_block_out_channels, vb, sizeof(vb));
+    c->vae_layers_per_block = 2; c->vae_norm_num_groups = 32; c->vae_norm_eps = 1e-6f; c->vae_scaling_factor = 0.18215;
+    c->num_train_timesteps = 1000; c->beta_start = 0.00085; c->beta_end = 0.012; c->steps_offset = 1;
+}
+
+const char* e2v_version(void) { return "eeg2video_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+e2v_status e2v_create(const e2v_config* cfg, int device, e2v_ctx** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return E2V_EINVAL; }
+    *out = nullptr;
+    e2v_ctx* c = nullptr;
+    e2v_status st = guarded(nullptr, [&] {
+        if (device != -1) {      // device = -1: host-only context (key scheme + DDIM schedule), no HIP call at all
+            int ndev = 0;
+            E2V_HIP(hipGetDeviceCount(&ndev));
+            E2V_REQUIRE(device >= 0 && device < ndev, E2V_EINVAL, "no such HIP device");
+            E2V_HIP(hipSetDevice(device));
+        }
+        E2V_REQUIRE(cfg->attention_heads > 0 && cfg->norm_num_groups > 0 && cfg->layers_per_block > 0, E2V_EINVAL, "bad config");
+        for (int i = 0; i < 4; ++i) {
+            E2V_REQUIRE(cfg->block_out_channels[i] % cfg->norm_num_groups == 0 && cfg->block_out_channels[i] % 32 == 0 &&
+                            (cfg->block_out_channels[i] / cfg->attention_heads) % 8 == 0,
+                        E2V_EINVAL, "block_out_channels must be multiples of 32, of norm_num_groups and of 8*heads");
+            E2V_REQUIRE(cfg->vae_block_out_channels[i] % cfg->vae_norm_num_groups == 0 && cfg->vae_block_out_channels[i] % 4 == 0,
+                        E2V_EINVAL, "vae_block_out_channels must be multiples of 4 and of vae_norm_num_groups");
+        }
+        E2V_REQUIRE(cfg->cross_attention_dim % 4 == 0 && cfg->in_channels % 4 == 0, E2V_EINVAL,
+                    "cross_attention_dim and in_channels must be multiples of 4");
+        c = new e2v_ctx();
+        c->cfg = *cfg;
+        c->device = device;
+        c->expected_keys();
+        make_alphas(c);
+    });
+    if (st != E2V_OK) { delete c; return st; }
+    *out = c;
+    return E2V_OK;
+}
+
+void e2v_destroy(e2v_ctx* c) {
+    if (!c) return;
+    if (c->device < 0) { delete c; return; }
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : c->raw) if (kv.second.d) (void)hipFree(kv.second.d);
+    for (float* p : c->owned) (void)hipFree(p);
+    if (c->gn_part) (void)hipFree(c->gn_part);
+    if (c->gn_scale) (void)hipFree(c->gn_scale);
+    if (c->d_timesteps) (void)hipFree(c->d_timesteps);
+    delete c;
+}
+
+const char* e2v_last_error(const e2v_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int64_t e2v_num_expected_keys(const e2v_ctx* c) { return c ? (int64_t)c->keys.size() : 0; }
+
+const char* e2v_expected_key(const e2v_ctx* c, int64_t i, int64_t* shape4, int* ndim) {
+    if (!c || i < 0 || i >= (int64_t)c->keys.size()) return nullptr;
+    const std::string& k = c->keys[(size_t)i];
+    const WTensor& t = c->raw.at(k);
+    if (ndim) *ndim = (int)t.shape.size();
+    if (shape4) for (size_t d = 0; d < 4; ++d) shape4[d] = d < t.shape.size() ? t.shape[d] : 1;
+    return k.c_str();
+}
+
+e2v_status e2v_load_tensor(e2v_ctx* c, const char* key, const void* host, e2v_dtype dtype, const int64_t* shape, int ndim) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(key && host && shape, E2V_EINVAL, "null argument");
+        auto it = c->raw.find(key);
+        E2V_REQUIRE(it != c->raw.end(), E2V_ENOWEIGHT, std::string("unexpected state-dict key: ") + key);
+        WTensor& t = it->second;
+        bool same = (int)t.shape.size() == ndim;
+        for (int d = 0; same && d < ndim; ++d) same = t.shape[d] == shape[d];
+        E2V_REQUIRE(same, E2V_ENOWEIGHT, std::string("shape mismatch for ") + key);
+        if (!t.d) {
+            E2V_HIP(hipMalloc((void**)&t.d, t.numel * sizeof(float)));
+            c->weight_bytes += t.numel * sizeof(float);
+        }
+        if (dtype == E2V_F32) {
+            E2V_HIP(hipMemcpy(t.d, host, t.numel * sizeof(float), hipMemcpyHostToDevice));
+        } else if (dtype == E2V_F16) {
+            std::vector<float> tmp(t.numel);
+            const uint16_t* h = static_cast<const uint16_t*>(host);
+            for (size_t i = 0; i < t.numel; ++i) tmp[i] = half_to_float(h[i]);
+            E2V_HIP(hipMemcpy(t.d, tmp.data(), t.numel * sizeof(float), hipMemcpyHostToDevice));
+        } else {
+            throw Error(E2V_EINVAL, "unsupported dtype");
+        }
+        t.loaded = true;
+    });
+}
+
+e2v_status e2v_finalize_weights(e2v_ctx* c, int which) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(which >= 1 && which <= 3, E2V_EINVAL, "which must be 1 (UNet), 2 (VAE) or 3");
+        c->finalize(which);
+    });
+}
+
+e2v_status e2v_ddim_timesteps(const e2v_ctx* c, int n, int64_t* out) {
+    if (!c || !out || n <= 0 || n > c->cfg.num_train_timesteps) return E2V_EINVAL;
+    const int64_t ratio = c->cfg.num_train_timesteps / n;            // step_ratio = T // n
+    for (int i = 0; i < n; ++i) out[i] = (int64_t)(n - 1 - i) * ratio + c->cfg.steps_offset;
+    return E2V_OK;
+}
+
+e2v_status e2v_ddim_alphas_cumprod(const e2v_ctx* c, float* out) {
+    if (!c || !out) return E2V_EINVAL;
+    std::memcpy(out, c->alphas.data(), c->alphas.size() * sizeof(float));
+    return E2V_OK;
+}
+
+e2v_status e2v_set_alphas_cumprod(e2v_ctx* c, const float* t, int n) {
+    if (!c || !t || n != c->cfg.num_train_timesteps) return E2V_EINVAL;
+    c->alphas.assign(t, t + n);
+    return E2V_OK;
+}
+
+e2v_status e2v_profile_begin(e2v_ctx* c) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] { E2V_HIP(hipDeviceSynchronize()); profiler().begin(); });
+}
+
+int64_t e2v_profile_end(e2v_ctx* c, char* json, int64_t cap) {
+    if (!c || !json || cap <= 0) return -1;
+    const std::string s = profiler().end_json();
+    const int64_t n = (int64_t)s.size() < cap - 1 ? (int64_t)s.size() : cap - 1;
+    std::memcpy(json, s.data(), (size_t)n);
+    json[n] = 0;
+    return (int64_t)s.size();
+}
+
+int64_t e2v_device_bytes(const e2v_ctx* c) { return c ? (int64_t)(c->weight_bytes + c->pool.bytes()) : 0; }
+
+// ---------------------------------------------------------------------------------------------------
+e2v_status e2v_unet_forward(e2v_ctx* c, const float* sample, const int64_t* host_t, int n_t, const float* cond, int N,
+                            int F, int H, int W, int T, float* out, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(sample && host_t && cond && out, E2V_EINVAL, "null argument");
+        E2V_REQUIRE(N > 0 && F > 0 && H > 0 && W > 0 && T > 0, E2V_ESHAPE, "non-positive dimension");
+        hipStream_t s = S(stream);
+        const int Cin = c->cfg.in_channels, Cout = c->cfg.out_channels;
+        const int FHW = F * H * W;
+        Act x(c->pool, (int64_t)N * FHW, Cin);
+        ncfhw_to_cl(sample, x.p, N, Cin, Cin, FHW, 1.0f, s);
+        Act y = c->unet_forward_cl(x.p, host_t, n_t, cond, N, F, H, W, T, s);
+        cl_to_ncfhw(y.p, Cout, out, N, Cout, FHW, 1.0f, 0.0f, 0, 0.f, 0.f, s);
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+static void ddim_coeffs(const e2v_ctx* c, int64_t t, int64_t t_prev, float co[4]) {
+    E2V_REQUIRE(t >= 0 && t < (int64_t)c->alphas.size() && t_prev < (int64_t)c->alphas.size(), E2V_EINVAL, "timestep out of range");
+    const float a_t = c->alphas[(size_t)t];
+    const float a_p = t_prev >= 0 ? c->alphas[(size_t)t_prev] : c->alphas[0];   // final_alpha_cumprod (set_alpha_to_one = False)
+    co[0] = std::sqrt(a_t);
+    co[1] = std::sqrt(1.0f - a_t);
+    co[2] = std::sqrt(a_p);
+    co[3] = std::sqrt(1.0f - a_p);
+}
+
+e2v_status e2v_ddim_cfg_step(e2v_ctx* c, const float* eu, const float* ec, const float* x, float* xo, int64_t count,
+                             float g, int64_t t, int64_t t_prev, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(eu && x && xo && count >= 0, E2V_EINVAL, "null argument");
+        float co[4];
+        ddim_coeffs(c, t, t_prev, co);
+        ddim_cfg_step(eu, ec, x, xo, count, g, co[0], co[1], co[2], co[3], S(stream));
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+static void decode_to_video(e2v_ctx* c, const float* z_cl, int B, int F, int h, int w, int post, float* videos, hipStream_t s) {
+    const int HW8 = 64 * h * w;
+    const int C3 = c->cfg.vae_in_channels;
+    Act frames(c->pool, (int64_t)B * F * HW8, C3);
+    for (int b = 0; b < B; ++b)        // one clip (F frames) per pass keeps the workspace at ~1 clip
+        c->vae_decode_frames(z_cl + (size_t)b * F * h * w * c->cfg.vae_latent_channels, F, h, w,
+                             frames.p + (size_t)b * F * HW8 * C3, s);
+    nchw_frames_to_ncfhw(frames.p, C3, videos, B, F, C3, HW8, post ? 0.5f : 1.0f, post ? 0.5f : 0.0f, post ? 1 : 0, s);
+}
+
+e2v_status e2v_vae_decode(e2v_ctx* c, const float* latents, int B, int F, int h, int w, int post, float* videos,
+                          e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(latents && videos, E2V_EINVAL, "null argument");
+        E2V_REQUIRE(B > 0 && F > 0 && h > 0 && w > 0, E2V_ESHAPE, "non-positive dimension");
+        hipStream_t s = S(stream);
+        const int lat = c->cfg.vae_latent_channels;
+        Act z(c->pool, (int64_t)B * F * h * w, lat);
+        ncfhw_to_cl(latents, z.p, B, lat, lat, F * h * w, post ? (float)(1.0 / c->cfg.vae_scaling_factor) : 1.0f, s);   // :177
+        decode_to_video(c, z.p, B, F, h, w, post, videos, s);
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+e2v_status e2v_vae_encode(e2v_ctx* c, const float* images, int n, int H, int W, float* mean, float* logvar, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(images && mean && logvar, E2V_EINVAL, "null argument");
+        E2V_REQUIRE(n > 0 && H % 8 == 0 && W % 8 == 0 && H > 0 && W > 0, E2V_ESHAPE, "H and W must be positive multiples of 8");
+        hipStream_t s = S(stream);
+        const int Cimg = c->cfg.vae_in_channels, Cp = c->vae.enc_in.cin_pad, lat = c->cfg.vae_latent_channels;
+        Act x(c->pool, (int64_t)n * H * W, Cp);
+        ncfhw_to_cl(images, x.p, n, Cimg, Cp, H * W, 1.0f, s);
+        const int hw = (H / 8) * (W / 8);
+        Act m(c->pool, (int64_t)n * hw, 2 * lat);
+        c->vae_encode_frames(x.p, n, H, W, m.p, s);
+        cl_to_ncfhw(m.p, 2 * lat, mean, n, lat, hw, 1.f, 0.f, 0, 0.f, 0.f, s);
+        cl_to_ncfhw(m.p + lat, 2 * lat, logvar, n, lat, hw, 1.f, 0.f, 1, -30.f, 20.f, s);
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+e2v_status e2v_generate(e2v_ctx* c, const float* latents, const float* cond, const float* uncond, int Bu, int B, int F,
+                        int h, int w, int T, int steps, float guidance, float eta, float* videos, float* latents_out,
+                        e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(latents && cond, E2V_EINVAL, "null argument");
+        E2V_REQUIRE(B > 0 && F > 0 && h > 0 && w > 0 && T > 0, E2V_ESHAPE, "non-positive dimension");
+        E2V_REQUIRE(steps > 0 && steps <= c->cfg.num_train_timesteps, E2V_EINVAL, "num_inference_steps out of range");
+        E2V_REQUIRE(eta == 0.0f, E2V_EINVAL, "only the deterministic DDIM update (eta = 0) is implemented");
+        const bool cfg_on = guidance > 1.0f;                                     // pipeline_tuneeeg2video.py:281
+        E2V_REQUIRE(!cfg_on || (uncond && (Bu == 1 || Bu == B)), E2V_EINVAL, "uncond must have batch 1 or B");
+        hipStream_t s = S(stream);
+        const int Cl = c->cfg.in_channels, D = c->cfg.cross_attention_dim;
+        const int P = F * h * w;
+        const size_t per = (size_t)P * Cl;
+        const int N = cfg_on ? 2 * B : B;
+
+        Act x(c->pool, (int64_t)B * P, Cl);
+        ncfhw_to_cl(latents, x.p, B, Cl, Cl, P, 1.0f, s);                        // init_noise_sigma = 1 (:244)
+        Act emb;                                                                 // [uncond ; cond] (:162-172)
+        const float* embp = cond;
+        if (cfg_on) {
+            emb = Act(c->pool, (int64_t)N * T, D);
+            const size_t one = (size_t)T * D;
+            if (Bu == B) E2V_HIP(hipMemcpyAsync(emb.p, uncond, one * B * sizeof(float), hipMemcpyDeviceToDevice, s));
+            else for (int b = 0; b < B; ++b)
+                E2V_HIP(hipMemcpyAsync(emb.p + b * one, uncond, one * sizeof(float), hipMemcpyDeviceToDevice, s));
+            E2V_HIP(hipMemcpyAsync(emb.p + B * one, cond, one * B * sizeof(float), hipMemcpyDeviceToDevice, s));
+            embp = emb.p;
+        }
+        std::vector<int64_t> ts(steps);
+        e2v_ddim_timesteps(c, steps, ts.data());                                 // :287-288
+        const int64_t ratio = c->cfg.num_train_timesteps / steps;
+        Act xin;
+        if (cfg_on) xin = Act(c->pool, (int64_t)N * P, Cl);
+        for (int i = 0; i < steps; ++i) {                                        // :311
+            const float* in = x.p;
+            if (cfg_on) {                                                        // latent_model_input = cat([latents]*2) (:313)
+                E2V_HIP(hipMemcpyAsync(xin.p, x.p, per * B * sizeof(float), hipMemcpyDeviceToDevice, s));
+                E2V_HIP(hipMemcpyAsync(xin.p + per * B, x.p, per * B * sizeof(float), hipMemcpyDeviceToDevice, s));
+                in = xin.p;
+            }
+            Act eps = c->unet_forward_cl(in, &ts[i], 1, embp, N, F, h, w, T, s);  // :317
+            float co[4];
+            ddim_coeffs(c, ts[i], ts[i] - ratio, co);
+            ddim_cfg_step(eps.p, cfg_on ? eps.p + per * B : nullptr, x.p, x.p, (long long)(per * B), guidance, co[0], co[1],
+                          co[2], co[3], s);                                      // :320-325
+        }
+        if (latents_out) cl_to_ncfhw(x.p, Cl, latents_out, B, Cl, P, 1.f, 0.f, 0, 0.f, 0.f, s);
+        if (videos) {                                                            // decode_latents (:175-184)
+            Act z(c->pool, (int64_t)B * P, Cl);
+            const float inv = (float)(1.0 / c->cfg.vae_scaling_factor);
+            ncfhw_to_cl(x.p, z.p, 1, 1, 1, (int)(per * B), inv, s);      // z = 1 / 0.18215 * latents (:177), flat scale
+            decode_to_video(c, z.p, B, F, h, w, 1, videos, s);
+        }
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernel-level entry points (eeg2video_hip_ops.h)
+// ---------------------------------------------------------------------------------------------------
+e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, int c1, int n_img, int Hs, int Ws, int Hi,
+                          int Wi, int Ho, int Wo, int stride, int pad_lo, const float* w_oihw, const float* bias, int cout,
+                          const float* rowbias, int rows_per_sample, const float* resid, float* out, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(x0 && w_oihw && out && c0 % 4 == 0 && c1 % 4 == 0 && c0 > 0, E2V_EINVAL, "bad conv arguments");
+        hipStream_t s = S(stream);
+        const int cin = c0 + c1;
+        Act wp(c->pool, (int64_t)cout * 9, cin);
+        pack_conv3x3(w_oihw, wp.p, cout, cin, cin, s);
+        IgemmArgs g;
+        g.a0 = x0; g.c0 = c0; g.lda0 = c0; g.a1 = x1; g.c1 = c1; g.lda1 = c1;
+        g.w = wp.p; g.ldw = 9 * cin; g.out = out; g.ldc = cout; g.bias = bias;
+        g.rowbias = rowbias; g.rb_ld = cout; g.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+        g.resid = resid; g.ldr = cout; g.M = n_img * Ho * Wo; g.N = cout; g.taps = 9;
+        g.Ho = Ho; g.Wo = Wo; g.Hi = Hi; g.Wi = Wi; g.Hs = Hs; g.Ws = Ws; g.stride = stride; g.pad = pad_lo;
+        if (Hi != Hs || Wi != Ws) { g.upsample = 1; g.ups_h = (float)Hs / (float)Hi; g.ups_w = (float)Ws / (float)Wi; }
+        igemm(g, s);
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+e2v_status e2v_op_linear(e2v_ctx* c, const float* x, int ldx, int64_t M, int K, const float* w, const float* bias, int N,
+                         const float* resid, int geglu, float* out, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(x && w && out && K % 4 == 0 && ldx % 4 == 0, E2V_EINVAL, "bad linear arguments");
+        hipStream_t s = S(stream);
+        IgemmArgs g;
+        g.a0 = x; g.c0 = K; g.lda0 = ldx; g.ldw = K; g.out = out; g.M = (int)M; g.taps = 1; g.resid = resid;
+        Act wp, bp;
+        if (geglu) {
+            E2V_REQUIRE(N % 32 == 0 && bias, E2V_EINVAL, "GEGLU width must be a multiple of 32 and have a bias");
+            wp = Act(c->pool, 2 * N, K);
+            bp = Act(c->pool, 1, 2 * N);
+            for (int q = 0; q < N / 32; ++q) {
+                copy_rows(w + (size_t)(q * 32) * K, K, wp.p + (size_t)(q * 64) * K, K, 32, K, s);
+                copy_rows(w + (size_t)(N + q * 32) * K, K, wp.p + (size_t)(q * 64 + 32) * K, K, 32, K, s);
+                copy_rows(bias + q * 32, 32, bp.p + q * 64, 32, 1, 32, s);
+                copy_rows(bias + N + q * 32, 32, bp.p + q * 64 + 32, 32, 1, 32, s);
+            }
+            g.w = wp.p; g.bias = bp.p; g.N = 2 * N; g.ldc = N; g.geglu = 1;
+        } else {
+            g.w = w; g.bias = bias; g.N = N; g.ldc = N; g.ldr = N;
+        }
+        igemm(g, s);
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+e2v_status e2v_op_groupnorm(e2v_ctx* c, const float* x0, int c0, const float* x1, int c1, int samples, int P, int groups,
+                            float eps, const float* gamma, const float* beta, int act, float* out, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        const int C = c0 + c1;
+        E2V_REQUIRE(x0 && gamma && beta && out && c0 % 4 == 0 && c1 % 4 == 0 && C % groups == 0, E2V_EINVAL, "bad groupnorm arguments");
+        hipStream_t s = S(stream);
+        Act part(c->pool, (int64_t)samples * groupnorm_chunks(P), C * 2);
+        Act sc(c->pool, samples, C * 2);
+        GroupNormArgs a;
+        a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1; a.ld0 = c0; a.ld1 = c1; a.gamma = gamma; a.beta = beta;
+        a.out = out; a.ldo = C; a.samples = samples; a.P = P; a.groups = groups; a.eps = eps; a.silu = act;
+        a.ws_part = part.p; a.ws_scale = sc.p;
+        groupnorm(a, s);
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+e2v_status e2v_op_layernorm(e2v_ctx* c, const float* x, int64_t rows, int C, const float* gamma, const float* beta, float eps,
+                            float* out, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(x && gamma && beta && out && C % 4 == 0 && C <= 1280, E2V_EINVAL, "bad layernorm arguments");
+        layernorm(x, C, gamma, beta, out, C, (int)rows, C, eps, S(stream));
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+e2v_status e2v_op_attention(e2v_ctx* c, const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,
+                            int n, int F, int heads, int D, int Nq, int Nk, int mode, float scale, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(q && k && v && o, E2V_EINVAL, "null argument");
+        E2V_REQUIRE(D == 8 || D == 16 || D == 32 || D == 40 || D == 64 || D == 80 || D == 160, E2V_EINVAL,
+                    "head dim must be one of 8, 16, 32, 40, 64, 80, 160");
+        E2V_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && Nq > 0 && Nk > 0, E2V_EINVAL, "bad strides / sizes");
+        E2V_REQUIRE(mode == 1 || Nq == Nk, E2V_ESHAPE, "self-attention needs Nq == Nk");
+        AttnArgs a;
+        a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv; a.o = o; a.ldo = ldo; a.n = n; a.F = F; a.heads = heads; a.D = D;
+        a.Nq = Nq; a.Nk = Nk; a.mode = mode; a.scale = scale;
+        flash_attention(a, S(stream));
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+e2v_status e2v_op_temporal_attention(e2v_ctx* c, const float* qkv, float* out, int n, int F, int HW, int heads, int D,
+                                     float scale, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(qkv && out && F <= 8 && D % 4 == 0, E2V_EINVAL, "bad temporal attention arguments");
+        const int C = heads * D;
+        temporal_attention(qkv, 3 * C, out, C, n, F, HW, heads, D, scale, S(stream));
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+e2v_status e2v_op_to_channels_last(e2v_ctx* c, const float* in, float* out, int n, int C, int Cpad, int FHW, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] { ncfhw_to_cl(in, out, n, C, Cpad, FHW, 1.0f, S(stream)); E2V_HIP(hipGetLastError()); });
+}
+
+e2v_status e2v_op_from_channels_last(e2v_ctx* c, const float* in, int ld, float* out, int n, int C, int FHW, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] { cl_to_ncfhw(in, ld, out, n, C, FHW, 1.f, 0.f, 0, 0.f, 0.f, S(stream)); E2V_HIP(hipGetLastError()); });
+}
+
+}  // extern "C"

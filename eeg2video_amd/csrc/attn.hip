@@ -1,0 +1,323 @@
+// Fused fp32 attention for the three attentions of BasicTransformerBlock (attention.py:232-269).
+//
+// flash_attention: sparse-causal self-attention (attn1, attention.py:272-328) and cross-attention to
+// the cond tokens (attn2).  The reference gathers and concatenates K/V of frame 0 and frame i-1
+// (attention.py:292-301) and materialises a [48, N, 2N] score tensor per sample; here the two key
+// segments are walked in place with an online softmax, nothing is concatenated or materialised.
+// Frames 0 and 1 both see [K0; K0]; softmax over a duplicated key set equals softmax over the set,
+// so they walk frame 0 once.
+//
+// MFMA mapping (v_mfma_f32_32x32x2_f32, exact fp32): one wave owns 32 queries.  S^T = K Q^T puts the
+// QUERY on the lane (C/D column) and the 32 keys of the tile in the 16 accumulator registers of the
+// two lane halves, so the row max / row sum of the online softmax are per-lane scalars (one
+// cross-half exchange), and P^T is already in the B-operand layout of O^T = V^T P^T: no LDS round
+// trip, no transposes.  K and V tiles (32 keys) are staged through LDS, double-buffered.
+#include "kernels.h"
+#include "prof.h"
+
+namespace e2v {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int D>
+__global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs p) {
+    constexpr int LD = D + 4;               // padded LDS row: conflict-free ds_read_b128 of 16 rows
+    constexpr int T = (D + 31) / 32;        // 32-wide dv tiles of O^T
+    constexpr int G = D / 8;
+    constexpr int DQ = D / 4;
+    constexpr int NF4 = 32 * DQ;
+    constexpr int LPT = (NF4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buf][K | V][32][LD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int sf = blockIdx.z;
+    const int smp = sf / p.F, f = sf - smp * p.F;
+    const int head = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const bool active = q0 < p.Nq;
+
+    int nseg = 1;
+    size_t kvbase[2];
+    if (p.mode == 0) {
+        kvbase[0] = (size_t)(smp * p.F) * p.Nk;
+        kvbase[1] = (size_t)(smp * p.F + (f > 0 ? f - 1 : 0)) * p.Nk;
+        nseg = f >= 2 ? 2 : 1;
+    } else {
+        kvbase[0] = kvbase[1] = (size_t)smp * p.Nk;
+    }
+    const int tps = (p.Nk + 31) / 32;
+    const int ntiles = nseg * tps;
+
+    // Q fragments, pre-multiplied by scale * log2(e): scores live in the exp2 domain
+    f32x4 qf[G];
+    {
+        const int qrow = min(q0 + j, p.Nq - 1);
+        const float* qp = p.q + ((size_t)sf * p.Nq + qrow) * p.ldq + head * D + h * 4;
+        const float c = p.scale * 1.44269504088896340736f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            qf[g] = *reinterpret_cast<const f32x4*>(qp + g * 8);
+            qf[g] *= c;
+        }
+    }
+
+    f32x4 kreg[LPT], vreg[LPT];
+    auto load_tile = [&](int tt) {
+        const int seg = tt / tps;
+        const int key0 = (tt - seg * tps) * 32;
+#pragma unroll
+        for (int e = 0; e < LPT; ++e) {
+            const int idx = tid + 256 * e;
+            f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (idx < NF4) {
+                const int row = idx / DQ, c4 = idx - row * DQ;
+                const int key = key0 + row;
+                if (key < p.Nk) {
+                    const size_t off = (kvbase[seg] + key) * p.ldkv + head * D + c4 * 4;
+                    kk = *reinterpret_cast<const f32x4*>(p.k + off);
+                    vv = *reinterpret_cast<const f32x4*>(p.v + off);
+                }
+            }
+            kreg[e] = kk;
+            vreg[e] = vv;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* Ks = smem + buf * (2 * 32 * LD);
+        float* Vs = Ks + 32 * LD;
+#pragma unroll
+        for (int e = 0; e < LPT; ++e) {
+            const int idx = tid + 256 * e;
+            if (idx < NF4) {
+                const int row = idx / DQ, c4 = idx - row * DQ;
+                *reinterpret_cast<f32x4*>(Ks + row * LD + c4 * 4) = kreg[e];
+                *reinterpret_cast<f32x4*>(Vs + row * LD + c4 * 4) = vreg[e];
+            }
+        }
+    };
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int tt = 0; tt < ntiles; ++tt) {
+        const int buf = tt & 1;
+        if (tt + 1 < ntiles) load_tile(tt + 1);
+        if (active) {
+            const float* Ks = smem + buf * (2 * 32 * LD);
+            const float* Vs = Ks + 32 * LD;
+            const int seg = tt / tps;
+            const int key0 = (tt - seg * tps) * 32;
+            // S^T[key][query] = sum_d K[key][d] Q[query][d]
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            const float* kp = Ks + j * LD + h * 4;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + g * 8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[g][s], st, 0, 0, 0);
+            }
+            // online softmax; register r of lane half h holds key  key0 + (r&3) + 8(r>>2) + 4h
+            float mt = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (key >= p.Nk) st[r] = -INFINITY;
+                mt = fmaxf(mt, st[r]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = fmaxf(m_i, mt);
+            const float alpha = exp2f(m_i - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = exp2f(st[r] - m_new);
+                ps += st[r];
+            }
+            l_i = l_i * alpha + ps;
+            m_i = m_new;
+            // O^T[dv][query] += sum_key V[key][dv] P[query][key]
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+                const int dv = min(t * 32 + j, D - 1);
+                const float* vp = Vs + (4 * h) * LD + dv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float vv = vp[((r & 3) + 8 * (r >> 2)) * LD];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[r], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        if (tt + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // lanes l and l+32 hold the two key halves of the same query: fold the partial row sums
+    const float l_tot = l_i + __shfl_xor(l_i, 32);
+    if (active && q0 + j < p.Nq) {
+        const float inv = 1.0f / l_tot;
+        float* op = p.o + ((size_t)sf * p.Nq + q0 + j) * p.ldo + head * D;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int dv = t * 32 + 8 * rg + 4 * h;
+                if (dv < D) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[t][rg * 4 + e] * inv;
+                    *reinterpret_cast<f32x4*>(op + dv) = o;
+                }
+            }
+    }
+}
+
+template <int D>
+static void launch_flash(const AttnArgs& a, hipStream_t s) {
+    static bool configured = false;
+    constexpr size_t smem = (size_t)2 * 2 * 32 * (D + 4) * sizeof(float);
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_kernel<D>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        configured = true;
+    }
+    dim3 grid((a.Nq + 127) / 128, a.heads, a.n * a.F);
+    const double nk = a.mode == 0 ? 2.0 * a.Nk : (double)a.Nk;       // the reference attends to 2N concatenated keys
+    const double probs = (double)a.n * a.F * a.heads;
+    ProfScope ps(a.mode == 0 ? "flash_attn_sparse_causal" : "flash_attn_cross", 4.0 * probs * a.Nq * nk * D,
+                 4.0 * probs * D * (2.0 * a.Nq + 2.0 * (a.mode == 0 ? a.Nk : (double)a.Nk / a.F)), s);
+    hipLaunchKernelGGL((flash_attn_kernel<D>), grid, dim3(256), smem, s, a);
+}
+
+void flash_attention(const AttnArgs& a, hipStream_t s) {
+    switch (a.D) {
+        case 8: launch_flash<8>(a, s); break;
+        case 16: launch_flash<16>(a, s); break;
+        case 32: launch_flash<32>(a, s); break;
+        case 40: launch_flash<40>(a, s); break;
+        case 64: launch_flash<64>(a, s); break;
+        case 80: launch_flash<80>(a, s); break;
+        case 160: launch_flash<160>(a, s); break;
+        default: break;   // rejected by the host wrapper before it gets here
+    }
+}
+
+// ---- temporal attention: F x F per (pixel, head); tokens stay where they are --------------------------
+// The reference transposes (b f) d c -> (b d) f c and back (attention.py:262,267); with channel-last
+// rows (sample, frame, pixel) the F rows of one pixel are HW rows apart and are read in place.
+static constexpr int FMAX = 8;
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restrict__ qkv, int ld, float* __restrict__ out,
+                                                            int ldo, int n, int F, int HW, int heads, int D, float scale) {
+    const size_t total = (size_t)n * HW * heads * F;
+    const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int i = gid % F;
+    const int head = (gid / F) % heads;
+    const size_t ph = gid / ((size_t)F * heads);
+    const int pix = ph % HW;
+    const int smp = ph / HW;
+    const int C = heads * D;
+    const size_t row0 = (size_t)smp * F * HW + pix;          // frame 0 row; frame f is f*HW rows further
+    const float* qp = qkv + (row0 + (size_t)i * HW) * ld + head * D;
+    const float* kp = qkv + row0 * ld + C + head * D;
+    const float* vp = qkv + row0 * ld + 2 * C + head * D;
+    const size_t fstride = (size_t)HW * ld;
+    float s[FMAX];
+#pragma unroll
+    for (int jf = 0; jf < FMAX; ++jf) s[jf] = 0.f;
+    for (int c = 0; c < D; c += 4) {
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + c);
+#pragma unroll
+        for (int jf = 0; jf < FMAX; ++jf)
+            if (jf < F) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + jf * fstride + c);
+                s[jf] += qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
+            }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int jf = 0; jf < FMAX; ++jf)
+        if (jf < F) {
+            s[jf] *= scale;
+            m = fmaxf(m, s[jf]);
+        }
+    float l = 0.f;
+#pragma unroll
+    for (int jf = 0; jf < FMAX; ++jf)
+        if (jf < F) {
+            s[jf] = expf(s[jf] - m);
+            l += s[jf];
+        }
+    const float inv = 1.0f / l;
+    float* op = out + (row0 + (size_t)i * HW) * ldo + head * D;
+    for (int c = 0; c < D; c += 4) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jf = 0; jf < FMAX; ++jf)
+            if (jf < F) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(vp + jf * fstride + c);
+                o += vv * (s[jf] * inv);
+            }
+        *reinterpret_cast<f32x4*>(op + c) = o;
+    }
+}
+
+void temporal_attention(const float* qkv, int ld, float* out, int ldo, int n, int F, int HW, int heads, int D, float scale,
+                        hipStream_t s) {
+    const size_t total = (size_t)n * HW * heads * F;
+    if (!total) return;
+    ProfScope ps("temporal_attn", 4.0 * total * F * D, 4.0 * 4.0 * (double)n * F * HW * heads * D, s);
+    hipLaunchKernelGGL(temporal_attn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv, ld, out, ldo, n, F, HW,
+                       heads, D, scale);
+}
+
+// ---- row softmax in place (single-head VAE attention, 2304 keys, fp32 as the dep computes it) ----------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int ld, int rows, int cols) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    float* xr = x + (size_t)row * ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, xr[c]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float l = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float e = expf(xr[c] - m);
+        xr[c] = e;
+        l += e;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off);
+    if (lane == 0) red[wave] = l;
+    __syncthreads();
+    l = (red[0] + red[1]) + (red[2] + red[3]);
+    const float inv = 1.0f / l;
+    for (int c = threadIdx.x; c < cols; c += 256) xr[c] *= inv;
+}
+
+void softmax_rows(float* x, int ld, int rows, int cols, hipStream_t s) {
+    if (rows <= 0) return;
+    ProfScope ps("softmax_rows", 8.0 * rows * cols, 2.0 * 4.0 * rows * (double)cols, s);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, x, ld, rows, cols);
+}
+
+}  // namespace e2v

@@ -1,0 +1,153 @@
+// Element-wise and layout kernels of the path (all HBM-bound, grid-stride, 16-byte lanes where the
+// layout allows): boundary layout conversion NCFHW <-> channel-last, the fused classifier-free
+// guidance + DDIM update, the timestep sinusoid, SiLU, and a tiled transpose for the VAE attention.
+#include "kernels.h"
+#include "prof.h"
+
+namespace e2v {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int grid_for(size_t total, int cap = 8192) {
+    size_t b = (total + 255) / 256;
+    return (int)(b < (size_t)cap ? (b ? b : 1) : cap);
+}
+
+// in [n][C][FHW] -> out [n][FHW][Cpad] (extra channels zero), times `scale`
+__global__ void ncfhw_to_cl_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int C, int Cpad, int FHW,
+                                   float scale) {
+    const size_t total = (size_t)n * FHW * Cpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % Cpad;
+        const size_t r = i / Cpad;
+        const int p = r % FHW;
+        const int b = r / FHW;
+        out[i] = c < C ? in[((size_t)b * C + c) * FHW + p] * scale : 0.f;
+    }
+}
+void ncfhw_to_cl(const float* in, float* out, int n, int C, int Cpad, int FHW, float scale, hipStream_t s) {
+    const size_t total = (size_t)n * FHW * Cpad;
+    hipLaunchKernelGGL(ncfhw_to_cl_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, n, C, Cpad, FHW, scale);
+}
+
+// in [n][FHW][ld] (first C channels) -> out [n][C][FHW]; y = x*mul + add, optional clamp to [0,1]
+__global__ void cl_to_ncfhw_kernel(const float* __restrict__ in, int ld, float* __restrict__ out, int n, int C, int FHW,
+                                   float mul, float add, int clamp, float lo, float hi) {
+    const size_t total = (size_t)n * C * FHW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = i % FHW;
+        const size_t r = i / FHW;
+        const int c = r % C;
+        const int b = r / C;
+        float v = in[((size_t)b * FHW + p) * ld + c] * mul + add;
+        if (clamp) v = fminf(fmaxf(v, lo), hi);
+        out[i] = v;
+    }
+}
+void cl_to_ncfhw(const float* in, int ld, float* out, int n, int C, int FHW, float mul, float add, int clamp, float lo,
+                 float hi, hipStream_t s) {
+    const size_t total = (size_t)n * C * FHW;
+    hipLaunchKernelGGL(cl_to_ncfhw_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, ld, out, n, C, FHW, mul, add, clamp, lo,
+                       hi);
+}
+
+// frames decoded as (b f) images, channel-last [n*F][HW][ld] -> video [n][C][F][HW]
+// ('(b f) c h w -> b c f h w' of pipeline_tuneeeg2video.py:180, then (v/2+0.5).clamp(0,1) of :181)
+__global__ void frames_to_ncfhw_kernel(const float* __restrict__ in, int ld, float* __restrict__ out, int n, int F, int C,
+                                       int HW, float mul, float add, int clamp01) {
+    const size_t total = (size_t)n * C * F * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = i % HW;
+        size_t r = i / HW;
+        const int f = r % F; r /= F;
+        const int c = r % C;
+        const int b = r / C;
+        float v = in[(((size_t)b * F + f) * HW + p) * ld + c] * mul + add;
+        if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+        out[i] = v;
+    }
+}
+void nchw_frames_to_ncfhw(const float* in, int ld, float* out, int n, int F, int C, int HW, float mul, float add, int clamp01,
+                          hipStream_t s) {
+    const size_t total = (size_t)n * C * F * HW;
+    hipLaunchKernelGGL(frames_to_ncfhw_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, ld, out, n, F, C, HW, mul, add,
+                       clamp01);
+}
+
+// diffusers get_timestep_embedding: w_i = exp(-ln(10000) i / (half - shift)),
+// emb = [sin(t w), cos(t w)], swapped to [cos, sin] when flip_sin_to_cos.  t has nt entries (1 = broadcast).
+__global__ void timestep_sinusoid_kernel(const long long* __restrict__ t, int nt, float* __restrict__ out, int n, int dim,
+                                         int flip, float shift) {
+    const int half = dim / 2;
+    const int total = n * half;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / half, k = i - b * half;
+        const float tv = (float)t[nt == 1 ? 0 : b];
+        const float expo = (-9.210340371976184f * (float)k) / ((float)half - shift);
+        const float arg = tv * expf(expo);
+        const float sv = sinf(arg), cv = cosf(arg);
+        float* o = out + (size_t)b * dim;
+        if (flip) { o[k] = cv; o[half + k] = sv; } else { o[k] = sv; o[half + k] = cv; }
+    }
+}
+void timestep_sinusoid(const long long* t, int nt, float* out, int n, int dim, int flip, float shift, hipStream_t s) {
+    hipLaunchKernelGGL(timestep_sinusoid_kernel, dim3(grid_for((size_t)n * dim / 2)), dim3(256), 0, s, t, nt, out, n, dim, flip,
+                       shift);
+}
+
+__global__ void silu_kernel(const float* __restrict__ in, float* __restrict__ out, size_t count) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = in[i];
+        out[i] = v / (1.0f + expf(-v));
+    }
+}
+void silu(const float* in, float* out, long long count, hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(silu_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, s, in, out, (size_t)count);
+}
+
+// out[b][c][r] = in[b][r][c], 32x32 LDS tiles
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
+                                                        int ld_out, int rows, int cols, long long sb_in, long long sb_out) {
+    __shared__ float tile[32][33];
+    const float* src = in + (size_t)blockIdx.z * sb_in;
+    float* dst = out + (size_t)blockIdx.z * sb_out;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < cols && r < rows) dst[(size_t)c * ld_out + r] = tile[tx][k];
+    }
+}
+void transpose2d(const float* in, int ld_in, float* out, int ld_out, int rows, int cols, int batch, long long sb_in,
+                 long long sb_out, hipStream_t s) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, ld_in, out, ld_out, rows, cols, sb_in, sb_out);
+}
+
+// pipeline_tuneeeg2video.py:320-325 fused: guidance, then DDIM (eta = 0):
+//   x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);  x' = sqrt(a_p) x0 + sqrt(1-a_p) eps
+// eps_c == nullptr: no guidance (guidance_scale <= 1), eps = eps_u.
+__global__ void ddim_cfg_step_kernel(const float* __restrict__ eu, const float* __restrict__ ec, const float* __restrict__ x,
+                                     float* __restrict__ xo, size_t count, float g, float sa, float sb, float sap, float sbp) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        float e = eu[i];
+        if (ec) e = e + g * (ec[i] - e);
+        const float x0 = (x[i] - sb * e) / sa;
+        xo[i] = sap * x0 + sbp * e;
+    }
+}
+void ddim_cfg_step(const float* eps_u, const float* eps_c, const float* x, float* x_out, long long count, float guidance,
+                   float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_p, float sqrt_1m_a_p, hipStream_t s) {
+    if (count <= 0) return;
+    ProfScope ps("ddim_cfg_step", 8.0 * count, 4.0 * count * (eps_c ? 4.0 : 3.0), s);
+    hipLaunchKernelGGL(ddim_cfg_step_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, s, eps_u, eps_c, x, x_out,
+                       (size_t)count, guidance, sqrt_a_t, sqrt_1m_a_t, sqrt_a_p, sqrt_1m_a_p);
+}
+
+}  // namespace e2v

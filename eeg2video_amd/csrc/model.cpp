@@ -1,0 +1,677 @@
+// Model graphs of the EEG2Video generation hot path on one HIP stream (see model.h).
+#include "model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+using namespace e2v;
+
+// =====================================================================================================
+// expected state-dict keys (SURVEY App. D for the UNet, App. C.5 for the VAE) -- mirrors
+// eeg2video_amd/weights.py; the test-suite checks both against the reference's own state dict.
+// =====================================================================================================
+namespace {
+
+struct KeySink {
+    e2v_ctx* c;
+    void add(const std::string& k, std::vector<int64_t> shape) {
+        WTensor t;
+        t.shape = std::move(shape);
+        t.numel = 1;
+        for (auto d : t.shape) t.numel *= (size_t)d;
+        c->keys.push_back(k);
+        c->raw.emplace(k, std::move(t));
+    }
+    void conv(const std::string& n, int co, int ci, int k) { add(n + ".weight", {co, ci, k, k}); add(n + ".bias", {co}); }
+    void lin(const std::string& n, int co, int ci, bool bias = true) {
+        add(n + ".weight", {co, ci});
+        if (bias) add(n + ".bias", {co});
+    }
+    void norm(const std::string& n, int ch) { add(n + ".weight", {ch}); add(n + ".bias", {ch}); }
+    void resnet3d(const std::string& p, int cin, int cout, int temb) {      // resnet.py:141-172
+        norm(p + ".norm1", cin); conv(p + ".conv1", cout, cin, 3);
+        if (temb > 0) lin(p + ".time_emb_proj", cout, temb);
+        norm(p + ".norm2", cout); conv(p + ".conv2", cout, cout, 3);
+        if (cin != cout) conv(p + ".conv_shortcut", cout, cin, 1);
+    }
+    void transformer3d(const std::string& p, int ch, int cross) {            // attention.py:58-87,158-202
+        norm(p + ".norm", ch); conv(p + ".proj_in", ch, ch, 1);
+        const std::string b = p + ".transformer_blocks.0";
+        const char* names[3] = {"attn1", "attn2", "attn_temp"};
+        const int kv[3] = {ch, cross, ch};
+        for (int i = 0; i < 3; ++i) {
+            const std::string a = b + "." + names[i];
+            lin(a + ".to_q", ch, ch, false); lin(a + ".to_k", ch, kv[i], false); lin(a + ".to_v", ch, kv[i], false);
+            lin(a + ".to_out.0", ch, ch);
+        }
+        for (const char* n : {"norm1", "norm2", "norm3", "norm_temp"}) norm(b + "." + n, ch);
+        lin(b + ".ff.net.0.proj", 8 * ch, ch); lin(b + ".ff.net.2", ch, 4 * ch);
+        conv(p + ".proj_out", ch, ch, 1);
+    }
+    void vae_mid(const std::string& p, int ch) {
+        resnet3d(p + ".resnets.0", ch, ch, 0);
+        const std::string a = p + ".attentions.0";
+        norm(a + ".group_norm", ch);
+        for (const char* n : {"query", "key", "value", "proj_attn"}) lin(a + "." + n, ch, ch);
+        resnet3d(p + ".resnets.1", ch, ch, 0);
+    }
+};
+
+std::string idx(const std::string& a, int i, const std::string& b, int j) {
+    return a + "." + std::to_string(i) + "." + b + "." + std::to_string(j);
+}
+
+}  // namespace
+
+void e2v_ctx::expected_keys() {
+    KeySink s{this};
+    const int* boc = cfg.block_out_channels;
+    const int temb = boc[0] * 4, cross = cfg.cross_attention_dim, L = cfg.layers_per_block;
+    s.conv("conv_in", boc[0], cfg.in_channels, 3);
+    s.lin("time_embedding.linear_1", temb, boc[0]);
+    s.lin("time_embedding.linear_2", temb, temb);
+    int out_c = boc[0];
+    for (int i = 0; i < 4; ++i) {                      // unet.py:113-139; blocks 0-2 carry attention
+        const int in_c = out_c;
+        out_c = boc[i];
+        for (int j = 0; j < L; ++j) {
+            s.resnet3d(idx("down_blocks", i, "resnets", j), j == 0 ? in_c : out_c, out_c, temb);
+            if (i < 3) s.transformer3d(idx("down_blocks", i, "attentions", j), out_c, cross);
+        }
+        if (i != 3) s.conv("down_blocks." + std::to_string(i) + ".downsamplers.0.conv", out_c, out_c, 3);
+    }
+    s.resnet3d("mid_block.resnets.0", boc[3], boc[3], temb);
+    s.transformer3d("mid_block.attentions.0", boc[3], cross);
+    s.resnet3d("mid_block.resnets.1", boc[3], boc[3], temb);
+    const int rev[4] = {boc[3], boc[2], boc[1], boc[0]};
+    out_c = rev[0];
+    for (int i = 0; i < 4; ++i) {                      // unet.py:164-202; blocks 1-3 carry attention
+        const int prev = out_c;
+        out_c = rev[i];
+        const int in_c = rev[std::min(i + 1, 3)];
+        for (int j = 0; j < L + 1; ++j) {
+            const int skip = (j == L) ? in_c : out_c;  // unet_blocks.py:431-432
+            const int rin = (j == 0) ? prev : out_c;
+            s.resnet3d(idx("up_blocks", i, "resnets", j), rin + skip, out_c, temb);
+            if (i > 0) s.transformer3d(idx("up_blocks", i, "attentions", j), out_c, cross);
+        }
+        if (i != 3) s.conv("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out_c, out_c, 3);
+    }
+    s.norm("conv_norm_out", boc[0]);
+    s.conv("conv_out", cfg.out_channels, boc[0], 3);
+
+    // ---- VAE ("vae." prefix) ----
+    const int* vb = cfg.vae_block_out_channels;
+    const int VL = cfg.vae_layers_per_block, lat = cfg.vae_latent_channels;
+    s.conv("vae.encoder.conv_in", vb[0], cfg.vae_in_channels, 3);
+    out_c = vb[0];
+    for (int i = 0; i < 4; ++i) {
+        const int in_c = out_c;
+        out_c = vb[i];
+        for (int j = 0; j < VL; ++j) s.resnet3d(idx("vae.encoder.down_blocks", i, "resnets", j), j == 0 ? in_c : out_c, out_c, 0);
+        if (i != 3) s.conv("vae.encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", out_c, out_c, 3);
+    }
+    s.vae_mid("vae.encoder.mid_block", vb[3]);
+    s.norm("vae.encoder.conv_norm_out", vb[3]);
+    s.conv("vae.encoder.conv_out", 2 * lat, vb[3], 3);
+    const int vrev[4] = {vb[3], vb[2], vb[1], vb[0]};
+    s.conv("vae.decoder.conv_in", vrev[0], lat, 3);
+    s.vae_mid("vae.decoder.mid_block", vrev[0]);
+    out_c = vrev[0];
+    for (int i = 0; i < 4; ++i) {
+        const int in_c = out_c;
+        out_c = vrev[i];
+        for (int j = 0; j < VL + 1; ++j) s.resnet3d(idx("vae.decoder.up_blocks", i, "resnets", j), j == 0 ? in_c : out_c, out_c, 0);
+        if (i != 3) s.conv("vae.decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out_c, out_c, 3);
+    }
+    s.norm("vae.decoder.conv_norm_out", vb[0]);
+    s.conv("vae.decoder.conv_out", cfg.vae_in_channels, vb[0], 3);
+    s.conv("vae.quant_conv", 2 * lat, 2 * lat, 1);
+    s.conv("vae.post_quant_conv", lat, lat, 1);
+}
+
+float* e2v_ctx::dev_alloc(size_t floats) {
+    void* p = nullptr;
+    E2V_HIP(hipMalloc(&p, std::max<size_t>(floats, 1) * sizeof(float)));
+    owned.push_back(static_cast<float*>(p));
+    weight_bytes += floats * sizeof(float);
+    return static_cast<float*>(p);
+}
+
+// =====================================================================================================
+// finalize: torch layouts -> kernel layouts
+// =====================================================================================================
+namespace {
+
+struct Packer {
+    e2v_ctx* c;
+    hipStream_t s = nullptr;
+    const WTensor& t(const std::string& k) {
+        auto it = c->raw.find(k);
+        E2V_REQUIRE(it != c->raw.end(), E2V_ENOWEIGHT, "unknown key " + k);
+        E2V_REQUIRE(it->second.loaded, E2V_ENOWEIGHT, "state-dict key not loaded: " + k);
+        return it->second;
+    }
+    NormW norm(const std::string& n) { return NormW{t(n + ".weight").d, t(n + ".bias").d, (int)t(n + ".weight").shape[0]}; }
+    LinW lin(const std::string& n, bool bias = true) {       // Linear or 1x1 conv: [out][in] as it is
+        const WTensor& w = t(n + ".weight");
+        return LinW{w.d, bias ? t(n + ".bias").d : nullptr, (int)w.shape[1], (int)w.shape[0]};
+    }
+    ConvW conv3(const std::string& n) {                      // [O][I][3][3] -> [O][tap][I padded to 4]
+        const WTensor& w = t(n + ".weight");
+        const int co = (int)w.shape[0], ci = (int)w.shape[1];
+        const int cp = (ci + 3) / 4 * 4;
+        float* d = c->dev_alloc((size_t)co * 9 * cp);
+        pack_conv3x3(w.d, d, co, ci, cp, s);
+        return ConvW{d, t(n + ".bias").d, ci, cp, co};
+    }
+    LinW fuse_rows(const std::vector<std::string>& names, bool bias) {   // stack Linear weights along `out`
+        int in = 0, out = 0;
+        for (auto& n : names) { const WTensor& w = t(n + ".weight"); in = (int)w.shape[1]; out += (int)w.shape[0]; }
+        float* d = c->dev_alloc((size_t)out * in);
+        float* b = bias ? c->dev_alloc(out) : nullptr;
+        int r = 0;
+        for (auto& n : names) {
+            const WTensor& w = t(n + ".weight");
+            copy_rows(w.d, in, d + (size_t)r * in, in, (int)w.shape[0], in, s);
+            if (bias) copy_rows(t(n + ".bias").d, (int)w.shape[0], b + r, (int)w.shape[0], 1, (int)w.shape[0], s);
+            r += (int)w.shape[0];
+        }
+        return LinW{d, b, in, out};
+    }
+    LinW geglu(const std::string& n) {        // rows [value 0..4C) | gate 0..4C)] -> per 64: [32 value | 32 gate]
+        const WTensor& w = t(n + ".weight");
+        const WTensor& bsrc = t(n + ".bias");
+        const int out = (int)w.shape[0], in = (int)w.shape[1], half = out / 2;
+        E2V_REQUIRE(half % 32 == 0, E2V_EINVAL, "GEGLU inner width must be a multiple of 32");
+        float* d = c->dev_alloc((size_t)out * in);
+        float* b = c->dev_alloc(out);
+        for (int q = 0; q < half / 32; ++q) {
+            copy_rows(w.d + (size_t)(q * 32) * in, in, d + (size_t)(q * 64) * in, in, 32, in, s);
+            copy_rows(w.d + (size_t)(half + q * 32) * in, in, d + (size_t)(q * 64 + 32) * in, in, 32, in, s);
+            copy_rows(bsrc.d + q * 32, 32, b + q * 64, 32, 1, 32, s);
+            copy_rows(bsrc.d + half + q * 32, 32, b + q * 64 + 32, 32, 1, 32, s);
+        }
+        return LinW{d, b, in, out};
+    }
+    ResW resnet(const std::string& p, bool temb) {
+        ResW r;
+        r.n1 = norm(p + ".norm1"); r.c1 = conv3(p + ".conv1");
+        if (temb) r.temb = lin(p + ".time_emb_proj");
+        r.n2 = norm(p + ".norm2"); r.c2 = conv3(p + ".conv2");
+        r.cin = r.c1.cin; r.cout = r.c1.cout;
+        if (c->raw.count(p + ".conv_shortcut.weight")) r.sc = lin(p + ".conv_shortcut");
+        return r;
+    }
+    TransW transformer(const std::string& p) {
+        TransW w;
+        const std::string b = p + ".transformer_blocks.0";
+        w.norm = norm(p + ".norm"); w.proj_in = lin(p + ".proj_in"); w.proj_out = lin(p + ".proj_out");
+        w.ln1 = norm(b + ".norm1"); w.ln2 = norm(b + ".norm2"); w.ln3 = norm(b + ".norm3"); w.lnt = norm(b + ".norm_temp");
+        w.a1_qkv = fuse_rows({b + ".attn1.to_q", b + ".attn1.to_k", b + ".attn1.to_v"}, false);
+        w.a1_out = lin(b + ".attn1.to_out.0");
+        w.a2_q = lin(b + ".attn2.to_q", false);
+        w.a2_kv = fuse_rows({b + ".attn2.to_k", b + ".attn2.to_v"}, false);
+        w.a2_out = lin(b + ".attn2.to_out.0");
+        w.ff1 = geglu(b + ".ff.net.0.proj"); w.ff2 = lin(b + ".ff.net.2");
+        w.at_qkv = fuse_rows({b + ".attn_temp.to_q", b + ".attn_temp.to_k", b + ".attn_temp.to_v"}, false);
+        w.at_out = lin(b + ".attn_temp.to_out.0");
+        w.C = w.norm.c;
+        return w;
+    }
+    VAEAttnW vae_attn(const std::string& a) {
+        VAEAttnW w;
+        w.norm = norm(a + ".group_norm");
+        w.qkv = fuse_rows({a + ".query", a + ".key", a + ".value"}, true);
+        w.proj = lin(a + ".proj_attn");
+        w.C = w.norm.c;
+        return w;
+    }
+};
+
+}  // namespace
+
+void e2v_ctx::finalize(int which) {
+    Packer P{this};
+    const int L = cfg.layers_per_block;
+    if (which & 1) {
+        UNetW u;
+        u.conv_in = P.conv3("conv_in");
+        u.te1 = P.lin("time_embedding.linear_1"); u.te2 = P.lin("time_embedding.linear_2");
+        for (int i = 0; i < 4; ++i) {
+            UNetW::Block b;
+            for (int j = 0; j < L; ++j) {
+                b.res.push_back(P.resnet(idx("down_blocks", i, "resnets", j), true));
+                if (i < 3) b.attn.push_back(P.transformer(idx("down_blocks", i, "attentions", j)));
+            }
+            if (i != 3) { b.resample = true; b.rs = P.conv3("down_blocks." + std::to_string(i) + ".downsamplers.0.conv"); }
+            u.down.push_back(std::move(b));
+        }
+        u.mid_r0 = P.resnet("mid_block.resnets.0", true);
+        u.mid_attn = P.transformer("mid_block.attentions.0");
+        u.mid_r1 = P.resnet("mid_block.resnets.1", true);
+        for (int i = 0; i < 4; ++i) {
+            UNetW::Block b;
+            for (int j = 0; j < L + 1; ++j) {
+                b.res.push_back(P.resnet(idx("up_blocks", i, "resnets", j), true));
+                if (i > 0) b.attn.push_back(P.transformer(idx("up_blocks", i, "attentions", j)));
+            }
+            if (i != 3) { b.resample = true; b.rs = P.conv3("up_blocks." + std::to_string(i) + ".upsamplers.0.conv"); }
+            u.up.push_back(std::move(b));
+        }
+        u.norm_out = P.norm("conv_norm_out");
+        u.conv_out = P.conv3("conv_out");
+        unet = std::move(u);
+    }
+    if (which & 2) {
+        VAEW v;
+        const int VL = cfg.vae_layers_per_block;
+        v.post_quant = P.lin("vae.post_quant_conv");
+        v.dec_in = P.conv3("vae.decoder.conv_in");
+        v.dec_mid0 = P.resnet("vae.decoder.mid_block.resnets.0", false);
+        v.dec_attn = P.vae_attn("vae.decoder.mid_block.attentions.0");
+        v.dec_mid1 = P.resnet("vae.decoder.mid_block.resnets.1", false);
+        for (int i = 0; i < 4; ++i) {
+            VAEW::Block b;
+            for (int j = 0; j < VL + 1; ++j) b.res.push_back(P.resnet(idx("vae.decoder.up_blocks", i, "resnets", j), false));
+            if (i != 3) { b.resample = true; b.rs = P.conv3("vae.decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv"); }
+            v.dec_up.push_back(std::move(b));
+        }
+        v.dec_norm_out = P.norm("vae.decoder.conv_norm_out");
+        v.dec_out = P.conv3("vae.decoder.conv_out");
+        v.quant = P.lin("vae.quant_conv");
+        v.enc_in = P.conv3("vae.encoder.conv_in");
+        for (int i = 0; i < 4; ++i) {
+            VAEW::Block b;
+            for (int j = 0; j < VL; ++j) b.res.push_back(P.resnet(idx("vae.encoder.down_blocks", i, "resnets", j), false));
+            if (i != 3) { b.resample = true; b.rs = P.conv3("vae.encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv"); }
+            v.enc_down.push_back(std::move(b));
+        }
+        v.enc_mid0 = P.resnet("vae.encoder.mid_block.resnets.0", false);
+        v.enc_attn = P.vae_attn("vae.encoder.mid_block.attentions.0");
+        v.enc_mid1 = P.resnet("vae.encoder.mid_block.resnets.1", false);
+        v.enc_norm_out = P.norm("vae.encoder.conv_norm_out");
+        v.enc_out = P.conv3("vae.encoder.conv_out");
+        vae = std::move(v);
+    }
+    E2V_HIP(hipStreamSynchronize(nullptr));
+    E2V_HIP(hipGetLastError());
+    // the torch-layout copies of re-laid-out tensors are no longer needed
+    auto drop = [&](const std::string& k) {
+        auto it = raw.find(k);
+        if (it != raw.end() && it->second.d) {
+            (void)hipFree(it->second.d);
+            weight_bytes -= it->second.numel * sizeof(float);
+            it->second.d = nullptr;
+            it->second.loaded = false;
+        }
+    };
+    for (const auto& k : keys) {
+        const bool is_vae = k.rfind("vae.", 0) == 0;
+        if ((is_vae && !(which & 2)) || (!is_vae && !(which & 1))) continue;
+        const WTensor& w = raw[k];
+        const bool conv3 = w.shape.size() == 4 && w.shape[2] == 3;
+        const bool fused = k.find(".to_q.") != std::string::npos || k.find(".to_k.") != std::string::npos ||
+                           k.find(".to_v.") != std::string::npos || k.find(".ff.net.0.proj.") != std::string::npos ||
+                           k.find(".query.") != std::string::npos || k.find(".key.") != std::string::npos ||
+                           k.find(".value.") != std::string::npos;
+        const bool keep_q = k.find(".attn2.to_q.") != std::string::npos;
+        if ((conv3 || fused) && !keep_q) drop(k);
+    }
+    if (which & 1) unet_ready = true;
+    if (which & 2) vae_ready = true;
+}
+
+// =====================================================================================================
+// graph runner
+// =====================================================================================================
+namespace {
+
+struct Geo { int nimg, H, W; };     // images (= n*F frames) and their map size
+
+struct Runner {
+    e2v_ctx* c;
+    hipStream_t s;
+    Pool& pool() { return c->pool; }
+
+    void gn_ws(int samples, int P, int C) {
+        const size_t need_p = (size_t)samples * groupnorm_chunks(P) * C * 2;
+        const size_t need_s = (size_t)samples * C * 2;
+        if (need_p > c->gn_part_floats) {
+            E2V_HIP(hipStreamSynchronize(s));
+            if (c->gn_part) (void)hipFree(c->gn_part);
+            E2V_HIP(hipMalloc((void**)&c->gn_part, need_p * sizeof(float)));
+            c->gn_part_floats = need_p;
+        }
+        if (need_s > c->gn_scale_floats) {
+            E2V_HIP(hipStreamSynchronize(s));
+            if (c->gn_scale) (void)hipFree(c->gn_scale);
+            E2V_HIP(hipMalloc((void**)&c->gn_scale, need_s * sizeof(float)));
+            c->gn_scale_floats = need_s;
+        }
+    }
+
+    Act gn(const NormW& w, const float* x0, int c0, const float* x1, int c1, int samples, int P, int groups, float eps,
+           bool act) {
+        const int C = c0 + c1;
+        E2V_REQUIRE(C == w.c && C % groups == 0 && c0 % 4 == 0 && c1 % 4 == 0, E2V_ESHAPE, "GroupNorm channel mismatch");
+        gn_ws(samples, P, C);
+        Act out(pool(), (int64_t)samples * P, C);
+        GroupNormArgs a;
+        a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1; a.ld0 = c0; a.ld1 = c1;
+        a.gamma = w.g; a.beta = w.b; a.out = out.p; a.ldo = C;
+        a.samples = samples; a.P = P; a.groups = groups; a.eps = eps; a.silu = act ? 1 : 0;
+        a.ws_part = c->gn_part; a.ws_scale = c->gn_scale;
+        groupnorm(a, s);
+        return out;
+    }
+
+    Act ln(const NormW& w, const Act& x) {
+        E2V_REQUIRE(x.C == w.c && x.C % 4 == 0 && x.C <= 1280, E2V_ESHAPE, "LayerNorm width unsupported");
+        Act out(pool(), x.rows, x.C);
+        layernorm(x.p, x.C, w.g, w.b, out.p, x.C, (int)x.rows, x.C, 1e-5f, s);
+        return out;
+    }
+
+    // out[M][N] = A[M][K] W^T + b (+ resid); geglu: out[M][N/2]
+    Act linear(const LinW& w, const float* a, int lda, int64_t M, const float* resid = nullptr, int ldr = 0,
+               bool geglu = false, const float* a1 = nullptr, int c1 = 0, int lda1 = 0) {
+        const int K0 = w.in - c1;
+        E2V_REQUIRE(K0 > 0 && K0 % 4 == 0 && c1 % 4 == 0 && lda % 4 == 0, E2V_ESHAPE, "linear: K must be a multiple of 4");
+        Act out(pool(), M, geglu ? w.out / 2 : w.out);
+        IgemmArgs g;
+        g.a0 = a; g.c0 = K0; g.lda0 = lda; g.a1 = a1; g.c1 = c1; g.lda1 = lda1;
+        g.w = w.w; g.ldw = w.in; g.out = out.p; g.ldc = out.C; g.bias = w.b;
+        g.resid = resid; g.ldr = ldr; g.M = (int)M; g.N = w.out; g.taps = 1; g.geglu = geglu ? 1 : 0;
+        igemm(g, s);
+        return out;
+    }
+
+    // 3x3 conv over `geo.nimg` images; (Hi, Wi) = logical input size (after nearest resize), (Ho, Wo) output size
+    Act conv3(const ConvW& w, const float* x0, int c0, const float* x1, int c1, Geo geo, int Hi, int Wi, int Ho, int Wo,
+              int stride, int pad, const float* rowbias = nullptr, int rows_per_sample = 1, const float* resid = nullptr) {
+        E2V_REQUIRE(c0 + c1 == w.cin_pad, E2V_ESHAPE, "conv: input channels do not match the weight");
+        Act out(pool(), (int64_t)geo.nimg * Ho * Wo, w.cout);
+        IgemmArgs g;
+        g.a0 = x0; g.c0 = c0; g.lda0 = c0; g.a1 = x1; g.c1 = c1; g.lda1 = c1;
+        g.w = w.w; g.ldw = 9 * w.cin_pad; g.out = out.p; g.ldc = w.cout; g.bias = w.b;
+        g.rowbias = rowbias; g.rb_ld = w.cout; g.rows_per_sample = rows_per_sample;
+        g.resid = resid; g.ldr = w.cout;
+        g.M = (int)out.rows; g.N = w.cout; g.taps = 9;
+        g.Ho = Ho; g.Wo = Wo; g.Hi = Hi; g.Wi = Wi; g.Hs = geo.H; g.Ws = geo.W; g.stride = stride; g.pad = pad;
+        if (Hi != geo.H || Wi != geo.W) {
+            g.upsample = 1;
+            g.ups_h = (float)geo.H / (float)Hi;        // torch: scale = (float)input_size / output_size
+            g.ups_w = (float)geo.W / (float)Wi;
+        }
+        igemm(g, s);
+        return out;
+    }
+
+    // ResnetBlock3D.forward (resnet.py:174-204); x1 = skip tensor concatenated on channels (may be null).
+    // samples x P rows share GroupNorm statistics and one time-embedding row; geo describes the frames.
+    Act resnet(const ResW& w, const float* x0, int c0, const float* x1, int c1, int samples, int P, Geo geo, int groups,
+               float eps, const float* temb_silu, int temb_dim) {
+        E2V_REQUIRE(c0 + c1 == w.cin, E2V_ESHAPE, "resnet: channel mismatch");
+        Act tp;
+        if (w.temb.w) {
+            E2V_REQUIRE(temb_silu != nullptr, E2V_EINVAL, "resnet needs a time embedding");
+            tp = linear(w.temb, temb_silu, temb_dim, samples);                                        // :183
+        }
+        Act h1;
+        {
+            Act hn = gn(w.n1, x0, c0, x1, c1, samples, P, groups, eps, true);                        // :177-178
+            h1 = conv3(w.c1, hn.p, w.cin, nullptr, 0, geo, geo.H, geo.W, geo.H, geo.W, 1, 1,          // :180,186
+                       tp.p, P);
+        }
+        Act h2 = gn(w.n2, h1.p, w.cout, nullptr, 0, samples, P, groups, eps, true);                  // :188,194
+        h1.reset();
+        Act sc;
+        const float* resid = x0;
+        if (w.sc.w) {                                                                                 // :199-200
+            sc = linear(w.sc, x0, c0, (int64_t)samples * P, nullptr, 0, false, x1, c1, c1);
+            resid = sc.p;
+        } else {
+            E2V_REQUIRE(c1 == 0, E2V_ESHAPE, "identity shortcut with a concatenated input");
+        }
+        return conv3(w.c2, h2.p, w.cout, nullptr, 0, geo, geo.H, geo.W, geo.H, geo.W, 1, 1, nullptr, 1, resid);   // :197,202
+    }
+
+    // Transformer3DModel.forward + BasicTransformerBlock.forward (attention.py:89-136, 232-269)
+    Act transformer(const TransW& w, const Act& x, int n, int F, int HW, const float* cond, int T, int heads, int groups) {
+        const int C = w.C, D = C / heads;
+        const int64_t rows = (int64_t)n * F * HW;
+        const float scale = 1.0f / std::sqrt((float)D);
+        E2V_REQUIRE(C % heads == 0 && D % 8 == 0, E2V_EINVAL, "attention head dim must be a multiple of 8");
+        Act t;
+        {
+            Act hn = gn(w.norm, x.p, C, nullptr, 0, n * F, HW, groups, 1e-6f, false);                 // :99 (per frame)
+            t = linear(w.proj_in, hn.p, C, rows);                                                     // :101-103
+        }
+        {   // attn1: sparse-causal self-attention                                                      :234-243
+            Act nrm = ln(w.ln1, t);
+            Act qkv = linear(w.a1_qkv, nrm.p, C, rows);
+            nrm.reset();
+            Act ao(pool(), rows, C);
+            AttnArgs a;
+            a.q = qkv.p; a.ldq = 3 * C; a.k = qkv.p + C; a.v = qkv.p + 2 * C; a.ldkv = 3 * C; a.o = ao.p; a.ldo = C;
+            a.n = n; a.F = F; a.heads = heads; a.D = D; a.Nq = HW; a.Nk = HW; a.mode = 0; a.scale = scale;
+            flash_attention(a, s);
+            qkv.reset();
+            t = linear(w.a1_out, ao.p, C, rows, t.p, C);
+        }
+        {   // attn2: cross-attention to the cond tokens (identical for the F frames of a sample)         :245-255
+            Act nrm = ln(w.ln2, t);
+            Act q = linear(w.a2_q, nrm.p, C, rows);
+            nrm.reset();
+            Act kv = linear(w.a2_kv, cond, w.a2_kv.in, (int64_t)n * T);
+            Act ao(pool(), rows, C);
+            AttnArgs a;
+            a.q = q.p; a.ldq = C; a.k = kv.p; a.v = kv.p + C; a.ldkv = 2 * C; a.o = ao.p; a.ldo = C;
+            a.n = n; a.F = F; a.heads = heads; a.D = D; a.Nq = HW; a.Nk = T; a.mode = 1; a.scale = scale;
+            flash_attention(a, s);
+            t = linear(w.a2_out, ao.p, C, rows, t.p, C);
+        }
+        {   // GEGLU feed-forward                                                                          :258
+            Act nrm = ln(w.ln3, t);
+            Act hgate = linear(w.ff1, nrm.p, C, rows, nullptr, 0, true);
+            nrm.reset();
+            t = linear(w.ff2, hgate.p, 4 * C, rows, t.p, C);
+        }
+        {   // temporal attention over the F frames of each pixel                                         :261-267
+            E2V_REQUIRE(F <= 8, E2V_EINVAL, "temporal attention supports at most 8 frames");
+            Act nrm = ln(w.lnt, t);
+            Act qkv = linear(w.at_qkv, nrm.p, C, rows);
+            nrm.reset();
+            Act ao(pool(), rows, C);
+            temporal_attention(qkv.p, 3 * C, ao.p, C, n, F, HW, heads, D, scale, s);
+            qkv.reset();
+            t = linear(w.at_out, ao.p, C, rows, t.p, C);
+        }
+        return linear(w.proj_out, t.p, C, rows, x.p, C);                                              // :123,130
+    }
+
+    // AttentionBlock of the VAE mid block (diffusers 0.11.1): one head over H*W tokens, per image
+    Act vae_attention(const VAEAttnW& w, const Act& x, int nimg, int HW, int groups, float eps) {
+        const int C = w.C;
+        E2V_REQUIRE(HW % 4 == 0, E2V_EINVAL, "VAE attention needs H*W to be a multiple of 4");
+        const int64_t rows = (int64_t)nimg * HW;
+        Act qkv;
+        {
+            Act hn = gn(w.norm, x.p, C, nullptr, 0, nimg, HW, groups, eps, false);
+            qkv = linear(w.qkv, hn.p, C, rows);
+        }
+        Act sc(pool(), rows, HW);
+        {
+            IgemmArgs g;
+            g.a0 = qkv.p; g.c0 = C; g.lda0 = 3 * C; g.w = qkv.p + C; g.ldw = 3 * C;
+            g.out = sc.p; g.ldc = HW; g.M = HW; g.N = HW; g.taps = 1; g.alpha = 1.0f / std::sqrt((float)C);
+            g.batch = nimg; g.sa0 = (long long)HW * 3 * C; g.sw = (long long)HW * 3 * C; g.sout = (long long)HW * HW;
+            igemm(g, s);
+        }
+        softmax_rows(sc.p, HW, (int)rows, HW, s);
+        Act vt(pool(), (int64_t)nimg * C, HW);
+        transpose2d(qkv.p + 2 * C, 3 * C, vt.p, HW, HW, C, nimg, (long long)HW * 3 * C, (long long)C * HW, s);
+        qkv.reset();
+        Act o(pool(), rows, C);
+        {
+            IgemmArgs g;
+            g.a0 = sc.p; g.c0 = HW; g.lda0 = HW; g.w = vt.p; g.ldw = HW; g.out = o.p; g.ldc = C;
+            g.M = HW; g.N = C; g.taps = 1; g.batch = nimg;
+            g.sa0 = (long long)HW * HW; g.sw = (long long)C * HW; g.sout = (long long)HW * C;
+            igemm(g, s);
+        }
+        return linear(w.proj, o.p, C, rows, x.p, C);
+    }
+};
+
+int down_size(int x) { return (x - 1) / 2 + 1; }     // 3x3, stride 2, padding 1
+
+}  // namespace
+
+// -----------------------------------------------------------------------------------------------------
+// UNet3DConditionModel.forward (unet.py:278-413), channel-last in and out
+// -----------------------------------------------------------------------------------------------------
+Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int n_t, const float* cond, int N, int F,
+                             int H, int W, int T, hipStream_t s) {
+    E2V_REQUIRE(unet_ready, E2V_ESTATE, "UNet weights are not finalized");
+    E2V_REQUIRE(n_t == 1 || n_t == N, E2V_EINVAL, "timesteps must have 1 or N entries");
+    Runner R{this, s};
+    const int heads = cfg.attention_heads, groups = cfg.norm_num_groups;
+    const float eps = cfg.norm_eps;
+    const int boc0 = cfg.block_out_channels[0], temb_dim = boc0 * 4;
+
+    // time embedding (unet.py:324-345): sinusoid -> linear_1 -> SiLU -> linear_2; resnets consume SiLU(emb)
+    if (d_timesteps_cap < N) {
+        E2V_HIP(hipStreamSynchronize(s));
+        if (d_timesteps) (void)hipFree(d_timesteps);
+        E2V_HIP(hipMalloc((void**)&d_timesteps, sizeof(long long) * N));
+        d_timesteps_cap = N;
+    }
+    static_assert(sizeof(long long) == sizeof(int64_t), "int64");
+    E2V_HIP(hipMemcpyAsync(d_timesteps, host_t, sizeof(int64_t) * n_t, hipMemcpyHostToDevice, s));
+    Act temb_silu;
+    {
+        Act sin(pool, N, boc0);
+        timestep_sinusoid(d_timesteps, n_t, sin.p, N, boc0, cfg.flip_sin_to_cos, cfg.freq_shift, s);
+        Act e1 = R.linear(unet.te1, sin.p, boc0, N);
+        silu(e1.p, e1.p, (long long)N * temb_dim, s);
+        Act emb = R.linear(unet.te2, e1.p, temb_dim, N);
+        silu(emb.p, emb.p, (long long)N * temb_dim, s);
+        temb_silu = std::move(emb);
+    }
+
+    int hs[4], ws[4];
+    hs[0] = H; ws[0] = W;
+    for (int i = 1; i < 4; ++i) { hs[i] = down_size(hs[i - 1]); ws[i] = down_size(ws[i - 1]); }
+
+    struct Skip { Act a; int lvl; };
+    std::vector<Skip> skips;
+    skips.reserve(16);
+    auto P_of = [&](int l) { return F * hs[l] * ws[l]; };
+    auto geo_of = [&](int l) { return Geo{N * F, hs[l], ws[l]}; };
+
+    Act x = R.conv3(unet.conv_in, sample_cl, unet.conv_in.cin_pad, nullptr, 0, geo_of(0), H, W, H, W, 1, 1);   // :358
+    // The skip tensors alias the running activation in the reference; here the running tensor is moved
+    // into the skip list and read from there (no copy) -- `x` then points at the list's last entry.
+    auto keep = [&](Act&& a, int lvl) -> const Act& {
+        skips.push_back(Skip{std::move(a), lvl});
+        return skips.back().a;
+    };
+    const Act* cur = &keep(std::move(x), 0);                                                         // :361
+    for (int i = 0; i < 4; ++i) {                                                                    // :362-373
+        const UNetW::Block& b = unet.down[i];
+        for (size_t j = 0; j < b.res.size(); ++j) {
+            Act h = R.resnet(b.res[j], cur->p, cur->C, nullptr, 0, N, P_of(i), geo_of(i), groups, eps, temb_silu.p, temb_dim);
+            if (!b.attn.empty()) h = R.transformer(b.attn[j], h, N, F, hs[i] * ws[i], cond, T, heads, groups);
+            cur = &keep(std::move(h), i);
+        }
+        if (b.resample) {                                                                            // resnet.py:99-107
+            Act d = R.conv3(b.rs, cur->p, cur->C, nullptr, 0, geo_of(i), hs[i], ws[i], hs[i + 1], ws[i + 1], 2, 1);
+            cur = &keep(std::move(d), i + 1);
+        }
+    }
+    // mid (unet_blocks.py:199-205)
+    Act h = R.resnet(unet.mid_r0, cur->p, cur->C, nullptr, 0, N, P_of(3), geo_of(3), groups, eps, temb_silu.p, temb_dim);
+    h = R.transformer(unet.mid_attn, h, N, F, hs[3] * ws[3], cond, T, heads, groups);
+    h = R.resnet(unet.mid_r1, h.p, h.C, nullptr, 0, N, P_of(3), geo_of(3), groups, eps, temb_silu.p, temb_dim);
+    // up (unet.py:381-404)
+    for (int i = 0; i < 4; ++i) {
+        const UNetW::Block& b = unet.up[i];
+        const int lvl = 3 - i;
+        for (size_t j = 0; j < b.res.size(); ++j) {
+            E2V_REQUIRE(!skips.empty() && skips.back().lvl == lvl, E2V_ESTATE, "skip bookkeeping out of step");
+            Skip sk = std::move(skips.back());                                                       // unet_blocks.py:485-487
+            skips.pop_back();
+            Act o = R.resnet(b.res[j], h.p, h.C, sk.a.p, sk.a.C, N, P_of(lvl), geo_of(lvl), groups, eps, temb_silu.p, temb_dim);
+            if (!b.attn.empty()) o = R.transformer(b.attn[j], o, N, F, hs[lvl] * ws[lvl], cond, T, heads, groups);
+            h = std::move(o);
+        }
+        if (b.resample) {   // Upsample3D: nearest to the next skip's (f,h,w) then 3x3 conv (resnet.py:58-69, unet.py:389-390)
+            h = R.conv3(b.rs, h.p, h.C, nullptr, 0, geo_of(lvl), hs[lvl - 1], ws[lvl - 1], hs[lvl - 1], ws[lvl - 1], 1, 1);
+        }
+    }
+    Act hn = R.gn(unet.norm_out, h.p, h.C, nullptr, 0, N, P_of(0), groups, eps, true);                 // :406-407
+    h.reset();
+    Act out = R.conv3(unet.conv_out, hn.p, hn.C, nullptr, 0, geo_of(0), H, W, H, W, 1, 1);             // :408
+    E2V_HIP(hipGetLastError());
+    return out;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// AutoencoderKL (diffusers 0.11.1).  Images are independent: "samples" = frames, F = 1.
+// -----------------------------------------------------------------------------------------------------
+void e2v_ctx::vae_decode_frames(const float* z_cl, int nf, int h, int w, float* out_cl, hipStream_t s) {
+    E2V_REQUIRE(vae_ready, E2V_ESTATE, "VAE weights are not finalized");
+    Runner R{this, s};
+    const int g = cfg.vae_norm_num_groups;
+    const float eps = cfg.vae_norm_eps;
+    const int lat = cfg.vae_latent_channels;
+    int H = h, W = w;
+    Act x = R.linear(vae.post_quant, z_cl, lat, (int64_t)nf * H * W);
+    x = R.conv3(vae.dec_in, x.p, lat, nullptr, 0, Geo{nf, H, W}, H, W, H, W, 1, 1);
+    x = R.resnet(vae.dec_mid0, x.p, x.C, nullptr, 0, nf, H * W, Geo{nf, H, W}, g, eps, nullptr, 0);
+    x = R.vae_attention(vae.dec_attn, x, nf, H * W, g, eps);
+    x = R.resnet(vae.dec_mid1, x.p, x.C, nullptr, 0, nf, H * W, Geo{nf, H, W}, g, eps, nullptr, 0);
+    for (size_t i = 0; i < vae.dec_up.size(); ++i) {
+        const VAEW::Block& b = vae.dec_up[i];
+        for (const ResW& r : b.res) x = R.resnet(r, x.p, x.C, nullptr, 0, nf, H * W, Geo{nf, H, W}, g, eps, nullptr, 0);
+        if (b.resample) {        // F.interpolate(scale_factor=2, nearest) + 3x3 conv
+            x = R.conv3(b.rs, x.p, x.C, nullptr, 0, Geo{nf, H, W}, 2 * H, 2 * W, 2 * H, 2 * W, 1, 1);
+            H *= 2; W *= 2;
+        }
+    }
+    Act hn = R.gn(vae.dec_norm_out, x.p, x.C, nullptr, 0, nf, H * W, g, eps, true);
+    x.reset();
+    Act y = R.conv3(vae.dec_out, hn.p, hn.C, nullptr, 0, Geo{nf, H, W}, H, W, H, W, 1, 1);
+    E2V_HIP(hipMemcpyAsync(out_cl, y.p, (size_t)y.rows * y.C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    E2V_HIP(hipGetLastError());
+}
+
+void e2v_ctx::vae_encode_frames(const float* img_cl4, int n, int H0, int W0, float* moments_cl, hipStream_t s) {
+    E2V_REQUIRE(vae_ready, E2V_ESTATE, "VAE weights are not finalized");
+    Runner R{this, s};
+    const int g = cfg.vae_norm_num_groups;
+    const float eps = cfg.vae_norm_eps;
+    int H = H0, W = W0;
+    Act x = R.conv3(vae.enc_in, img_cl4, vae.enc_in.cin_pad, nullptr, 0, Geo{n, H, W}, H, W, H, W, 1, 1);
+    for (size_t i = 0; i < vae.enc_down.size(); ++i) {
+        const VAEW::Block& b = vae.enc_down[i];
+        for (const ResW& r : b.res) x = R.resnet(r, x.p, x.C, nullptr, 0, n, H * W, Geo{n, H, W}, g, eps, nullptr, 0);
+        if (b.resample) {        // F.pad(x, (0,1,0,1)) then 3x3 stride-2 conv without padding
+            const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;
+            x = R.conv3(b.rs, x.p, x.C, nullptr, 0, Geo{n, H, W}, H, W, Ho, Wo, 2, 0);
+            H = Ho; W = Wo;
+        }
+    }
+    x = R.resnet(vae.enc_mid0, x.p, x.C, nullptr, 0, n, H * W, Geo{n, H, W}, g, eps, nullptr, 0);
+    x = R.vae_attention(vae.enc_attn, x, n, H * W, g, eps);
+    x = R.resnet(vae.enc_mid1, x.p, x.C, nullptr, 0, n, H * W, Geo{n, H, W}, g, eps, nullptr, 0);
+    Act hn = R.gn(vae.enc_norm_out, x.p, x.C, nullptr, 0, n, H * W, g, eps, true);
+    x.reset();
+    Act y = R.conv3(vae.enc_out, hn.p, hn.C, nullptr, 0, Geo{n, H, W}, H, W, H, W, 1, 1);
+    Act m = R.linear(vae.quant, y.p, y.C, y.rows);
+    E2V_HIP(hipMemcpyAsync(moments_cl, m.p, (size_t)m.rows * m.C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    E2V_HIP(hipGetLastError());
+}

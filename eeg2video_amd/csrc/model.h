@@ -1,0 +1,98 @@
+// The model graphs of the hot path, run as sequences of gfx950 kernel launches on one stream:
+// UNet3DConditionModel.forward (unet.py:278-413), AutoencoderKL encode/decode (diffusers 0.11.1,
+// SURVEY App. C.5) and the DDIM denoising loop of TuneAVideoPipeline.__call__
+// (pipeline_tuneeeg2video.py:287-334).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "runtime.h"
+
+namespace e2v {
+
+struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
+struct LinW { const float* w = nullptr; const float* b = nullptr; int in = 0, out = 0; };
+struct ConvW { const float* w = nullptr; const float* b = nullptr; int cin = 0, cin_pad = 0, cout = 0; };
+
+struct ResW {
+    NormW n1, n2;
+    ConvW c1, c2;
+    LinW temb;        // w == nullptr: no time embedding (VAE)
+    LinW sc;          // w == nullptr: identity shortcut
+    int cin = 0, cout = 0;
+};
+
+struct TransW {
+    NormW norm, ln1, ln2, ln3, lnt;
+    LinW proj_in, proj_out;
+    LinW a1_qkv, a1_out;            // sparse-causal self-attention, fused [3C][C]
+    LinW a2_q, a2_kv, a2_out;       // cross-attention, fused [2C][cross]
+    LinW ff1, ff2;                  // ff1 rows interleaved [32 value | 32 gate] for the GEGLU epilogue
+    LinW at_qkv, at_out;            // temporal attention
+    int C = 0;
+};
+
+struct UNetW {
+    ConvW conv_in, conv_out;
+    LinW te1, te2;
+    NormW norm_out;
+    struct Block {
+        std::vector<ResW> res;
+        std::vector<TransW> attn;       // empty for DownBlock3D / UpBlock3D
+        bool resample = false;
+        ConvW rs;                       // downsampler / upsampler conv
+    };
+    std::vector<Block> down, up;
+    ResW mid_r0, mid_r1;
+    TransW mid_attn;
+};
+
+struct VAEAttnW { NormW norm; LinW qkv, proj; int C = 0; };
+struct VAEW {
+    struct Block { std::vector<ResW> res; bool resample = false; ConvW rs; };
+    // decoder
+    LinW post_quant;
+    ConvW dec_in, dec_out;
+    ResW dec_mid0, dec_mid1;
+    VAEAttnW dec_attn;
+    std::vector<Block> dec_up;
+    NormW dec_norm_out;
+    // encoder
+    LinW quant;
+    ConvW enc_in, enc_out;
+    ResW enc_mid0, enc_mid1;
+    VAEAttnW enc_attn;
+    std::vector<Block> enc_down;
+    NormW enc_norm_out;
+};
+
+}  // namespace e2v
+
+struct e2v_ctx {
+    e2v_config cfg;
+    int device = 0;
+    std::string err;
+    std::vector<std::string> keys;                               // expected keys, in state-dict order
+    std::unordered_map<std::string, e2v::WTensor> raw;           // uploaded tensors (torch layout)
+    std::vector<float*> owned;                                   // packed weights + misc device blocks
+    size_t weight_bytes = 0;
+    e2v::Pool pool;
+    e2v::UNetW unet;
+    e2v::VAEW vae;
+    bool unet_ready = false, vae_ready = false;
+    std::vector<float> alphas;                                   // host alpha-bar table
+    float* gn_part = nullptr; size_t gn_part_floats = 0;         // GroupNorm workspaces (grown on demand)
+    float* gn_scale = nullptr; size_t gn_scale_floats = 0;
+    long long* d_timesteps = nullptr; int d_timesteps_cap = 0;
+
+    float* dev_alloc(size_t floats);
+    void expected_keys();
+    void finalize(int which);
+    // graphs (channel-last in/out); see model.cpp
+    e2v::Act unet_forward_cl(const float* sample_cl, const int64_t* host_t, int n_t, const float* cond, int N, int F,
+                             int H, int W, int T, hipStream_t s);
+    void vae_decode_frames(const float* z_cl, int nframes, int h, int w, float* out_cl3, hipStream_t s);
+    void vae_encode_frames(const float* img_cl4, int n, int H, int W, float* moments_cl8, hipStream_t s);
+};

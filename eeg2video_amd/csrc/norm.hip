@@ -1,0 +1,224 @@
+// GroupNorm(+SiLU) and LayerNorm over channel-last fp32 activations (HBM-bound kernels).
+//
+// GroupNorm (nn.GroupNorm call sites resnet.py:177,188; unet.py:406; attention.py:99): a group is
+// (C/groups) channels x P rows of one slab -- up to 1.66 MB (C=960 @6x36x64), far beyond LDS, and the
+// group width (10/20/30/40/60/80 channels) does not align to 16-byte lanes.  So statistics are taken
+// PER CHANNEL first: (1) every block sums x and x^2 of one row chunk for all channels (coalesced
+// float4 rows, fp32 partials over <=64 values per thread); (2) one wave per (slab, group) folds the
+// partials of its channels in fp64 and emits per-(slab, channel) scale/shift; (3) a streaming pass
+// applies y = act(x*scale + shift).  Two sources = the channel concat of the up blocks
+// (unet_blocks.py:487), whose groups may straddle the seam (1920/32 = 60 does not divide 1280).
+#include "kernels.h"
+#include "prof.h"
+
+namespace e2v {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int GN_ROWS_PER_CHUNK = 256;
+
+int groupnorm_chunks(int P) { return (P + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK; }
+
+// largest divisor of cq that is <= 64
+static int quad_tile(int cq) {
+    int best = 1;
+    for (int d = 1; d <= 64 && d <= cq; ++d)
+        if (cq % d == 0) best = d;
+    return best;
+}
+
+// grid (chunks, slabs); part[((slab*chunks + chunk)*Ctot + coff + c)*2 + {0,1}]
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int ld, int C, int P, int chunks,
+                                                         float* __restrict__ part, int Ctot, int coff, int QT) {
+    __shared__ f32x4 red[2][256];
+    const int chunk = blockIdx.x, slab = blockIdx.y;
+    const int R = 256 / QT;
+    const int q = threadIdx.x % QT, r = threadIdx.x / QT;
+    const int p0 = chunk * GN_ROWS_PER_CHUNK;
+    const int p1 = min(P, p0 + GN_ROWS_PER_CHUNK);
+    const float* base = x + (size_t)slab * P * ld;
+    float* dst = part + ((size_t)(slab * chunks + chunk) * Ctot + coff) * 2;
+    const int CQ = C / 4;
+    for (int q0 = 0; q0 < CQ; q0 += QT) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+        if (r < R) {
+            for (int pr = p0 + r; pr < p1; pr += R) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)pr * ld + (q0 + q) * 4);
+                s += v;
+                ss += v * v;
+            }
+        }
+        red[0][threadIdx.x] = s;
+        red[1][threadIdx.x] = ss;
+        __syncthreads();
+        if (threadIdx.x < QT) {
+            f32x4 ts = {0.f, 0.f, 0.f, 0.f}, tss = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < R; ++k) {
+                ts += red[0][k * QT + threadIdx.x];
+                tss += red[1][k * QT + threadIdx.x];
+            }
+            float* d = dst + (size_t)(q0 + threadIdx.x) * 8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                d[2 * e] = ts[e];
+                d[2 * e + 1] = tss[e];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// grid (groups, slabs), one wave each
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, int chunks, int Ctot, int groups,
+                                                         int P, float eps, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ scsh) {
+    const int g = blockIdx.x, slab = blockIdx.y, lane = threadIdx.x;
+    const int cpg = Ctot / groups;
+    double s = 0.0, ss = 0.0;
+    const int total = chunks * cpg;
+    for (int i = lane; i < total; i += 64) {
+        const int ch = i / cpg, c = g * cpg + (i - ch * cpg);
+        const float* e = part + ((size_t)(slab * chunks + ch) * Ctot + c) * 2;
+        s += (double)e[0];
+        ss += (double)e[1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        ss += __shfl_xor(ss, off);
+    }
+    const double cnt = (double)cpg * (double)P;
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+        const double ga = (double)gamma[c];
+        float* o = scsh + ((size_t)slab * Ctot + c) * 2;
+        o[0] = (float)(rstd * ga);
+        o[1] = (float)((double)beta[c] - mean * rstd * ga);
+    }
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int c0,
+                                                       int c1, int ld0, int ld1, const float* __restrict__ scsh,
+                                                       float* __restrict__ out, int ldo, int P, size_t rows, int act) {
+    const int Ctot = c0 + c1;
+    const int CQ = Ctot / 4;
+    const size_t total = rows * CQ;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / CQ;
+        const int c = (int)(i - row * CQ) * 4;
+        const int slab = (int)(row / P);
+        const f32x4 v = (c < c0) ? *reinterpret_cast<const f32x4*>(x0 + row * ld0 + c)
+                                 : *reinterpret_cast<const f32x4*>(x1 + row * ld1 + (c - c0));
+        const float* sc = scsh + ((size_t)slab * Ctot + c) * 2;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sc);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(sc + 4);
+        f32x4 y;
+        y[0] = v[0] * a[0] + a[1];
+        y[1] = v[1] * a[2] + a[3];
+        y[2] = v[2] * b[0] + b[1];
+        y[3] = v[3] * b[2] + b[3];
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = silu_f(y[e]);
+        }
+        *reinterpret_cast<f32x4*>(out + row * ldo + c) = y;
+    }
+}
+
+void groupnorm(const GroupNormArgs& a, hipStream_t s) {
+    const int Ctot = a.c0 + a.c1;
+    const int chunks = groupnorm_chunks(a.P);
+    const double elems = (double)a.samples * a.P * Ctot;
+    ProfScope ps(a.silu ? "groupnorm_silu" : "groupnorm", 8.0 * elems, 2.0 * 4.0 * elems, s);   // algorithmic: read + write
+    {
+        const int qt = quad_tile(a.c0 / 4);
+        hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, a.samples), dim3(256), 0, s, a.x0, a.ld0, a.c0, a.P, chunks,
+                           a.ws_part, Ctot, 0, qt);
+    }
+    if (a.c1 > 0) {
+        const int qt = quad_tile(a.c1 / 4);
+        hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, a.samples), dim3(256), 0, s, a.x1, a.ld1, a.c1, a.P, chunks,
+                           a.ws_part, Ctot, a.c0, qt);
+    }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.samples), dim3(64), 0, s, a.ws_part, chunks, Ctot, a.groups,
+                       a.P, a.eps, a.gamma, a.beta, a.ws_scale);
+    const size_t rows = (size_t)a.samples * a.P;
+    const size_t total = rows * (Ctot / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, s, a.x0, a.x1, a.c0, a.c1, a.ld0, a.ld1, a.ws_scale,
+                       a.out, a.ldo, a.P, rows, a.silu);
+}
+
+// ---- LayerNorm: one wave per row, row held in registers (C <= 64*4*NV) ------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ out, int ldo,
+                                                        int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int CQ = C / 4;
+    const float* xr = x + (size_t)row * ldx;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int q = lane + 64 * k;
+        if (q < CQ) {
+            v[k] = *reinterpret_cast<const f32x4*>(xr + q * 4);
+            s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        } else {
+            v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int q = lane + 64 * k;
+        if (q < CQ) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[k][e] - mean;
+                ss += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float rstd = rsqrtf(ss / (float)C + eps);
+    float* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int q = lane + 64 * k;
+        if (q < CQ) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + q * 4);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[k][e] - mean) * rstd * g[e] + b[e];
+            *reinterpret_cast<f32x4*>(orow + q * 4) = y;
+        }
+    }
+}
+
+void layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* out, int ldo, int rows, int C,
+               float eps, hipStream_t s) {
+    const int blocks = (rows + 3) / 4;
+    ProfScope ps("layernorm", 8.0 * rows * C, 2.0 * 4.0 * rows * C, s);
+    if (C <= 256)
+        hipLaunchKernelGGL((layernorm_kernel<1>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
+    else if (C <= 768)
+        hipLaunchKernelGGL((layernorm_kernel<3>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<5>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
+}
+
+}  // namespace e2v

@@ -1,0 +1,44 @@
+#include "prof.h"
+
+#include <cstdio>
+#include <map>
+
+namespace e2v {
+
+Profiler& profiler() {
+    static Profiler p;
+    return p;
+}
+
+void Profiler::begin() {
+    entries.clear();
+    on = true;
+}
+
+std::string Profiler::end_json() {
+    on = false;
+    (void)hipDeviceSynchronize();
+    struct Agg { long launches = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::map<std::string, Agg> agg;
+    for (auto& e : entries) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e.a, e.b);
+        Agg& a = agg[e.name];
+        a.launches += 1; a.ms += ms; a.flops += e.flops; a.bytes += e.bytes;
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    entries.clear();
+    std::string out = "{";
+    bool first = true;
+    char buf[512];
+    for (auto& kv : agg) {
+        std::snprintf(buf, sizeof(buf), "%s\"%s\": {\"launches\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                      first ? "" : ", ", kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.flops, kv.second.bytes);
+        out += buf;
+        first = false;
+    }
+    return out + "}";
+}
+
+}  // namespace e2v

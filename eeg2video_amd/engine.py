@@ -1,0 +1,251 @@
+"""``Engine``: one ``e2v_ctx`` (weights + workspace on one GPU) behind a small Python object.
+
+torch is used for what the boundary needs and nothing else: device buffers (``torch.empty``),
+the current HIP stream, and D2H copies.  Every computation is a call into ``libeeg2video_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import UNetConfig, VAEConfig
+
+_ERRORS = {
+    _lib.E2V_EINVAL: ValueError,
+    _lib.E2V_ESHAPE: ValueError,
+    _lib.E2V_ENOWEIGHT: RuntimeError,
+    _lib.E2V_EHIP: RuntimeError,
+    _lib.E2V_ESTATE: RuntimeError,
+}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Engine:
+    """Owns one ``e2v_ctx``.  ``unet_cfg`` / ``vae_cfg`` mirror the reference configs."""
+
+    UNET, VAE = 1, 2
+
+    def __init__(self, unet_cfg: UNetConfig = UNetConfig(), vae_cfg: VAEConfig = VAEConfig(), device: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("eeg2video_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU path")
+        self.lib = _lib.load()
+        self.unet_cfg, self.vae_cfg = unet_cfg, vae_cfg
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        torch.zeros(1, device=self.device)          # make sure torch has initialised the device's context
+        cfg = _lib.E2VConfig()
+        self.lib.e2v_default_config(C.byref(cfg))
+        cfg.in_channels, cfg.out_channels = unet_cfg.in_channels, unet_cfg.out_channels
+        cfg.block_out_channels = (C.c_int * 4)(*unet_cfg.block_out_channels)
+        cfg.layers_per_block = unet_cfg.layers_per_block
+        cfg.cross_attention_dim = unet_cfg.cross_attention_dim
+        cfg.attention_heads = unet_cfg.attention_head_dim
+        cfg.norm_num_groups, cfg.norm_eps = unet_cfg.norm_num_groups, unet_cfg.norm_eps
+        cfg.flip_sin_to_cos, cfg.freq_shift = int(unet_cfg.flip_sin_to_cos), float(unet_cfg.freq_shift)
+        cfg.vae_in_channels, cfg.vae_latent_channels = vae_cfg.in_channels, vae_cfg.latent_channels
+        cfg.vae_block_out_channels = (C.c_int * 4)(*vae_cfg.block_out_channels)
+        cfg.vae_layers_per_block = vae_cfg.layers_per_block
+        cfg.vae_norm_num_groups, cfg.vae_norm_eps = vae_cfg.norm_num_groups, vae_cfg.norm_eps
+        cfg.vae_scaling_factor = vae_cfg.scaling_factor
+        self._cfg = cfg
+        ctx = C.c_void_p()
+        st = self.lib.e2v_create(C.byref(cfg), device, C.byref(ctx))
+        if st != _lib.E2V_OK:
+            raise _ERRORS.get(st, RuntimeError)(self.lib.e2v_last_error(None).decode())
+        self.ctx = ctx
+        self.ready = 0
+
+    def __del__(self):
+        ctx, self.ctx = getattr(self, "ctx", None), None
+        if ctx:
+            self.lib.e2v_destroy(ctx)
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, st: int) -> None:
+        if st != _lib.E2V_OK:
+            raise _ERRORS.get(st, RuntimeError)(self.lib.e2v_last_error(self.ctx).decode())
+
+    def _dev(self, t: torch.Tensor, name: str) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor):
+            raise ValueError(f"`{name}` has to be of type `torch.Tensor` but is {type(t)}")
+        return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def expected_keys(self) -> Dict[str, Tuple[int, ...]]:
+        out = {}
+        shape = (C.c_int64 * 4)()
+        nd = C.c_int()
+        for i in range(self.lib.e2v_num_expected_keys(self.ctx)):
+            k = self.lib.e2v_expected_key(self.ctx, i, shape, C.byref(nd)).decode()
+            out[k] = tuple(int(shape[d]) for d in range(nd.value))
+        return out
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Mapping[str, object], prefix: str = "") -> None:
+        """Upload tensors keyed by the reference's state-dict names (``prefix='vae.'`` for the VAE)."""
+        for k, v in sd.items():
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            a = np.ascontiguousarray(v)
+            if a.dtype == np.float16:
+                dt = _lib.E2V_F16
+            else:
+                a = np.ascontiguousarray(a, dtype=np.float32)
+                dt = _lib.E2V_F32
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            self._check(self.lib.e2v_load_tensor(self.ctx, (prefix + k).encode(), a.ctypes.data_as(C.c_void_p), dt,
+                                                 shape, a.ndim))
+
+    def finalize(self, which: int) -> None:
+        self._check(self.lib.e2v_finalize_weights(self.ctx, which))
+        self.ready |= which
+
+    def device_bytes(self) -> int:
+        return int(self.lib.e2v_device_bytes(self.ctx))
+
+    def profile_begin(self) -> None:
+        self._check(self.lib.e2v_profile_begin(self.ctx))
+
+    def profile_end(self) -> dict:
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        n = self.lib.e2v_profile_end(self.ctx, buf, len(buf))
+        if n < 0:
+            raise RuntimeError("e2v_profile_end failed")
+        return json.loads(buf.value.decode())
+
+    # ------------------------------------------------------------------ schedule
+    def ddim_timesteps(self, n: int) -> np.ndarray:
+        out = np.empty(n, dtype=np.int64)
+        self._check(self.lib.e2v_ddim_timesteps(self.ctx, n, out.ctypes.data_as(_lib.c_int64_p)))
+        return out
+
+    def alphas_cumprod(self) -> np.ndarray:
+        out = np.empty(self._cfg.num_train_timesteps, dtype=np.float32)
+        self._check(self.lib.e2v_ddim_alphas_cumprod(self.ctx, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def set_alphas_cumprod(self, table: np.ndarray) -> None:
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        self._check(self.lib.e2v_set_alphas_cumprod(self.ctx, t.ctypes.data_as(C.POINTER(C.c_float)), t.size))
+
+    # ------------------------------------------------------------------ hot path
+    def unet_forward(self, sample: torch.Tensor, timesteps: Sequence[int], cond: torch.Tensor) -> torch.Tensor:
+        sample, cond = self._dev(sample, "sample"), self._dev(cond, "encoder_hidden_states")
+        if sample.dim() != 5 or cond.dim() != 3 or cond.shape[0] != sample.shape[0]:
+            raise ValueError(f"expected sample [N,C,F,H,W] and cond [N,T,D], got {tuple(sample.shape)} / {tuple(cond.shape)}")
+        n, c, f, h, w = sample.shape
+        if c != self.unet_cfg.in_channels or cond.shape[2] != self.unet_cfg.cross_attention_dim:
+            raise ValueError("channel count of `sample` or feature dim of `encoder_hidden_states` does not match the config")
+        ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int64).reshape(-1))
+        out = torch.empty((n, self.unet_cfg.out_channels, f, h, w), device=self.device, dtype=torch.float32)
+        self._check(self.lib.e2v_unet_forward(self.ctx, sample.data_ptr(), ts.ctypes.data_as(_lib.c_int64_p), ts.size,
+                                              cond.data_ptr(), n, f, h, w, cond.shape[1], out.data_ptr(), _stream()))
+        return out
+
+    def ddim_cfg_step(self, eps_uncond: torch.Tensor, eps_cond: Optional[torch.Tensor], x: torch.Tensor,
+                      guidance_scale: float, t: int, t_prev: int) -> torch.Tensor:
+        eu, x = self._dev(eps_uncond, "eps"), self._dev(x, "sample")
+        ec = self._dev(eps_cond, "eps_cond") if eps_cond is not None else None
+        out = torch.empty_like(x)
+        self._check(self.lib.e2v_ddim_cfg_step(self.ctx, eu.data_ptr(), ec.data_ptr() if ec is not None else None,
+                                               x.data_ptr(), out.data_ptr(), x.numel(), float(guidance_scale), int(t),
+                                               int(t_prev), _stream()))
+        return out
+
+    def vae_decode(self, latents: torch.Tensor, postprocess: bool = True) -> torch.Tensor:
+        z = self._dev(latents, "latents")
+        if z.dim() == 4:
+            z = z[:, :, None]
+            squeeze = True
+        else:
+            squeeze = False
+        b, c, f, h, w = z.shape
+        out = torch.empty((b, self.vae_cfg.out_channels, f, 8 * h, 8 * w), device=self.device, dtype=torch.float32)
+        self._check(self.lib.e2v_vae_decode(self.ctx, z.contiguous().data_ptr(), b, f, h, w, int(postprocess),
+                                            out.data_ptr(), _stream()))
+        return out[:, :, 0] if squeeze else out
+
+    def vae_encode(self, images: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        x = self._dev(images, "images")
+        n, c, h, w = x.shape
+        lat = self.vae_cfg.latent_channels
+        mean = torch.empty((n, lat, h // 8, w // 8), device=self.device, dtype=torch.float32)
+        logvar = torch.empty_like(mean)
+        self._check(self.lib.e2v_vae_encode(self.ctx, x.data_ptr(), n, h, w, mean.data_ptr(), logvar.data_ptr(), _stream()))
+        return mean, logvar
+
+    def generate(self, latents: torch.Tensor, cond: torch.Tensor, uncond: Optional[torch.Tensor],
+                 num_inference_steps: int = 50, guidance_scale: float = 7.5, eta: float = 0.0, decode: bool = True,
+                 return_latents: bool = False):
+        x, cond = self._dev(latents, "latents"), self._dev(cond, "cond")
+        b, c, f, h, w = x.shape
+        un = self._dev(uncond, "uncond") if uncond is not None else None
+        videos = torch.empty((b, self.vae_cfg.out_channels, f, 8 * h, 8 * w), device=self.device,
+                             dtype=torch.float32) if decode else None
+        lat_out = torch.empty_like(x) if return_latents else None
+        self._check(self.lib.e2v_generate(
+            self.ctx, x.data_ptr(), cond.data_ptr(), un.data_ptr() if un is not None else None,
+            un.shape[0] if un is not None else 0, b, f, h, w, cond.shape[1], int(num_inference_steps),
+            float(guidance_scale), float(eta), videos.data_ptr() if decode else None,
+            lat_out.data_ptr() if return_latents else None, _stream()))
+        return (videos, lat_out) if return_latents else videos
+
+    # ------------------------------------------------------------------ kernel-level ops (channel-last tensors)
+    def op_conv3x3(self, x0, w, bias=None, x1=None, *, n_img, Hs, Ws, Hi=None, Wi=None, stride=1, pad_lo=1, pad_hi=1,
+                   rowbias=None, rows_per_sample=1, resid=None):
+        Hi, Wi = Hi or Hs, Wi or Ws
+        Ho = (Hi + pad_lo + pad_hi - 3) // stride + 1
+        Wo = (Wi + pad_lo + pad_hi - 3) // stride + 1
+        cout = w.shape[0]
+        out = torch.empty((n_img * Ho * Wo, cout), device=self.device, dtype=torch.float32)
+        p = lambda t: t.data_ptr() if t is not None else None
+        self._check(self.lib.e2v_op_conv3x3(self.ctx, x0.data_ptr(), x0.shape[1], p(x1), x1.shape[1] if x1 is not None else 0,
+                                            n_img, Hs, Ws, Hi, Wi, Ho, Wo, stride, pad_lo, w.data_ptr(), p(bias), cout,
+                                            p(rowbias), rows_per_sample, p(resid), out.data_ptr(), _stream()))
+        return out
+
+    def op_linear(self, x, w, bias=None, resid=None, geglu=False):
+        m, k = x.shape
+        n = w.shape[0] // 2 if geglu else w.shape[0]
+        out = torch.empty((m, n), device=self.device, dtype=torch.float32)
+        p = lambda t: t.data_ptr() if t is not None else None
+        self._check(self.lib.e2v_op_linear(self.ctx, x.data_ptr(), x.stride(0), m, k, w.data_ptr(), p(bias), n, p(resid),
+                                           int(geglu), out.data_ptr(), _stream()))
+        return out
+
+    def op_groupnorm(self, x0, gamma, beta, *, samples, P, groups, eps, silu=False, x1=None):
+        c = x0.shape[1] + (x1.shape[1] if x1 is not None else 0)
+        out = torch.empty((samples * P, c), device=self.device, dtype=torch.float32)
+        self._check(self.lib.e2v_op_groupnorm(self.ctx, x0.data_ptr(), x0.shape[1], x1.data_ptr() if x1 is not None else None,
+                                              x1.shape[1] if x1 is not None else 0, samples, P, groups, float(eps),
+                                              gamma.data_ptr(), beta.data_ptr(), int(silu), out.data_ptr(), _stream()))
+        return out
+
+    def op_layernorm(self, x, gamma, beta, eps=1e-5):
+        out = torch.empty_like(x)
+        self._check(self.lib.e2v_op_layernorm(self.ctx, x.data_ptr(), x.shape[0], x.shape[1], gamma.data_ptr(),
+                                              beta.data_ptr(), float(eps), out.data_ptr(), _stream()))
+        return out
+
+    def op_attention(self, q, k, v, *, n, F, heads, D, Nq, Nk, mode, scale):
+        """q/k/v: 2-D views (row stride = ``.stride(0)``) of channel-last buffers; returns [n*F*Nq, heads*D]."""
+        out = torch.empty((n * F * Nq, heads * D), device=self.device, dtype=torch.float32)
+        assert k.stride(0) == v.stride(0)
+        self._check(self.lib.e2v_op_attention(self.ctx, q.data_ptr(), q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(0),
+                                              out.data_ptr(), out.stride(0), n, F, heads, D, Nq, Nk, mode, float(scale),
+                                              _stream()))
+        return out
+
+    def op_temporal_attention(self, qkv, *, n, F, HW, heads, D, scale):
+        out = torch.empty((n * F * HW, heads * D), device=self.device, dtype=torch.float32)
+        self._check(self.lib.e2v_op_temporal_attention(self.ctx, qkv.data_ptr(), out.data_ptr(), n, F, HW, heads, D,
+                                                       float(scale), _stream()))
+        return out

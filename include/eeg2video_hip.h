@@ -1,0 +1,155 @@
+/* eeg2video_hip.h -- C ABI of libeeg2video_hip.so: the MI355X (gfx950) implementation of the
+ * EEG2Video generation hot path (Tune-A-Video denoising loop + Stable-Diffusion VAE).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository gaspachoo/EEG2Video, snapshot 2025-07-11).  The reference is pure Python; its FFI for
+ * this path would be a ctypes binding, shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns an e2v_status (0 = ok, < 0 = error); e2v_last_error() gives the text.
+ *   - tensors are plain pointers + sizes.  Activations at the boundary are fp32, contiguous, in the
+ *     reference's own layouts (latents NCFHW, conditioning [N,T,D], videos NCFHW).  Unless a
+ *     parameter says "host", pointers are DEVICE pointers of the ctx's device, owned by the caller.
+ *   - the library owns weights and workspace inside the ctx; after e2v_finalize_weights() and one
+ *     warm-up call of a given shape no further device allocation happens (workspace is cached).
+ *   - one ctx per device; calls on one ctx must be externally serialised (the reference is a single
+ *     Python thread on the default stream, @torch.no_grad()).  `stream` is a hipStream_t (NULL = the
+ *     default stream); all work of a call is enqueued on it and the call does not synchronise unless
+ *     stated.
+ */
+#ifndef EEG2VIDEO_HIP_H
+#define EEG2VIDEO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct e2v_ctx e2v_ctx;
+typedef void* e2v_stream;          /* hipStream_t */
+
+typedef enum {
+    E2V_OK = 0,
+    E2V_EINVAL = -1,     /* bad argument (ValueError in the reference) */
+    E2V_ESHAPE = -2,     /* shape mismatch ("Unexpected latents shape", pipeline_tuneeeg2video.py:239-240) */
+    E2V_ENOWEIGHT = -3,  /* missing / unknown / mis-shaped state-dict key (RuntimeError, unet.py:442-448) */
+    E2V_EHIP = -4,       /* HIP runtime error */
+    E2V_ESTATE = -5      /* call order (weights not finalized, ...) */
+} e2v_status;
+
+typedef enum { E2V_F32 = 0, E2V_F16 = 1 } e2v_dtype;
+
+/* Mirror of the UNet3DConditionModel ctor kwargs the path uses (EEG2Video/models/unet.py:41-78) and of
+ * the AutoencoderKL config (diffusers 0.11.1 vae/config.json).  e2v_default_config()
+ * fills the Stable-Diffusion v1-4 values. */
+typedef struct {
+    int in_channels, out_channels;          /* 4, 4 */
+    int block_out_channels[4];              /* 320, 640, 1280, 1280 */
+    int layers_per_block;                   /* 2 */
+    int cross_attention_dim;                /* 768 */
+    int attention_heads;                    /* `attention_head_dim` = 8 = NUMBER of heads (unet_blocks.py:257-259) */
+    int norm_num_groups;                    /* 32 */
+    float norm_eps;                         /* 1e-5 */
+    int flip_sin_to_cos;                    /* 1 */
+    float freq_shift;                       /* 0 */
+    /* VAE */
+    int vae_in_channels, vae_latent_channels;   /* 3, 4 */
+    int vae_block_out_channels[4];          /* 128, 256, 512, 512 */
+    int vae_layers_per_block;               /* 2 */
+    int vae_norm_num_groups;                /* 32 */
+    float vae_norm_eps;                     /* 1e-6 */
+    double vae_scaling_factor;              /* 0.18215 (pipeline_tuneeeg2video.py:177) */
+    /* DDIM (SD-v1-4 scheduler config) */
+    int num_train_timesteps;                /* 1000 */
+    double beta_start, beta_end;            /* 0.00085, 0.012, "scaled_linear" */
+    int steps_offset;                       /* 1 (forced by pipeline_tuneeeg2video.py:59-71) */
+} e2v_config;
+
+void e2v_default_config(e2v_config* cfg);
+const char* e2v_version(void);
+
+/* ---- context ------------------------------------------------------------------------------------ */
+/* replaces: UNet3DConditionModel.__init__ / TuneAVideoPipeline.__init__ + .to("cuda")
+ * (unet.py:41-207, pipeline_tuneeeg2video.py:43-113, inference_eeg2video.py:69-70) */
+/* device = -1 creates a HOST-ONLY context: it serves the key scheme and the DDIM schedule (no HIP call is
+ * made, so it works on a machine without a GPU); every device entry point then returns E2V_ESTATE. */
+e2v_status e2v_create(const e2v_config* cfg, int device, e2v_ctx** out);
+void e2v_destroy(e2v_ctx* ctx);
+const char* e2v_last_error(const e2v_ctx* ctx);      /* ctx may be NULL: last error of a failed e2v_create */
+
+/* ---- weights ------------------------------------------------------------------------------------ */
+/* replaces: ModelMixin.from_pretrained / load_state_dict (unet.py:415-449, inference_eeg2video.py:69).
+ * `key` is the reference state-dict key; UNet keys as they are ("conv_in.weight", "down_blocks.0....",
+ * SURVEY App. D), VAE keys prefixed "vae." ("vae.decoder.conv_in.weight").  `data` is a HOST pointer in
+ * the torch layout (Conv2d [Cout,Cin,kh,kw], Linear [out,in]); the shape is checked against the config. */
+e2v_status e2v_load_tensor(e2v_ctx* ctx, const char* key, const void* host_data, e2v_dtype dtype,
+                           const int64_t* shape, int ndim);
+/* number of keys the config expects / a key by index (for loaders that iterate) */
+int64_t e2v_num_expected_keys(const e2v_ctx* ctx);
+const char* e2v_expected_key(const e2v_ctx* ctx, int64_t i, int64_t* shape4, int* ndim);
+/* re-layout to the kernels' formats (tap-major convs, fused QKV / KV, GEGLU row interleave).
+ * which: bit 0 = UNet, bit 1 = VAE; every expected key of the selected parts must have been loaded. */
+e2v_status e2v_finalize_weights(e2v_ctx* ctx, int which);
+
+/* ---- schedule (host, integer-exact) ---------------------------------------------------------------- */
+/* replaces: DDIMScheduler.set_timesteps (call site pipeline_tuneeeg2video.py:287-288).
+ * t_i = (i * (T // n))[::-1] + steps_offset, int64; n=50 -> 981, 961, ..., 21, 1. */
+e2v_status e2v_ddim_timesteps(const e2v_ctx* ctx, int num_inference_steps, int64_t* host_out);
+/* alpha-bar table (fp32 cumprod of 1 - linspace(sqrt(b0), sqrt(b1), T)^2), host copy of T floats.
+ * The library computes it with scalar fp32 arithmetic; torch.linspace's vectorised CPU kernel can differ in
+ * the last bit depending on the host's SIMD width, so a host that wants the very table its own diffusers
+ * install would build hands it in with e2v_set_alphas_cumprod (the Python mirror does). */
+e2v_status e2v_ddim_alphas_cumprod(const e2v_ctx* ctx, float* host_out);
+e2v_status e2v_set_alphas_cumprod(e2v_ctx* ctx, const float* host_table, int n);
+
+/* ---- the hot path --------------------------------------------------------------------------------- */
+/* replaces: UNet3DConditionModel.forward (unet.py:278-413).
+ * sample [N,C,F,H,W], timesteps int64 HOST array of length n_t (1 = broadcast, else N),
+ * cond [N,T,cross_attention_dim], out [N,out_channels,F,H,W]. */
+e2v_status e2v_unet_forward(e2v_ctx* ctx, const float* sample, const int64_t* host_timesteps, int n_t,
+                            const float* cond, int N, int F, int H, int W, int T, float* out, e2v_stream stream);
+
+/* replaces: noise_pred chunk + guidance + scheduler.step (pipeline_tuneeeg2video.py:320-325), eta = 0.
+ * eps_cond may be NULL (guidance off).  t, t_prev are train timesteps (t_prev < 0 -> final alpha = abar[0]). */
+e2v_status e2v_ddim_cfg_step(e2v_ctx* ctx, const float* eps_uncond, const float* eps_cond, const float* x,
+                             float* x_out, int64_t count, float guidance_scale, int64_t t, int64_t t_prev,
+                             e2v_stream stream);
+
+/* postprocess = 1 replaces TuneAVideoPipeline.decode_latents (pipeline_tuneeeg2video.py:175-184) without the
+ * D2H copy: latents [B,4,F,h,w] -> (vae.decode(latents / 0.18215).sample / 2 + 0.5).clamp(0,1) as videos
+ * [B,3,F,8h,8w].  postprocess = 0 replaces AutoencoderKL.decode (call site :179): z [B,4,F,h,w] is decoded as
+ * given (no 1/0.18215, no clamp); the (b f) frames of the reference are B = n, F = 1. */
+e2v_status e2v_vae_decode(e2v_ctx* ctx, const float* latents, int B, int F, int h, int w, int postprocess,
+                          float* videos, e2v_stream stream);
+/* replaces: AutoencoderKL.encode(...).latent_dist (train_finetune_videodiffusion.py:264,
+ * EEG2Video_New/Seq2Seq/generate_1200_latent.py:38): images [n,3,H,W] -> mean, logvar [n,4,H/8,W/8]
+ * (logvar clamped to [-30,20]); no 0.18215 factor (that is the caller's, as in the reference). */
+e2v_status e2v_vae_encode(e2v_ctx* ctx, const float* images, int n, int H, int W, float* mean, float* logvar,
+                          e2v_stream stream);
+
+/* replaces: the body of TuneAVideoPipeline.__call__ after _encode_eeg (pipeline_tuneeeg2video.py:287-334):
+ * set_timesteps, the denoising loop with classifier-free guidance (guidance_scale > 1) and the VAE decode,
+ * all enqueued on `stream` without a host round trip per step.
+ * latents [B,4,F,h,w] (already scaled by init_noise_sigma = 1), cond [B,T,D], uncond [Bu,T,D] with Bu = 1
+ * (broadcast, the reference's negative.npy) or B; videos [B,3,F,8h,8w] (may be NULL: skip decode);
+ * latents_out [B,4,F,h,w] (may be NULL). */
+e2v_status e2v_generate(e2v_ctx* ctx, const float* latents, const float* cond, const float* uncond, int Bu,
+                        int B, int F, int h, int w, int T, int num_inference_steps, float guidance_scale,
+                        float eta, float* videos, float* latents_out, e2v_stream stream);
+
+/* Per-kernel-class timing with HIP events on the launch stream (used by bench.py for the roofline figures).
+ * Between begin and end every kernel launch of the library is bracketed by an event pair and tagged with its
+ * algorithmic flops / bytes.  e2v_profile_end synchronises and writes a JSON object
+ * {"<kernel class>": {"launches": n, "ms": total, "flops": total, "bytes": total}, ...} into `json`
+ * (NUL-terminated, truncated to `cap`); it returns the untruncated length or -1. */
+e2v_status e2v_profile_begin(e2v_ctx* ctx);
+int64_t e2v_profile_end(e2v_ctx* ctx, char* json, int64_t cap);
+
+/* bytes of device memory currently held by the ctx (weights + cached workspace) */
+int64_t e2v_device_bytes(const e2v_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EEG2VIDEO_HIP_H */

@@ -1,0 +1,65 @@
+/* eeg2video_hip_ops.h -- kernel-level entry points of libeeg2video_hip.so.
+ *
+ * These expose the individual gfx950 kernels behind the model-level ABI of eeg2video_hip.h so that each
+ * can be checked against the oracle and profiled on its own.  Activations are CHANNEL-LAST fp32 device
+ * tensors: [n, F, H, W, C] is a row-major matrix [n*F*H*W][C].  Weights are device pointers in the
+ * torch layouts the reference's modules hold (Conv2d [Cout,Cin,3,3], Linear [out,in]).
+ * Reference op each one stands for is named per function (paths relative to the reference repo).
+ */
+#ifndef EEG2VIDEO_HIP_OPS_H
+#define EEG2VIDEO_HIP_OPS_H
+
+#include "eeg2video_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* InflatedConv3d 3x3 (EEG2Video/models/resnet.py:10-18) over n_img frames of Hs x Ws, optionally after a
+ * nearest resize to (Hi, Wi) (Upsample3D, resnet.py:58-61; Hi = Hs, Wi = Ws: none).  Input = channel concat
+ * of x0 (c0) and x1 (c1, may be NULL/0).  Output map (Ho, Wo) = floor((Hi + pad_lo + pad_hi - 3)/stride) + 1
+ * with pad_lo rows/cols of zeros above/left (pad_hi is implied by Ho).  Epilogue: + bias[cout]
+ * + rowbias[row / rows_per_sample][cout] (time embedding, resnet.py:186) + resid[row][cout]. */
+e2v_status e2v_op_conv3x3(e2v_ctx* ctx, const float* x0, int c0, const float* x1, int c1, int n_img, int Hs, int Ws,
+                          int Hi, int Wi, int Ho, int Wo, int stride, int pad_lo, const float* w_oihw, const float* bias,
+                          int cout, const float* rowbias, int rows_per_sample, const float* resid, float* out,
+                          e2v_stream stream);
+
+/* nn.Linear / 1x1 conv: out[M][N] = x[M][K] w[N][K]^T + bias (+ resid).  geglu != 0: w is the GEGLU
+ * projection [2*N2][K] in torch row order (value rows then gate rows, attention.py:189 via diffusers GEGLU);
+ * out[M][N2] = (x w_v^T + b_v) * gelu_erf(x w_g^T + b_g). */
+e2v_status e2v_op_linear(e2v_ctx* ctx, const float* x, int ldx, int64_t M, int K, const float* w, const float* bias,
+                         int N, const float* resid, int geglu, float* out, e2v_stream stream);
+
+/* nn.GroupNorm (+ SiLU) with statistics over (C/groups channels) x (P rows) per slab; slabs = samples.
+ * 5-D GroupNorm of ResnetBlock3D (resnet.py:177): samples = n, P = F*H*W.  Per-frame GroupNorm of
+ * Transformer3DModel (attention.py:99): samples = n*F, P = H*W. */
+e2v_status e2v_op_groupnorm(e2v_ctx* ctx, const float* x0, int c0, const float* x1, int c1, int samples, int P,
+                            int groups, float eps, const float* gamma, const float* beta, int silu, float* out,
+                            e2v_stream stream);
+
+/* nn.LayerNorm over the last dim (attention.py:167,184,190,202) */
+e2v_status e2v_op_layernorm(e2v_ctx* ctx, const float* x, int64_t rows, int C, const float* gamma, const float* beta,
+                            float eps, float* out, e2v_stream stream);
+
+/* softmax(q k^T * scale) v per (sample, frame, head).
+ * mode 0: SparseCausalAttention (attention.py:272-328): q, k, v are [n*F*Nq][ld]; keys of frame f are
+ *         [frame 0 ; frame max(f-1, 0)].  mode 1: keys shared by the F frames of a sample, k, v [n*Nk][ldkv]. */
+e2v_status e2v_op_attention(e2v_ctx* ctx, const float* q, int ldq, const float* k, const float* v, int ldkv, float* o,
+                            int ldo, int n, int F, int heads, int D, int Nq, int Nk, int mode, float scale,
+                            e2v_stream stream);
+
+/* attn_temp (attention.py:261-267): self-attention over the F frames of every pixel; qkv [n*F*HW][3C]. */
+e2v_status e2v_op_temporal_attention(e2v_ctx* ctx, const float* qkv, float* out, int n, int F, int HW, int heads, int D,
+                                     float scale, e2v_stream stream);
+
+/* layout conversion at the boundary: [n][C][FHW] <-> [n][FHW][Cpad] */
+e2v_status e2v_op_to_channels_last(e2v_ctx* ctx, const float* in, float* out, int n, int C, int Cpad, int FHW,
+                                   e2v_stream stream);
+e2v_status e2v_op_from_channels_last(e2v_ctx* ctx, const float* in, int ld, float* out, int n, int C, int FHW,
+                                     e2v_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,215 @@
+"""GPU: the model-level C ABI (UNet forward, DDIM/CFG step, VAE, the fused generate loop) and the Python
+mirrors of the reference interfaces, against the CPU oracle and the reference-generated goldens.
+
+Tolerance: BASELINE.json asks for <= 1e-3 relative fp32 on the end-to-end frames; single modules are held to
+1e-4 of the tensor's scale (fp32 both sides; only the summation order differs)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from eeg2video_amd.weights import (TINY_UNET, TINY_VAE, counter_normal, synth_state_dict, unet_param_spec,
+                                   vae_param_spec)
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    """One engine with tiny UNet + VAE ('perturbed' weights: no neutral gamma/beta, non-zero temporal to_out)."""
+    from eeg2video_amd.pipeline import build_pipeline
+    usd = synth_state_dict(unet_param_spec(TINY_UNET), seed=42, mode="perturbed")
+    vsd = synth_state_dict(vae_param_spec(TINY_VAE), seed=43, mode="perturbed")
+    pipe = build_pipeline(TINY_UNET, TINY_VAE, device=0, unet_sd=usd, vae_sd=vsd)
+    pipe.set_progress_bar_config(disable=True)
+    return pipe, {k: _t(v) for k, v in usd.items()}, {k: _t(v) for k, v in vsd.items()}
+
+
+def test_key_scheme_matches_library(tiny):
+    pipe = tiny[0]
+    exp = pipe.unet.engine.expected_keys()
+    spec = dict(unet_param_spec(TINY_UNET))
+    spec.update({"vae." + k: v for k, v in vae_param_spec(TINY_VAE).items()})
+    assert exp == spec
+
+
+def test_unet_forward_vs_reference_golden(tiny, golden_dir):
+    """The reference's own UNet3DConditionModel.forward output (tests/golden/make_golden.py, tier 2)."""
+    pipe = tiny[0]
+    g = np.load(os.path.join(golden_dir, "reference_t2_unet_tiny.npz"))
+    x, cond = _t(g["t2.unet.x"]), _t(g["t2.unet.cond"])
+    y = pipe.unet(x.cuda(), 501, encoder_hidden_states=cond.cuda()).sample
+    assert rel_err(y, _t(g["t2.unet.out_t501"])) < 1e-4
+    y2 = pipe.unet(x.cuda(), torch.tensor([751, 1]), encoder_hidden_states=cond.cuda())["sample"]
+    assert rel_err(y2, _t(g["t2.unet.out_t751_1"])) < 1e-4
+
+
+@pytest.mark.parametrize("shape,tokens", [((2, 4, 3, 9, 12), 11), ((1, 4, 6, 8, 8), 77), ((3, 4, 2, 5, 7), 5)])
+def test_unet_forward_vs_oracle(tiny, shape, tokens):
+    from oracle import unet3d_forward
+    pipe, usd, _ = tiny
+    x = _t(counter_normal(5, "x", shape))
+    cond = _t(counter_normal(6, "c", (shape[0], tokens, TINY_UNET.cross_attention_dim)))
+    ref = unet3d_forward(usd, TINY_UNET, x, 301, cond)
+    y = pipe.unet(x.cuda(), 301, cond.cuda(), return_dict=False)[0]
+    assert y.shape == ref.shape and rel_err(y, ref) < 1e-4
+
+
+def test_unet_batch_entries_are_independent(tiny):
+    """No op of the UNet mixes samples (the property the multi-GPU sharding rests on)."""
+    pipe = tiny[0]
+    x = _t(counter_normal(7, "x", (3, 4, 3, 9, 12))).cuda()
+    cond = _t(counter_normal(8, "c", (3, 11, TINY_UNET.cross_attention_dim))).cuda()
+    full = pipe.unet(x, 41, cond).sample
+    for i in range(3):
+        one = pipe.unet(x[i:i + 1], 41, cond[i:i + 1]).sample
+        assert torch.equal(one, full[i:i + 1])          # bit-exact: same kernels, same summation order
+
+
+def test_ddim_cfg_step_vs_oracle(tiny):
+    from oracle import DDIMOracle
+    pipe = tiny[0]
+    eng = pipe.unet.engine
+    s = DDIMOracle()
+    s.set_timesteps(50)
+    x, eu, ec = (_t(counter_normal(9, k, (2, 4, 3, 9, 12))) for k in ("x", "eu", "ec"))
+    for t in (981, 501, 1):
+        eps = eu + 12.5 * (ec - eu)
+        ref = s.step(eps, t, x)
+        y = eng.ddim_cfg_step(eu.cuda(), ec.cuda(), x.cuda(), 12.5, t, t - 20)
+        assert rel_err(y, ref) < 2e-6
+        y1 = eng.ddim_cfg_step(eps.cuda(), None, x.cuda(), 1.0, t, t - 20)
+        assert rel_err(y1, ref) < 2e-6
+
+
+def test_ddim_schedule_bit_exact(tiny):
+    from oracle import DDIMOracle
+    eng = tiny[0].unet.engine
+    for n in (1, 4, 7, 50, 100, 250, 1000):
+        assert np.array_equal(eng.ddim_timesteps(n), DDIMOracle().set_timesteps(n))
+    assert np.array_equal(eng.alphas_cumprod(), tiny[0].scheduler.alphas_cumprod.numpy())      # handed over by bind()
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 4, 6), (3, 6, 4)])
+def test_vae_decode_vs_oracle(tiny, n, h, w):
+    from oracle import vae_decode
+    pipe, _, vsd = tiny
+    z = _t(counter_normal(10, "z", (n, 4, h, w)))
+    ref = vae_decode(vsd, TINY_VAE, z)
+    y = pipe.vae.decode(z.cuda()).sample
+    assert y.shape == ref.shape and rel_err(y, ref) < 1e-4
+
+
+def test_vae_encode_vs_oracle(tiny):
+    from oracle import vae_encode
+    pipe, _, vsd = tiny
+    img = _t(counter_normal(11, "img", (2, 3, 32, 48)))
+    mean, logvar = vae_encode(vsd, TINY_VAE, img)
+    dist = pipe.vae.encode(img.cuda()).latent_dist
+    assert rel_err(dist.mean, mean) < 1e-4 and rel_err(dist.logvar, logvar) < 1e-4
+    assert torch.equal(dist.mode(), dist.mean)
+
+
+def test_vae_decode_latents_roundtrip_shapes_and_range(tiny):
+    pipe = tiny[0]
+    lat = _t(counter_normal(12, "lat", (2, 4, 3, 4, 6)))
+    vid = pipe.decode_latents(lat.cuda())
+    assert isinstance(vid, np.ndarray) and vid.shape == (2, 3, 3, 32, 48) and vid.dtype == np.float32
+    assert vid.min() >= 0.0 and vid.max() <= 1.0
+
+
+@pytest.mark.parametrize("guidance", [12.5, 1.0])
+def test_generate_vs_oracle_end_to_end(tiny, guidance):
+    """BASELINE config-1 shape of test at tiny size: 4-step DDIM, CFG, decode; frames within 1e-3 relative."""
+    from oracle import generate
+    pipe, usd, vsd = tiny
+    b, f, h, w, tok = 2, 3, 8, 12, 9
+    lat = _t(counter_normal(13, "lat", (b, 4, f, h, w)))
+    cond = _t(counter_normal(14, "cond", (b, tok, TINY_UNET.cross_attention_dim)))
+    unc = _t(counter_normal(15, "unc", (1, tok, TINY_UNET.cross_attention_dim)))
+    trace = {}
+    ref = generate(usd, TINY_UNET, vsd, TINY_VAE, lat, cond, unc, num_inference_steps=4, guidance_scale=guidance, trace=trace)
+    eng = pipe.unet.engine
+    vid, lat_out = eng.generate(lat.cuda(), cond.cuda(), unc.cuda(), 4, guidance, 0.0, decode=True, return_latents=True)
+    assert rel_err(lat_out, trace["latents"][-1]) < 1e-3
+    assert vid.shape == ref.shape
+    assert (vid.cpu() - ref).abs().max().item() < 1e-3          # frames live in [0, 1]
+
+    # teacher-forced per-step check (SURVEY §8(d) parity procedure ii): feed the oracle's latents of step k
+    ts = eng.ddim_timesteps(4)
+    x = lat
+    for k, t in enumerate(ts):
+        if guidance > 1.0:
+            emb = torch.cat([unc.expand(b, -1, -1), cond])
+            eps = pipe.unet(torch.cat([x, x]).cuda(), int(t), emb.cuda()).sample
+            x_new = eng.ddim_cfg_step(eps[:b], eps[b:], x.cuda(), guidance, int(t), int(t) - 250)
+        else:
+            eps = pipe.unet(x.cuda(), int(t), cond.cuda()).sample
+            x_new = eng.ddim_cfg_step(eps, None, x.cuda(), guidance, int(t), int(t) - 250)
+        assert rel_err(x_new, trace["latents"][k]) < 2e-4, k
+        x = trace["latents"][k]
+
+
+def test_pipeline_call_matches_reference_semantics(tiny):
+    """TuneAVideoPipeline.__call__ drop-in: same kwargs, output object, fused and stepped loops agree."""
+    from oracle import generate
+    pipe, usd, vsd = tiny
+    b, f, tok = 1, 3, 77
+    d = TINY_UNET.cross_attention_dim
+    lat = _t(counter_normal(16, "lat", (b, 4, f, 4, 6)))
+    eeg = _t(counter_normal(17, "eeg", (b, tok * d)))               # New variant: precomputed embeddings, model=None
+    neg = _t(counter_normal(18, "neg", (1, tok, d)))
+    out = pipe(None, eeg, video_length=f, height=32, width=48, num_inference_steps=3, guidance_scale=12.5,
+               negative_prompt=neg, latents=lat.cuda())
+    assert out.videos.shape == (b, 3, f, 32, 48) and out.videos.dtype == torch.float32 and out.videos.device.type == "cpu"
+    assert out["videos"] is out.videos
+    ref = generate(usd, TINY_UNET, vsd, TINY_VAE, lat, eeg.reshape(b, tok, d), neg, 3, 12.5)
+    assert (out.videos - ref).abs().max().item() < 1e-3
+    seen = []
+    stepped = pipe(None, eeg, video_length=f, height=32, width=48, num_inference_steps=3, guidance_scale=12.5,
+                   negative_prompt=neg, latents=lat.cuda(), callback=lambda i, t, x: seen.append((i, int(t))),
+                   return_dict=False)
+    assert seen == [(0, 667), (1, 334), (2, 1)]
+    assert (stepped - out.videos).abs().max().item() < 1e-5
+    # a `model` callable is applied to the EEG first (pipeline_tuneeeg2video.py:149)
+    via_model = pipe(lambda e: e * 1.0, eeg, f, 32, 48, 3, 12.5, neg, latents=lat.cuda()).videos
+    assert torch.equal(via_model, out.videos)
+
+
+def test_pipeline_error_behaviour(tiny):
+    pipe = tiny[0]
+    d = TINY_UNET.cross_attention_dim
+    eeg = torch.zeros(1, 77 * d)
+    with pytest.raises(ValueError, match="has to be of type"):
+        pipe(None, [1, 2], 3, 32, 48)
+    with pytest.raises(ValueError, match="divisible by 8"):
+        pipe(None, eeg, 3, 30, 48)
+    with pytest.raises(ValueError, match="callback_steps"):
+        pipe(None, eeg, 3, 32, 48, callback_steps=0)
+    with pytest.raises(ValueError, match="Unexpected latents shape"):
+        pipe(None, eeg, 3, 32, 48, guidance_scale=1.0, latents=torch.zeros(1, 4, 3, 5, 6))
+    with pytest.raises(ValueError, match="generators"):
+        pipe(None, eeg, 3, 32, 48, guidance_scale=1.0, generator=[torch.Generator(), torch.Generator()])
+    with pytest.raises(ValueError, match="unconditional embedding"):
+        pipe(None, eeg, 3, 32, 48, guidance_scale=7.5)
+    with pytest.raises(RuntimeError):
+        pipe.unet.load_state_dict({"conv_in.weight": torch.zeros(1)})
+
+
+def test_cfg_guidance_one_is_identity(tiny):
+    """g = 1: eps_u + 1 * (eps_c - eps_u) == eps_c (SURVEY §4 invariant v)."""
+    eng = tiny[0].unet.engine
+    x, eu, ec = (_t(counter_normal(19, k, (1, 4, 3, 4, 6))).cuda() for k in ("x", "eu", "ec"))
+    a = eng.ddim_cfg_step(eu, ec, x, 1.0, 501, 481)
+    b = eng.ddim_cfg_step(ec, None, x, 1.0, 501, 481)
+    assert (a - b).abs().max().item() < 1e-6

@@ -1,0 +1,209 @@
+"""GPU: every hand-written kernel, called through the C ABI, against a plain PyTorch fp32 reference of the
+same op on the CPU (floating-point kernels: tolerance stated per test; fp32 MFMA is an exact-product fmaf
+chain, so differences are summation order only)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 2e-5, 2e-5      # fp32 vs fp32, different summation order
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from eeg2video_amd.engine import Engine
+    from eeg2video_amd.weights import TINY_UNET, TINY_VAE
+    return Engine(TINY_UNET, TINY_VAE, 0)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def to_cl(x):      # [n, C, H, W] -> [n*H*W, C]
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous()
+
+
+def from_cl(y, n, h, w):
+    return y.reshape(n, h, w, -1).permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = b.abs().max().item() + 1e-30
+    err = (a - b).abs().max().item()
+    assert err <= atol * max(1.0, scale) + rtol * scale, f"max abs err {err:.3e} (ref scale {scale:.3e})"
+
+
+# ------------------------------------------------------------------ conv / linear -------------------
+@pytest.mark.parametrize("cin,cout,n,h,w", [(32, 64, 2, 5, 8), (4, 64, 3, 9, 12), (64, 4, 2, 7, 5), (96, 320, 1, 18, 32),
+                                            (320, 320, 2, 36, 64)])
+def test_conv3x3_plain(eng, cin, cout, n, h, w):
+    x, wt, b = rnd(n, cin, h, w, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.1), rnd(cout, seed=3)
+    ref = F.conv2d(x, wt, b, padding=1)
+    y = eng.op_conv3x3(to_cl(x).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=h, Ws=w)
+    close(from_cl(y, n, h, w), ref)
+
+
+def test_conv3x3_stride2_both_paddings(eng):
+    n, c, h, w = 2, 32, 9, 12
+    x, wt, b = rnd(n, c, h, w, seed=4), rnd(64, c, 3, 3, seed=5, scale=0.1), rnd(64, seed=6)
+    ref = F.conv2d(x, wt, b, stride=2, padding=1)                               # Downsample3D (resnet.py:87)
+    y = eng.op_conv3x3(to_cl(x).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=h, Ws=w, stride=2)
+    close(from_cl(y, n, ref.shape[2], ref.shape[3]), ref)
+    x2 = rnd(n, c, 8, 12, seed=7)                                               # VAE encoder: F.pad (0,1,0,1), no padding
+    ref2 = F.conv2d(F.pad(x2, (0, 1, 0, 1)), wt, b, stride=2)
+    y2 = eng.op_conv3x3(to_cl(x2).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=8, Ws=12, stride=2, pad_lo=0, pad_hi=1)
+    close(from_cl(y2, n, ref2.shape[2], ref2.shape[3]), ref2)
+
+
+@pytest.mark.parametrize("hs,ws,hi,wi", [(5, 8, 9, 16), (5, 8, 10, 16), (3, 3, 5, 6), (2, 2, 3, 3), (5, 6, 12, 7)])
+def test_conv3x3_fused_nearest_resize(eng, hs, ws, hi, wi):
+    """Upsample3D: F.interpolate(size=...) nearest, then conv (resnet.py:58-69); 5 -> 9 is the L3->L2 case."""
+    n, c = 3, 32
+    x, wt, b = rnd(n, c, hs, ws, seed=8), rnd(64, c, 3, 3, seed=9, scale=0.1), rnd(64, seed=10)
+    ref = F.conv2d(F.interpolate(x, size=(hi, wi), mode="nearest"), wt, b, padding=1)
+    y = eng.op_conv3x3(to_cl(x).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=hs, Ws=ws, Hi=hi, Wi=wi)
+    close(from_cl(y, n, hi, wi), ref)
+
+
+def test_conv3x3_concat_rowbias_residual(eng):
+    """torch.cat([h, skip], 1) read in place + time-embedding row bias + residual epilogue."""
+    n_s, f, c0, c1, cout, h, w = 2, 3, 64, 32, 64, 5, 6
+    n = n_s * f
+    a, s = rnd(n, c0, h, w, seed=11), rnd(n, c1, h, w, seed=12)
+    wt, b = rnd(cout, c0 + c1, 3, 3, seed=13, scale=0.1), rnd(cout, seed=14)
+    temb, res = rnd(n_s, cout, seed=15), rnd(n, cout, h, w, seed=16)
+    ref = F.conv2d(torch.cat([a, s], 1), wt, b, padding=1) + temb.repeat_interleave(f, 0)[:, :, None, None] + res
+    y = eng.op_conv3x3(to_cl(a).cuda(), wt.cuda(), b.cuda(), x1=to_cl(s).cuda(), n_img=n, Hs=h, Ws=w,
+                       rowbias=temb.cuda().contiguous(), rows_per_sample=f * h * w, resid=to_cl(res).cuda())
+    close(from_cl(y, n, h, w), ref)
+
+
+@pytest.mark.parametrize("m,k,n", [(240, 1280, 1280), (77, 64, 128), (1000, 320, 960), (130, 40, 72), (5, 320, 1280)])
+def test_linear(eng, m, k, n):
+    x, w, b, r = rnd(m, k, seed=20), rnd(n, k, seed=21, scale=0.05), rnd(n, seed=22), rnd(m, n, seed=23)
+    close(eng.op_linear(x.cuda(), w.cuda(), b.cuda(), r.cuda()), F.linear(x, w, b) + r)
+    close(eng.op_linear(x.cuda(), w.cuda()), F.linear(x, w))
+
+
+@pytest.mark.parametrize("m,c", [(300, 64), (864, 320)])
+def test_linear_geglu(eng, m, c):
+    """FeedForward GEGLU (dep): h, gate = proj(x).chunk(2); h * gelu_erf(gate)."""
+    x, w, b = rnd(m, c, seed=24), rnd(8 * c, c, seed=25, scale=0.1), rnd(8 * c, seed=26)
+    h, g = F.linear(x, w, b).chunk(2, dim=-1)
+    close(eng.op_linear(x.cuda(), w.cuda(), b.cuda(), geglu=True), h * F.gelu(g))
+
+
+# ------------------------------------------------------------------ norms ---------------------------
+@pytest.mark.parametrize("c,groups,n,f,hw", [(320, 32, 2, 6, 40), (64, 32, 3, 3, 300), (960, 32, 1, 6, 100), (128, 8, 2, 1, 600)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_groupnorm_5d(eng, c, groups, n, f, hw, silu):
+    """5-D GroupNorm: statistics over (C/G) x F x H x W jointly (resnet.py:177)."""
+    x = rnd(n, c, f, hw, 1, seed=30) * 2.0 + 0.7
+    ga, be = rnd(c, seed=31) * 0.2 + 1.0, rnd(c, seed=32) * 0.2
+    ref = F.group_norm(x, groups, ga, be, 1e-5)
+    ref = F.silu(ref) if silu else ref
+    xcl = x.permute(0, 2, 3, 4, 1).reshape(n * f * hw, c).contiguous()
+    y = eng.op_groupnorm(xcl.cuda(), ga.cuda(), be.cuda(), samples=n, P=f * hw, groups=groups, eps=1e-5, silu=silu)
+    close(y.reshape(n, f, hw, 1, c).permute(0, 4, 1, 2, 3), ref)
+
+
+def test_groupnorm_concat_group_straddles_seam(eng):
+    """up-block concat 1280 + 640 -> 1920 channels, 60 per group: group 21 straddles the seam."""
+    n, c0, c1, p = 2, 64, 32, 500            # 96 / 32 = 3 channels per group; 64 / 3 is not an integer
+    a, s = rnd(n, c0, p, 1, seed=33), rnd(n, c1, p, 1, seed=34) * 3 - 1
+    ga, be = rnd(c0 + c1, seed=35) * 0.2 + 1.0, rnd(c0 + c1, seed=36) * 0.2
+    ref = F.silu(F.group_norm(torch.cat([a, s], 1), 32, ga, be, 1e-5))
+    cl = lambda t: t.permute(0, 2, 3, 1).reshape(n * p, -1).contiguous()
+    y = eng.op_groupnorm(cl(a).cuda(), ga.cuda(), be.cuda(), samples=n, P=p, groups=32, eps=1e-5, silu=True, x1=cl(s).cuda())
+    close(y.reshape(n, p, 1, c0 + c1).permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("c", [64, 320, 640, 1280])
+def test_layernorm(eng, c):
+    x, g, b = rnd(777, c, seed=40) * 3 + 1, rnd(c, seed=41) * 0.2 + 1, rnd(c, seed=42) * 0.2
+    close(eng.op_layernorm(x.cuda(), g.cuda(), b.cuda()), F.layer_norm(x, (c,), g, b, 1e-5))
+
+
+# ------------------------------------------------------------------ attention -----------------------
+def _ref_attn(q, k, v, scale):
+    s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1]), q, k.transpose(1, 2), beta=0, alpha=scale)
+    return torch.bmm(s.softmax(-1), v)
+
+
+def _heads(x, h):     # [b, s, h*d] -> [b*h, s, d]
+    b, s, c = x.shape
+    return x.reshape(b, s, h, c // h).permute(0, 2, 1, 3).reshape(b * h, s, c // h)
+
+
+def _unheads(x, h):
+    bh, s, d = x.shape
+    return x.reshape(bh // h, h, s, d).permute(0, 2, 1, 3).reshape(bh // h, s, h * d)
+
+
+@pytest.mark.parametrize("d,nq,f,n", [(8, 108, 3, 2), (16, 30, 4, 1), (32, 9, 3, 2), (40, 200, 6, 1), (80, 144, 3, 1),
+                                      (160, 40, 6, 2), (64, 70, 2, 1)])
+def test_sparse_causal_attention(eng, d, nq, f, n):
+    """attention.py:292-321: keys/values of frame i = [frame 0 ; frame max(i-1,0)], heads folded into batch."""
+    heads = 8 if d != 160 else 4
+    c = heads * d
+    qkv = rnd(n * f * nq, 3 * c, seed=50)
+    q, k, v = (qkv[:, i * c:(i + 1) * c].reshape(n * f, nq, c) for i in range(3))
+    former = torch.arange(f) - 1
+    former[0] = 0
+    gather = lambda t: torch.cat([t.reshape(n, f, nq, c)[:, [0] * f], t.reshape(n, f, nq, c)[:, former]], dim=2).reshape(n * f, 2 * nq, c)
+    ref = _unheads(_ref_attn(_heads(q, heads), _heads(gather(k), heads), _heads(gather(v), heads), d ** -0.5), heads)
+    g = qkv.cuda()
+    y = eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5)
+    close(y.reshape(n * f, nq, c), ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("d,nq,nk", [(8, 108, 11), (40, 300, 77), (80, 144, 77), (160, 40, 77)])
+def test_cross_attention(eng, d, nq, nk):
+    heads, n, f = 8, 2, 3
+    c = heads * d
+    q, kv = rnd(n * f * nq, c, seed=51), rnd(n * nk, 2 * c, seed=52)
+    k, v = kv[:, :c].reshape(n, nk, c), kv[:, c:].reshape(n, nk, c)
+    rep = lambda t: t.repeat_interleave(f, 0)
+    ref = _unheads(_ref_attn(_heads(q.reshape(n * f, nq, c), heads), _heads(rep(k), heads), _heads(rep(v), heads), d ** -0.5), heads)
+    gq, gkv = q.cuda(), kv.cuda()
+    y = eng.op_attention(gq, gkv[:, :c], gkv[:, c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nk, mode=1, scale=d ** -0.5)
+    close(y.reshape(n * f, nq, c), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_attention_online_softmax_rescale_branch(eng):
+    """Force the running max to jump at a late key tile (one key spiked against every query)."""
+    heads, d, n, f, nq = 8, 40, 1, 3, 100
+    c = heads * d
+    qkv = rnd(n * f * nq, 3 * c, seed=53)
+    qkv[2 * nq + 90, c:2 * c] *= 25.0          # a key of frame 2, in the 3rd tile of the 2nd segment for f = 3... and of frame>=?
+    qkv[70, c:2 * c] *= 25.0                   # a key of frame 0 (seen by every frame), 3rd tile
+    q, k, v = (qkv[:, i * c:(i + 1) * c].reshape(n * f, nq, c) for i in range(3))
+    former = torch.arange(f) - 1
+    former[0] = 0
+    gather = lambda t: torch.cat([t.reshape(n, f, nq, c)[:, [0] * f], t.reshape(n, f, nq, c)[:, former]], dim=2).reshape(n * f, 2 * nq, c)
+    ref = _unheads(_ref_attn(_heads(q, heads), _heads(gather(k), heads), _heads(gather(v), heads), d ** -0.5), heads)
+    g = qkv.cuda()
+    y = eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5)
+    close(y.reshape(n * f, nq, c), ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("d,f,hw", [(8, 3, 50), (40, 6, 33), (160, 6, 7)])
+def test_temporal_attention(eng, d, f, hw):
+    """attention.py:261-267: '(b f) d c -> (b d) f c', attention over frames, and back."""
+    heads, n = 8, 2
+    c = heads * d
+    qkv = rnd(n * f * hw, 3 * c, seed=54)
+    t = qkv.reshape(n, f, hw, 3 * c).permute(0, 2, 1, 3).reshape(n * hw, f, 3 * c)
+    q, k, v = t[..., :c], t[..., c:2 * c], t[..., 2 * c:]
+    ref = _unheads(_ref_attn(_heads(q, heads), _heads(k, heads), _heads(v, heads), d ** -0.5), heads)
+    ref = ref.reshape(n, hw, f, c).permute(0, 2, 1, 3).reshape(n * f * hw, c)
+    y = eng.op_temporal_attention(qkv.cuda(), n=n, F=f, HW=hw, heads=heads, D=d, scale=d ** -0.5)
+    close(y, ref, rtol=1e-4, atol=1e-5)

@@ -1,0 +1,119 @@
+"""CPU: the C-ABI library loads, exports every symbol the headers declare, and its host-side parts
+(state-dict key scheme, DDIM schedule) agree with the oracle and the reference-derived spec.  No GPU work."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from eeg2video_amd import _lib
+from eeg2video_amd.weights import UNetConfig, VAEConfig, unet_param_spec, vae_param_spec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.load()
+
+
+@pytest.fixture(scope="module")
+def host_ctx(lib):
+    cfg = _lib.E2VConfig()
+    lib.e2v_default_config(C.byref(cfg))
+    ctx = C.c_void_p()
+    assert lib.e2v_create(C.byref(cfg), -1, C.byref(ctx)) == 0
+    yield ctx
+    lib.e2v_destroy(ctx)
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(e2v_[a-z0-9_]+)\s*\(", text))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    declared = _declared("eeg2video_hip.h") | _declared("eeg2video_hip_ops.h")
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_default_config_is_sd_v1_4(lib):
+    cfg = _lib.E2VConfig()
+    lib.e2v_default_config(C.byref(cfg))
+    assert list(cfg.block_out_channels) == [320, 640, 1280, 1280] and cfg.cross_attention_dim == 768
+    assert cfg.attention_heads == 8 and cfg.norm_num_groups == 32 and abs(cfg.norm_eps - 1e-5) < 1e-12
+    assert list(cfg.vae_block_out_channels) == [128, 256, 512, 512] and cfg.vae_scaling_factor == 0.18215
+    assert cfg.num_train_timesteps == 1000 and cfg.steps_offset == 1 and cfg.beta_start == 0.00085
+
+
+def test_key_scheme_matches_python_spec(lib, host_ctx):
+    n = lib.e2v_num_expected_keys(host_ctx)
+    shape, nd = (C.c_int64 * 4)(), C.c_int()
+    got = {}
+    for i in range(n):
+        k = lib.e2v_expected_key(host_ctx, i, shape, C.byref(nd)).decode()
+        got[k] = tuple(shape[d] for d in range(nd.value))
+    want = dict(unet_param_spec(UNetConfig()))
+    want.update({"vae." + k: v for k, v in vae_param_spec(VAEConfig()).items()})
+    assert got == want and n == 798 + 248
+
+
+def test_ddim_timesteps_bit_exact(lib, host_ctx):
+    from oracle import DDIMOracle
+    for n in (1, 2, 3, 4, 7, 20, 50, 100, 250, 333, 1000):
+        out = np.empty(n, dtype=np.int64)
+        assert lib.e2v_ddim_timesteps(host_ctx, n, out.ctypes.data_as(_lib.c_int64_p)) == 0
+        assert np.array_equal(out, DDIMOracle().set_timesteps(n)), n
+    out = np.empty(4, dtype=np.int64)
+    lib.e2v_ddim_timesteps(host_ctx, 4, out.ctypes.data_as(_lib.c_int64_p))
+    assert out.tolist() == [751, 501, 251, 1]
+    assert lib.e2v_ddim_timesteps(host_ctx, 0, out.ctypes.data_as(_lib.c_int64_p)) == _lib.E2V_EINVAL
+
+
+def test_alpha_table_matches_torch_to_the_last_bits(lib, host_ctx):
+    from oracle import DDIMOracle
+    a = np.empty(1000, dtype=np.float32)
+    assert lib.e2v_ddim_alphas_cumprod(host_ctx, a.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    ref = DDIMOracle().alphas_cumprod.numpy()
+    assert np.max(np.abs(a - ref) / ref) < 1e-5
+    ref2 = ref.copy()
+    assert lib.e2v_set_alphas_cumprod(host_ctx, ref2.ctypes.data_as(C.POINTER(C.c_float)), 1000) == 0
+    lib.e2v_ddim_alphas_cumprod(host_ctx, a.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.array_equal(a, ref)
+
+
+def test_device_entry_points_refuse_host_only_context(lib, host_ctx):
+    assert lib.e2v_finalize_weights(host_ctx, 1) == _lib.E2V_ESTATE
+    assert b"host-only" in lib.e2v_last_error(host_ctx)
+    x = np.zeros(4, np.float32)
+    shape = (C.c_int64 * 1)(4)
+    assert lib.e2v_load_tensor(host_ctx, b"conv_in.bias", x.ctypes.data_as(C.c_void_p), 0, shape, 1) == _lib.E2V_ESTATE
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from eeg2video_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Engine()
+
+
+def test_mirror_input_checks_need_no_gpu():
+    """check_inputs / prepare_latents raise the reference's ValueErrors before any device work."""
+    import torch
+    from eeg2video_amd.pipeline import TuneAVideoPipeline
+    p = object.__new__(TuneAVideoPipeline)
+    p.vae_scale_factor = 8
+    with pytest.raises(ValueError, match="has to be of type"):
+        p.check_inputs("eeg", 288, 512, 1)
+    with pytest.raises(ValueError, match="divisible by 8"):
+        p.check_inputs(torch.zeros(1), 290, 512, 1)
+    with pytest.raises(ValueError, match="positive integer"):
+        p.check_inputs(torch.zeros(1), 288, 512, None)
+    with pytest.raises(ValueError, match="Unexpected latents shape"):
+        p.prepare_latents(1, 4, 6, 288, 512, torch.float32, torch.device("cpu"), None, torch.zeros(1, 4, 6, 36, 63))
