@@ -37,6 +37,7 @@ struct IgemmArgs {
     int geglu = 0;                 // W rows packed [32 value | 32 gate] per 64: out[m][n/2] = v * gelu(g)
     int batch = 1;                 // blockIdx.z; strides in floats
     long long sa0 = 0, sw = 0, sout = 0;
+    const float* zeros = nullptr;  // filled by the launcher: 16+ zero bytes, the source of masked loads
 };
 void igemm(const IgemmArgs& a, hipStream_t s);
 

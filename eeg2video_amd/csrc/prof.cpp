@@ -1,6 +1,7 @@
 #include "prof.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 
 namespace e2v {
@@ -12,6 +13,8 @@ Profiler& profiler() {
 
 void Profiler::begin() {
     entries.clear();
+    const char* d = std::getenv("E2V_PROFILE_DETAIL");
+    detail = d && d[0] == '1';
     on = true;
 }
 

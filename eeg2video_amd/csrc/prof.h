@@ -10,13 +10,14 @@
 namespace e2v {
 
 struct ProfEntry {
-    const char* name;
+    std::string name;
     double flops, bytes;
     hipEvent_t a, b;
 };
 
 struct Profiler {
     bool on = false;
+    bool detail = false;         // E2V_PROFILE_DETAIL=1: key igemm entries by shape as well
     std::vector<ProfEntry> entries;
     void begin();
     std::string end_json();      // synchronises, aggregates per kernel class, frees the events

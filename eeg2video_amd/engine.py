@@ -115,7 +115,7 @@ class Engine:
 
     def profile_end(self) -> dict:
         import json
-        buf = C.create_string_buffer(1 << 16)
+        buf = C.create_string_buffer(1 << 20)
         n = self.lib.e2v_profile_end(self.ctx, buf, len(buf))
         if n < 0:
             raise RuntimeError("e2v_profile_end failed")
