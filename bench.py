@@ -90,11 +90,15 @@ def main() -> int:
     ap.add_argument("--profile-ddim-steps", type=int, default=2, help="DDIM steps of the event-instrumented pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel-class table (JSON) here")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "E2V_FORCE_DEVICE" in os.environ:      # rehearsal only: several ranks on one GPU (with --backend gloo)
+        local = int(os.environ["E2V_FORCE_DEVICE"])
     if args.gpus != world:
         if args.gpus > 1:
             log(f"--gpus {args.gpus} needs a {args.gpus}-rank launch (python -m torch.distributed.run --nproc-per-node {args.gpus} ...)")
@@ -102,7 +106,10 @@ def main() -> int:
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     from eeg2video_amd.dist import all_gather_frames
     from eeg2video_amd.pipeline import build_pipeline
