@@ -15,6 +15,8 @@
 #include "kernels.h"
 #include "prof.h"
 
+#include <type_traits>
+
 namespace e2v {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -23,12 +25,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int D>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs p) {
     constexpr int LD = D + 4;               // padded LDS row: conflict-free ds_read_b128 of 16 rows
-    constexpr int T = (D + 31) / 32;        // 32-wide dv tiles of O^T
+    // O^T is built from 32-row MFMA tiles over the value columns.  When 8 columns are left over (d = 40: 32 + 8)
+    // they are accumulated on the VALU from the same P registers (128 FMAs per key tile, on the vector pipe while the
+    // matrix pipe runs the next MFMAs) instead of a second MFMA tile with 24 dead rows (16 of 52 MFMAs per tile).
+    constexpr int TF = D / 32;
+    constexpr bool VREM = (D - 32 * TF) == 8;
+    constexpr int T = VREM ? TF : (D + 31) / 32;
+    constexpr int TA = T > 0 ? T : 1;
     constexpr int G = D / 8;
     constexpr int DQ = D / 4;
-    constexpr int NF4 = 32 * DQ;
+    constexpr int KT = 32;                   // keys staged per barrier interval (64 measured no faster)
+    constexpr int NF4 = KT * DQ;
     constexpr int LPT = (NF4 + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buf][K | V][32][LD]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buf][K | V][KT][LD]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -48,7 +57,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs p) {
     } else {
         kvbase[0] = kvbase[1] = (size_t)smp * p.Nk;
     }
-    const int tps = (p.Nk + 31) / 32;
+    const int tps = (p.Nk + KT - 1) / KT;
     const int ntiles = nseg * tps;
 
     // Q fragments, pre-multiplied by scale * log2(e): scores live in the exp2 domain
@@ -67,7 +76,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs p) {
     f32x4 kreg[LPT], vreg[LPT];
     auto load_tile = [&](int tt) {
         const int seg = tt / tps;
-        const int key0 = (tt - seg * tps) * 32;
+        const int key0 = (tt - seg * tps) * KT;
 #pragma unroll
         for (int e = 0; e < LPT; ++e) {
             const int idx = tid + 256 * e;
@@ -86,8 +95,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs p) {
         }
     };
     auto store_tile = [&](int buf) {
-        float* Ks = smem + buf * (2 * 32 * LD);
-        float* Vs = Ks + 32 * LD;
+        float* Ks = smem + buf * (2 * KT * LD);
+        float* Vs = Ks + KT * LD;
 #pragma unroll
         for (int e = 0; e < LPT; ++e) {
             const int idx = tid + 256 * e;
@@ -99,11 +108,12 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs p) {
         }
     };
 
-    f32x16 acc[T];
+    f32x16 acc[TA];
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < TA; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f32x4 rem0 = {0.f, 0.f, 0.f, 0.f}, rem1 = {0.f, 0.f, 0.f, 0.f};     // value columns 32*TF+0..3 / +4..7
     float m_i = -INFINITY, l_i = 0.f;
 
     load_tile(0);
@@ -113,46 +123,60 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs p) {
     for (int tt = 0; tt < ntiles; ++tt) {
         const int buf = tt & 1;
         if (tt + 1 < ntiles) load_tile(tt + 1);
-        if (active) {
-            const float* Ks = smem + buf * (2 * 32 * LD);
-            const float* Vs = Ks + 32 * LD;
-            const int seg = tt / tps;
-            const int key0 = (tt - seg * tps) * 32;
+        const int seg_c = tt / tps;
+        const int kbase = (tt - seg_c * tps) * KT;
+        // one 32-key tile; `ragged` (compile-time) adds the key mask of a segment's last, partial tile
+        auto tile_body = [&](const int key0, const int sub, auto ragged) {
+            const float* Ks = smem + buf * (2 * KT * LD) + sub * 32 * LD;
+            const float* Vs = smem + buf * (2 * KT * LD) + KT * LD + sub * 32 * LD;
             // S^T[key][query] = sum_d K[key][d] Q[query][d]
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             f32x16 st;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = 0.f;
             const float* kp = Ks + j * LD + h * 4;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + g * 8);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[g][s], st, 0, 0, 0);
+                for (int s = 0; s < 4; ++s)
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[g][s], (g == 0 && s == 0) ? zero16 : st, 0, 0, 0);
             }
-            // online softmax; register r of lane half h holds key  key0 + (r&3) + 8(r>>2) + 4h
-            float mt = -INFINITY;
+            // online softmax; register r of lane half h holds key  key0 + (r&3) + 8(r>>2) + 4h.
+            // On gfx950 the fp32 MFMA runs at the vector rate and VALU instructions are NOT hidden behind it
+            // (measured: kernel cycles = MFMA busy + VALU active), so the softmax is kept lean: key masking only on
+            // the ragged last tile, raw v_exp_f32, and the accumulator rescale only when some row's max moved.
+            if constexpr (decltype(ragged)::value) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (key >= p.Nk) st[r] = -INFINITY;
-                mt = fmaxf(mt, st[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= p.Nk) st[r] = -INFINITY;
+                }
             }
-            mt = fmaxf(mt, __shfl_xor(mt, 32));
-            const float m_new = fmaxf(m_i, mt);
-            const float alpha = exp2f(m_i - m_new);
+            float mt = st[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mt = __builtin_fmaxf(mt, st[r]);
+            mt = __builtin_fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = __builtin_fmaxf(m_i, mt);
+            const bool moved = __any(m_new > m_i);                  // wave-uniform
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                st[r] = exp2f(st[r] - m_new);
+                st[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
                 ps += st[r];
             }
-            l_i = l_i * alpha + ps;
+            float alpha = 1.0f;
+            if (moved) {
+                alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+                l_i *= alpha;
+            }
+            l_i += ps;
             m_i = m_new;
             // O^T[dv][query] += sum_key V[key][dv] P[query][key]
 #pragma unroll
             for (int t = 0; t < T; ++t) {
+                if (moved) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+                }
                 const int dv = min(t * 32 + j, D - 1);
                 const float* vp = Vs + (4 * h) * LD + dv;
 #pragma unroll
@@ -161,6 +185,29 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs p) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[r], acc[t], 0, 0, 0);
                 }
             }
+            if constexpr (VREM) {      // value columns 32*TF .. 32*TF+7 for this lane's 16 keys
+                if (moved) {
+                    rem0 *= alpha;
+                    rem1 *= alpha;
+                }
+                const float* vr = Vs + (4 * h) * LD + 32 * TF;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* row = vr + ((r & 3) + 8 * (r >> 2)) * LD;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(row);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 4);
+                    rem0 += v0 * st[r];
+                    rem1 += v1 * st[r];
+                }
+            }
+        };
+#pragma unroll
+        for (int sub = 0; sub < KT / 32; ++sub) {
+            const int key0 = kbase + 32 * sub;
+            if (active && key0 < p.Nk) {
+                if (key0 + 32 <= p.Nk) tile_body(key0, sub, std::false_type{});
+                else tile_body(key0, sub, std::true_type{});
+            }
         }
         if (tt + 1 < ntiles) store_tile(buf ^ 1);
         __syncthreads();
@@ -168,6 +215,13 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs p) {
 
     // lanes l and l+32 hold the two key halves of the same query: fold the partial row sums
     const float l_tot = l_i + __shfl_xor(l_i, 32);
+    if constexpr (VREM) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            rem0[e] += __shfl_xor(rem0[e], 32);
+            rem1[e] += __shfl_xor(rem1[e], 32);
+        }
+    }
     if (active && q0 + j < p.Nq) {
         const float inv = 1.0f / l_tot;
         float* op = p.o + ((size_t)sf * p.Nq + q0 + j) * p.ldo + head * D;
@@ -183,6 +237,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs p) {
                     *reinterpret_cast<f32x4*>(op + dv) = o;
                 }
             }
+        if constexpr (VREM) {          // half h writes columns 32*TF + 4h .. +3
+            const f32x4 o = (h ? rem1 : rem0) * inv;
+            *reinterpret_cast<f32x4*>(op + 32 * TF + 4 * h) = o;
+        }
     }
 }
 

@@ -23,14 +23,13 @@ static constexpr int LDS_LD = 36;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int BM, int BN, int WGM, int WGN, int ABL = 0, int NBUF = 2>
-__global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(const IgemmArgs p) {
+template <int BM, int BN, int WGM, int WGN, int ABL, int NBUF>
+__device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, const int n0, float* smem) {
     constexpr int NT = 64 * WGM * WGN;              // threads; waves are laid out WGM x WGN over the tile
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int RPP = NT / 8;                     // tile rows covered by one pass of the loader (8 lanes per row)
     constexpr int AR = BM / RPP, BR = BN / RPP;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + NBUF * BM * LDS_LD;
 
@@ -38,17 +37,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(const IgemmArgs p
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-
-    // XCD-aware tile order: the 8 XCDs are dealt blocks round-robin; give each XCD a contiguous run of
-    // tiles (n fastest) so that the column blocks sharing one gathered A tile hit the same L2.
-    const int nbn = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int tile;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int bm = tile / nbn, bn = tile % nbn;
 
     const float* __restrict__ a0 = p.a0 + (size_t)blockIdx.z * p.sa0;
     const float* __restrict__ a1 = p.a1;
@@ -87,7 +75,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(const IgemmArgs p
     bool b_ok[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-        const int n = bn * BN + r0 + RPP * j;
+        const int n = n0 + r0 + RPP * j;
         b_ok[j] = n < p.N;
         b_row[j] = (size_t)(b_ok[j] ? n : 0) * p.ldw + c4 * 4;
     }
@@ -233,11 +221,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(const IgemmArgs p
     const int rquad = (lane >> 5) * 4;
     if (p.geglu) {
         if constexpr (TN == 2) {
-            const int nv = bn * BN + wn * WN + col;
+            const int nv = n0 + wn * WN + col;
             if (nv + 32 < p.N) {
                 const float bv = p.bias ? p.bias[nv] : 0.f;
                 const float bg = p.bias ? p.bias[nv + 32] : 0.f;
-                const int no = (bn * BN + wn * WN) / 2 + col;
+                const int no = (n0 + wn * WN) / 2 + col;
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -255,7 +243,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(const IgemmArgs p
     }
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
-        const int n = bn * BN + wn * WN + ni * 32 + col;
+        const int n = n0 + wn * WN + ni * 32 + col;
         if (n >= p.N) continue;
         const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
@@ -273,22 +261,70 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(const IgemmArgs p
     }
 }
 
-template <int BM, int BN, int WGM = 2, int WGN = 2, int ABL = 0, int NBUF = 2>
-static void launch_igemm(const IgemmArgs& a, hipStream_t s) {
+// One launch runs a MIX of tile shapes (IgemmArgs::rb1/w1/s1/s2): row blocks [0, rb1) are cut into w1 tiles of
+// 128x128 followed by s1 tiles of 128x64 (N = 320 -> 2 + 1, no wasted columns); row blocks [rb1, nbm) are cut into s2
+// tiles of 128x64 only.  The launcher sizes rb1 so that the 128x128 part fills whole rounds of the 512 resident
+// tiles and the ragged last round runs as half-size tiles (L1: 5 rounds -> 4.5, L2: 3 -> 2.5).
+// XCD-aware order: the 8 XCDs are dealt blocks round-robin; each XCD gets a contiguous run of tiles (columns
+// fastest), so the column tiles that share one gathered A tile hit the same L2.
+template <int ABL>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // XCD x = blockIdx % 8 owns the contiguous row blocks [x*nbm/8, (x+1)*nbm/8); the last `tail` of them are cut
+    // into 128x64 tiles only, the others into w1 tiles of 128x128 + s1 of 128x64.  Every XCD therefore ends on
+    // half-size tiles (an even tail), and column tiles sharing one gathered A tile stay on one L2.
+    const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
+    const int nrb = rb_hi - rb_lo;
+    const int tail = min(nrb, p.tail_rb);
+    const int per1 = p.w1 + p.s1;
+    const int n1 = (nrb - tail) * per1;
+    if (loc < n1) {
+        const int r = loc / per1, j = loc - r * per1;
+        if (j < p.w1)
+            igemm_tile<128, 128, 2, 2, ABL, 2>(p, rb_lo + r, j * 128, smem);
+        else
+            igemm_tile<128, 64, 2, 2, ABL, 2>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem);
+    } else {
+        const int t = loc - n1;
+        if (t >= tail * p.s2) return;                     // padding block of the 8 x max-chunk grid
+        const int r = t / p.s2;
+        igemm_tile<128, 64, 2, 2, ABL, 2>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem);
+    }
+}
+
+// dedicated single-shape kernels (E2V_IGEMM_SCHED=2: A/B reference for the mixed kernel)
+template <int BN>
+__global__ __launch_bounds__(256) void igemm_kernel_single(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nbn = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    igemm_tile<128, BN, 2, 2, 0, 2>(p, tile / nbn, (tile % nbn) * BN, smem);
+}
+
+template <int ABL>
+static void launch_igemm(const IgemmArgs& a, int ntiles, const char* cls, hipStream_t s) {
     static bool configured = false;
-    constexpr size_t smem = (size_t)NBUF * (BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t smem = (size_t)2 * (128 + 128) * LDS_LD * sizeof(float);
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WGM, WGN, ABL, NBUF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<ABL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         configured = true;
     }
-    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
-    dim3 grid(nbm * nbn, 1, a.batch);
+    dim3 grid(ntiles, 1, a.batch);
     const double K = (double)a.taps * (a.c0 + a.c1);
     const double rows_in = a.taps == 1 ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
-    ProfScope ps(BN == 128 ? "igemm_f32_128x128" : "igemm_f32_128x64", 2.0 * a.M * a.N * K * a.batch,
+    std::string pname = cls;
+    if (profiler().on && profiler().detail)
+        pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t" +
+                 std::to_string(a.taps) + (a.stride > 1 ? " s2" : "") + (a.upsample ? " up" : "") + (a.c1 ? " cat" : "") +
+                 (a.geglu ? " geglu" : "") + (a.batch > 1 ? " b" + std::to_string(a.batch) : "") + " rb1=" +
+                 std::to_string(a.rb1) + " w" + std::to_string(a.w1) + " s" + std::to_string(a.s1);
+    ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
                  4.0 * a.batch * (rows_in * (a.c0 + a.c1) + (double)a.N * K + (double)a.M * (a.geglu ? a.N / 2 : a.N)), s);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WGM, WGN, ABL, NBUF>), grid, dim3(64 * WGM * WGN), smem, s, a);
+    hipLaunchKernelGGL((igemm_kernel<ABL>), grid, dim3(256), smem, s, a);
 }
 
 // 256 zero bytes per device: the source of every masked 16-byte load
@@ -312,27 +348,67 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
         a.Wo = a.Wi = a.Ws = a.M;
         a.stride = 1; a.pad = 0; a.upsample = 0;
     }
+    // ---- tile schedule ----------------------------------------------------------------------------------
     static const int abl = [] { const char* e = std::getenv("E2V_IGEMM_ABLATE"); return e ? std::atoi(e) : 0; }();
-    static const int cfg = [] { const char* e = std::getenv("E2V_IGEMM_CFG"); return e ? std::atoi(e) : 0; }();
-    // 128x64 only where a 128-wide tile would waste > 12 % of its columns (N = 320: 384 vs 320)
-    const long n128 = (a.N + 127) / 128 * 128;
-    const bool narrow = !a.geglu && (double)(n128 - a.N) > 0.12 * (double)n128;
-    if (abl == 1) {      // timing experiment only (wrong results): no global loads inside the k-loop
-        if (!narrow) launch_igemm<128, 128, 2, 2, 1>(a, s); else launch_igemm<128, 64, 2, 2, 1>(a, s);
+    static const int sched = [] { const char* e = std::getenv("E2V_IGEMM_SCHED"); return e ? std::atoi(e) : 1; }();
+    const int nbm = (a.M + 127) / 128;
+    const int slots = 512;                                   // 2 workgroups per CU x 256 CUs
+    a.s2 = (a.N + 63) / 64;
+    a.w1 = a.N / 128;                                        // full 128-wide column tiles
+    const int rem = a.N - a.w1 * 128;
+    a.s1 = rem == 0 ? 0 : (rem <= 64 ? 1 : 0);
+    if (rem > 64) a.w1 += 1;                                 // 65..127 leftover columns: one more (masked) wide tile
+    a.rb1 = nbm;
+    const char* cls = "igemm_f32";
+    if (a.geglu) {                                           // the GEGLU epilogue pairs the two 32-column halves of a wave
+        a.w1 = (a.N + 127) / 128; a.s1 = 0;
+    } else if (a.w1 == 0) {                                  // N <= 64
+        a.rb1 = 0;
+    } else if (sched == 1) {
+        // per XCD: 64 resident tiles per round.  Keep whole rounds of full-size tiles; if what is left of the XCD's
+        // chunk is at most half a round, run it as half-size tiles (it then takes about half a round's time).
+        const double per_rb = a.w1 + 0.5 * a.s1;             // cost of one row block in 128x128 units
+        const int nrb = (nbm + 7) / 8;                       // row blocks of the largest chunk
+        const double units = per_rb * nrb * a.batch;
+        const int xslots = slots / 8;
+        if (units * 8 < slots) {
+            a.rb1 = 0;                                       // less than one round: half-size tiles spread over more CUs
+        } else if (a.batch == 1) {
+            const int full = (int)std::floor(units / xslots);
+            const int wide_rb = (int)std::floor(full * xslots / per_rb);
+            const int tail = nrb - wide_rb;
+            if (tail > 0 && tail * per_rb <= 0.5 * xslots) a.rb1 = nbm - 8 * tail < 0 ? 0 : nbm - 8 * tail;
+        }
+    }
+    a.nbm = nbm;
+    a.tail_rb = (nbm - a.rb1 + 7) / 8;                       // per XCD chunk (rb1 == 0: every row block is "tail")
+    if (a.rb1 == 0) a.tail_rb = nbm;
+    int ntiles = 0;                                          // grid = 8 x the largest chunk's tile count
+    for (int x = 0; x < 8; ++x) {
+        const int nrb = (int)(((long)(x + 1) * nbm) >> 3) - (int)(((long)x * nbm) >> 3);
+        const int tail = nrb < a.tail_rb ? nrb : a.tail_rb;
+        const int t = (nrb - tail) * (a.w1 + a.s1) + tail * a.s2;
+        ntiles = t > ntiles ? t : ntiles;
+    }
+    ntiles *= 8;
+    if (sched == 2 && !a.geglu && abl == 0) {               // A/B reference: one tile shape per launch
+        const long n128 = (a.N + 127) / 128 * 128;
+        const bool narrow = (double)(n128 - a.N) > 0.12 * (double)n128;
+        static bool cfgd = false;
+        if (!cfgd) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel_single<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel_single<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+            cfgd = true;
+        }
+        const int nb = nbm * (narrow ? (a.N + 63) / 64 : (a.N + 127) / 128);
+        ProfScope ps(narrow ? "igemm_f32_128x64" : "igemm_f32_128x128", 2.0 * a.M * a.N * (double)a.taps * (a.c0 + a.c1) * a.batch, 0.0, s);
+        if (narrow) hipLaunchKernelGGL((igemm_kernel_single<64>), dim3(nb, 1, a.batch), dim3(256), 55296, s, a);
+        else hipLaunchKernelGGL((igemm_kernel_single<128>), dim3(nb, 1, a.batch), dim3(256), 73728, s, a);
         return;
     }
-    if (abl == 2) {      // timing experiment only: no loads, no LDS stores, no barriers (MFMA + fragment reads)
-        if (!narrow) launch_igemm<128, 128, 2, 2, 2>(a, s); else launch_igemm<128, 64, 2, 2, 2>(a, s);
-        return;
-    }
-    if (narrow) { launch_igemm<128, 64, 2, 2>(a, s); return; }
-    switch (cfg) {       // experiments: alternative wave layouts of the wide tile
-        case 2: launch_igemm<128, 128, 1, 2>(a, s); break;
-        case 3: launch_igemm<256, 128, 2, 2>(a, s); break;
-        case 4: launch_igemm<256, 128, 4, 2>(a, s); break;
-        case 5: launch_igemm<128, 128, 2, 2, 0, 1>(a, s); break;
-        default: launch_igemm<128, 128, 2, 2>(a, s); break;
-    }
+    if (abl == 1) launch_igemm<1>(a, ntiles, cls, s);
+    else if (abl == 2) launch_igemm<2>(a, ntiles, cls, s);
+    else launch_igemm<0>(a, ntiles, cls, s);
 }
 
 // ---- one-off weight re-layout ---------------------------------------------------------------------

@@ -38,6 +38,7 @@ struct IgemmArgs {
     int batch = 1;                 // blockIdx.z; strides in floats
     long long sa0 = 0, sw = 0, sout = 0;
     const float* zeros = nullptr;  // filled by the launcher: 16+ zero bytes, the source of masked loads
+    int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, tail_rb = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
 };
 void igemm(const IgemmArgs& a, hipStream_t s);
 

@@ -11,10 +11,11 @@ t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 lat = torch.stack([t(counter_normal(1234 + k, "latent", (4, 6, 36, 64))) for k in range(B)]).cuda()
 cond = torch.stack([t(counter_normal(1235 + k, "cond", (77, 768))) for k in range(B)]).cuda()
 unc = t(counter_normal(1236, "uncond", (1, 77, 768))).cuda()
-eng.generate(lat, cond, unc, 1, 12.5, 0.0, decode=True)
+DEC = os.environ.get("DECODE", "1") == "1"
+eng.generate(lat, cond, unc, 1, 12.5, 0.0, decode=DEC)
 torch.cuda.synchronize()
 eng.profile_begin()
-eng.generate(lat, cond, unc, 1, 12.5, 0.0, decode=True)
+eng.generate(lat, cond, unc, 1, 12.5, 0.0, decode=DEC)
 tab = eng.profile_end()
 tot = sum(v["ms"] for v in tab.values())
 rows = sorted(tab.items(), key=lambda kv: -kv[1]["ms"])
