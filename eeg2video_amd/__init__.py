@@ -11,7 +11,7 @@ Layout (only what the path needs):
 
 The compute path has no CPU fallback: without the built library or without a GPU it raises.
 """
-from .weights import TINY_UNET, TINY_VAE, UNetConfig, VAEConfig  # noqa: F401
+from .weights import TINY_SEMANTIC, TINY_UNET, TINY_VAE, SemanticConfig, UNetConfig, VAEConfig  # noqa: F401
 
 __all__ = ["UNetConfig", "VAEConfig", "TINY_UNET", "TINY_VAE", "Engine", "UNet3DConditionModel", "AutoencoderKL",
            "DDIMScheduler", "TuneAVideoPipeline", "build_pipeline"]

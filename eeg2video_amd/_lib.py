@@ -28,6 +28,7 @@ class E2VConfig(C.Structure):
         ("vae_scaling_factor", C.c_double),
         ("num_train_timesteps", C.c_int), ("beta_start", C.c_double), ("beta_end", C.c_double),
         ("steps_offset", C.c_int),
+        ("sem_in_features", C.c_int), ("sem_hidden", C.c_int), ("sem_tokens", C.c_int),
     ]
 
 
@@ -57,6 +58,9 @@ SIGNATURES = {
     "e2v_vae_decode": (_i, [_ctx, _p, _i, _i, _i, _i, _i, _p, _stream]),
     "e2v_vae_encode": (_i, [_ctx, _p, _i, _i, _i, _p, _p, _stream]),
     "e2v_generate": (_i, [_ctx, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p, _p, _stream]),
+    "e2v_semantic_predict": (_i, [_ctx, _p, _i, _p, _stream]),
+    "e2v_dana_noise": (_i, [_ctx, _p, _p, _p, c_int64_p, _i, _f, _i, _i, _i, _i, _i, _p, _stream]),
+    "e2v_frames_to_uint8": (_i, [_ctx, _p, _p, _i64, _stream]),
     "e2v_device_bytes": (_i64, [_ctx]),
     "e2v_profile_begin": (_i, [_ctx]),
     "e2v_profile_end": (_i64, [_ctx, C.c_char_p, _i64]),

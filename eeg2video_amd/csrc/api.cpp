@@ -79,6 +79,7 @@ void e2v_default_config(e2v_config* c) {
     std::memcpy(c->vae_block_out_channels, vb, sizeof(vb));
     c->vae_layers_per_block = 2; c->vae_norm_num_groups = 32; c->vae_norm_eps = 1e-6f; c->vae_scaling_factor = 0.18215;
     c->num_train_timesteps = 1000; c->beta_start = 0.00085; c->beta_end = 0.012; c->steps_offset = 1;
+    c->sem_in_features = 310; c->sem_hidden = 10000; c->sem_tokens = 77;
 }
 
 const char* e2v_version(void) { return "eeg2video_hip 0.1 (gfx950, fp32 MFMA)"; }
@@ -172,7 +173,7 @@ e2v_status e2v_load_tensor(e2v_ctx* c, const char* key, const void* host, e2v_dt
 e2v_status e2v_finalize_weights(e2v_ctx* c, int which) {
     if (!c) return E2V_EINVAL;
     return guarded(c, [&] {
-        E2V_REQUIRE(which >= 1 && which <= 3, E2V_EINVAL, "which must be 1 (UNet), 2 (VAE) or 3");
+        E2V_REQUIRE(which >= 1 && which <= 7, E2V_EINVAL, "which is a bit mask: 1 UNet, 2 VAE, 4 semantic predictor");
         c->finalize(which);
     });
 }
@@ -194,6 +195,71 @@ e2v_status e2v_set_alphas_cumprod(e2v_ctx* c, const float* t, int n) {
     if (!c || !t || n != c->cfg.num_train_timesteps) return E2V_EINVAL;
     c->alphas.assign(t, t + n);
     return E2V_OK;
+}
+
+// ---- SURVEY 8(f) rows ---------------------------------------------------------------------------------------
+e2v_status e2v_semantic_predict(e2v_ctx* c, const float* eeg, int B, float* out, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(c->sem_ready, E2V_ESTATE, "semantic predictor weights are not finalized");
+        E2V_REQUIRE(eeg && out && B > 0, E2V_EINVAL, "bad arguments");
+        hipStream_t s = S(stream);
+        Act x(c->pool, B, c->sem_in_pad);
+        pad_cols(eeg, c->cfg.sem_in_features, x.p, c->sem_in_pad, B, s);
+        for (size_t i = 0; i < c->sem.size(); ++i) {              // Linear -> ReLU ... -> Linear (train_semantic_predictor.py:14-28)
+            const LinW& w = c->sem[i];
+            const bool last = i + 1 == c->sem.size();
+            Act y;
+            if (!last) y = Act(c->pool, B, w.out);
+            IgemmArgs g;
+            g.a0 = x.p; g.c0 = w.in; g.lda0 = w.in; g.w = w.w; g.ldw = w.in; g.bias = w.b;
+            g.out = last ? out : y.p; g.ldc = w.out; g.M = B; g.N = w.out; g.taps = 1; g.relu = last ? 0 : 1;
+            igemm(g, s);
+            if (!last) x = std::move(y);
+        }
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+e2v_status e2v_dana_noise(e2v_ctx* c, const float* x0, const float* ed, const float* es, const int64_t* host_t, int steps,
+                          float dyn_beta, int B, int F, int C, int H, int W, float* out, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(x0 && ed && es && host_t && out, E2V_EINVAL, "null argument");
+        E2V_REQUIRE(B > 0 && F > 0 && C > 0 && H > 0 && W > 0 && steps > 1, E2V_ESHAPE, "non-positive dimension");
+        E2V_REQUIRE(dyn_beta >= 0.f && dyn_beta <= 1.f, E2V_EINVAL, "dynamic_beta must be in [0, 1]");
+        // linear betas 1e-4 .. 0.02 (DANA_module.py:42-52), alphas_cumprod in fp32 as torch.cumprod does
+        std::vector<float> ac(steps);
+        {
+            const float b0 = 0.0001f, b1 = 0.02f, step = (b1 - b0) / (float)(steps - 1);
+            float prod = 1.f;
+            for (int i = 0; i < steps; ++i) {
+                const float beta = (i < steps / 2) ? b0 + step * (float)i : b1 - step * (float)(steps - 1 - i);
+                prod *= 1.f - beta;
+                ac[i] = prod;
+            }
+        }
+        std::vector<float> coef(2 * (size_t)B);
+        for (int b = 0; b < B; ++b) {
+            E2V_REQUIRE(host_t[b] >= 0 && host_t[b] < steps, E2V_EINVAL, "timestep out of range");
+            coef[2 * b] = std::sqrt(ac[(size_t)host_t[b]]);
+            coef[2 * b + 1] = std::sqrt(1.f - ac[(size_t)host_t[b]]);
+        }
+        hipStream_t s = S(stream);
+        Act dc(c->pool, B, 2);
+        E2V_HIP(hipMemcpyAsync(dc.p, coef.data(), coef.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        dana_noise(x0, ed, es, dc.p, std::sqrt(1.f - dyn_beta), std::sqrt(dyn_beta), out, B, F, C, H * W, s);
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+e2v_status e2v_frames_to_uint8(e2v_ctx* c, const float* videos, uint8_t* out, int64_t count, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(videos && out && count >= 0, E2V_EINVAL, "bad arguments");
+        frames_to_u8(videos, out, count, S(stream));
+        E2V_HIP(hipGetLastError());
+    });
 }
 
 e2v_status e2v_profile_begin(e2v_ctx* c) {

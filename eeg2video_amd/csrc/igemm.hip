@@ -255,6 +255,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
                     float v = acc[mi][ni][r] * p.alpha + bv;
                     if (p.rowbias) v += p.rowbias[(size_t)(m / p.rows_per_sample) * p.rb_ld + n];
                     if (p.resid) v += p.resid[(size_t)m * p.ldr + n];
+                    if (p.relu) v = fmaxf(v, 0.f);
                     out[(size_t)m * p.ldc + n] = v;
                 }
             }

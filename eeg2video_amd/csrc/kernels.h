@@ -34,6 +34,7 @@ struct IgemmArgs {
     int stride = 1, pad = 0;       // pad = rows/cols of zeros above/left (below/right is implied by Hi/Wi)
     int upsample = 0; float ups_h = 1.f, ups_w = 1.f;
     float alpha = 1.f;
+    int relu = 0;                  // out = max(out, 0) after bias (semantic-predictor MLP)
     int geglu = 0;                 // W rows packed [32 value | 32 gate] per 64: out[m][n/2] = v * gelu(g)
     int batch = 1;                 // blockIdx.z; strides in floats
     long long sa0 = 0, sw = 0, sout = 0;
@@ -103,5 +104,15 @@ void transpose2d(const float* in, int ld_in, float* out, int ld_out, int rows, i
 void ddim_cfg_step(const float* eps_u, const float* eps_c, const float* x, float* x_out, long long count,
                    float guidance, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_p, float sqrt_1m_a_p,
                    hipStream_t s);
+
+// (f) rows -------------------------------------------------------------------------------------------
+// DANA noise (EEG2Video/models/DANA_module.py:52-72) fused with the caller's layout fix 'a b c d e -> a c b d e'
+// (inference_eeg2video.py:77,82): x0, eps_div [B,F,C,HW], eps_same [B,1,C,HW] -> out [B,C,F,HW];
+// coef [B][2] = (sqrt(abar_t), sqrt(1 - abar_t)) per clip (device).
+void dana_noise(const float* x0, const float* eps_div, const float* eps_same, const float* coef, float sqrt_1m_beta,
+                float sqrt_beta, float* out, int B, int F, int C, int HW, hipStream_t s);
+// (x * 255) truncated to uint8, as save_videos_grid does (tuneavideo/util.py:29)
+void frames_to_u8(const float* in, unsigned char* out, long long count, hipStream_t s);
+void pad_cols(const float* in, int cols, float* out, int cols_pad, long long rows, hipStream_t s);
 
 }  // namespace e2v

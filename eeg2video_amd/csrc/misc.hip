@@ -150,4 +150,61 @@ void ddim_cfg_step(const float* eps_u, const float* eps_c, const float* x, float
                        (size_t)count, guidance, sqrt_a_t, sqrt_1m_a_t, sqrt_a_p, sqrt_1m_a_p);
 }
 
+// ---- SURVEY 8(f) rows ---------------------------------------------------------------------------------------
+__global__ void dana_kernel(const float* __restrict__ x0, const float* __restrict__ ed, const float* __restrict__ es,
+                            const float* __restrict__ coef, float s1b, float sb, float* __restrict__ out, int B, int F, int C,
+                            int HW) {
+    const size_t total = (size_t)B * C * F * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = i % HW;
+        size_t r = i / HW;
+        const int f = r % F; r /= F;
+        const int c = r % C;
+        const int b = r / C;
+        const size_t src = (((size_t)b * F + f) * C + c) * HW + p;          // [B,F,C,HW]
+        const size_t same = ((size_t)b * C + c) * HW + p;                   // [B,1,C,HW]
+        const float noise = ed[src] * s1b + es[same] * sb;                  // DANA_module.py:60-61
+        out[i] = coef[2 * b] * x0[src] + coef[2 * b + 1] * noise;           // :71-72
+    }
+}
+void dana_noise(const float* x0, const float* eps_div, const float* eps_same, const float* coef, float sqrt_1m_beta,
+                float sqrt_beta, float* out, int B, int F, int C, int HW, hipStream_t s) {
+    const size_t total = (size_t)B * C * F * HW;
+    if (!total) return;
+    ProfScope ps("dana_noise", 6.0 * total, 4.0 * total * 3.2, s);
+    hipLaunchKernelGGL(dana_kernel, dim3(grid_for(total)), dim3(256), 0, s, x0, eps_div, eps_same, coef, sqrt_1m_beta, sqrt_beta,
+                       out, B, F, C, HW);
+}
+
+__global__ void frames_to_u8_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, size_t count) {
+    const size_t n4 = count / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + 4 * i);
+        uchar4 o;
+        o.x = (unsigned char)(v[0] * 255.f); o.y = (unsigned char)(v[1] * 255.f);
+        o.z = (unsigned char)(v[2] * 255.f); o.w = (unsigned char)(v[3] * 255.f);
+        *reinterpret_cast<uchar4*>(out + 4 * i) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = n4 * 4; i < count; ++i) out[i] = (unsigned char)(in[i] * 255.f);
+}
+void frames_to_u8(const float* in, unsigned char* out, long long count, hipStream_t s) {
+    if (count <= 0) return;
+    ProfScope ps("frames_to_u8", 1.0 * count, 5.0 * count, s);
+    hipLaunchKernelGGL(frames_to_u8_kernel, dim3(grid_for((size_t)count / 4 + 1)), dim3(256), 0, s, in, out, (size_t)count);
+}
+
+__global__ void pad_cols_kernel(const float* __restrict__ in, int cols, float* __restrict__ out, int cp, size_t rows) {
+    const size_t total = rows * cp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % cp;
+        const size_t r = i / cp;
+        out[i] = c < cols ? in[r * cols + c] : 0.f;
+    }
+}
+void pad_cols(const float* in, int cols, float* out, int cols_pad, long long rows, hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(pad_cols_kernel, dim3(grid_for((size_t)rows * cols_pad)), dim3(256), 0, s, in, cols, out, cols_pad, (size_t)rows);
+}
+
 }  // namespace e2v

@@ -129,6 +129,13 @@ void e2v_ctx::expected_keys() {
     s.conv("vae.decoder.conv_out", cfg.vae_in_channels, vb[0], 3);
     s.conv("vae.quant_conv", 2 * lat, 2 * lat, 1);
     s.conv("vae.post_quant_conv", lat, lat, 1);
+
+    // ---- Semantic Predictor ("semantic." prefix; nn.Sequential indices of train_semantic_predictor.py:14-28) ----
+    if (cfg.sem_in_features > 0 && cfg.sem_hidden > 0) {
+        const int dims[6] = {cfg.sem_in_features, cfg.sem_hidden, cfg.sem_hidden, cfg.sem_hidden, cfg.sem_hidden,
+                             cfg.sem_tokens * cfg.cross_attention_dim};
+        for (int i = 0; i < 5; ++i) s.lin("semantic.mlp." + std::to_string(2 * i), dims[i + 1], dims[i]);
+    }
 }
 
 float* e2v_ctx::dev_alloc(size_t floats) {
@@ -295,6 +302,18 @@ void e2v_ctx::finalize(int which) {
         v.enc_out = P.conv3("vae.encoder.conv_out");
         vae = std::move(v);
     }
+    if (which & 4) {
+        E2V_REQUIRE(cfg.sem_in_features > 0 && cfg.sem_hidden > 0, E2V_ESTATE, "the config has no semantic predictor");
+        sem.clear();
+        for (int i = 0; i < 5; ++i) sem.push_back(P.lin("semantic.mlp." + std::to_string(2 * i)));
+        sem_in_pad = (cfg.sem_in_features + 3) / 4 * 4;          // 310 -> 312: 16-byte rows for the gather
+        if (sem_in_pad != cfg.sem_in_features) {
+            float* wp = dev_alloc((size_t)sem[0].out * sem_in_pad);
+            pad_cols(sem[0].w, cfg.sem_in_features, wp, sem_in_pad, sem[0].out, nullptr);
+            sem[0].w = wp;
+            sem[0].in = sem_in_pad;
+        }
+    }
     E2V_HIP(hipStreamSynchronize(nullptr));
     E2V_HIP(hipGetLastError());
     // the torch-layout copies of re-laid-out tensors are no longer needed
@@ -309,6 +328,7 @@ void e2v_ctx::finalize(int which) {
     };
     for (const auto& k : keys) {
         const bool is_vae = k.rfind("vae.", 0) == 0;
+        if (k.rfind("semantic.", 0) == 0) continue;
         if ((is_vae && !(which & 2)) || (!is_vae && !(which & 1))) continue;
         const WTensor& w = raw[k];
         const bool conv3 = w.shape.size() == 4 && w.shape[2] == 3;
@@ -321,6 +341,7 @@ void e2v_ctx::finalize(int which) {
     }
     if (which & 1) unet_ready = true;
     if (which & 2) vae_ready = true;
+    if (which & 4) sem_ready = true;
 }
 
 // =====================================================================================================

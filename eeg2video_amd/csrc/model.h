@@ -81,7 +81,9 @@ struct e2v_ctx {
     e2v::Pool pool;
     e2v::UNetW unet;
     e2v::VAEW vae;
-    bool unet_ready = false, vae_ready = false;
+    bool unet_ready = false, vae_ready = false, sem_ready = false;
+    std::vector<e2v::LinW> sem;                                  // semantic predictor layers (first one K-padded to 4)
+    int sem_in_pad = 0;
     std::vector<float> alphas;                                   // host alpha-bar table
     float* gn_part = nullptr; size_t gn_part_floats = 0;         // GroupNorm workspaces (grown on demand)
     float* gn_scale = nullptr; size_t gn_scale_floats = 0;

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .weights import UNetConfig, VAEConfig
+from .weights import SemanticConfig, UNetConfig, VAEConfig
 
 _ERRORS = {
     _lib.E2V_EINVAL: ValueError,
@@ -30,14 +30,15 @@ def _stream() -> int:
 class Engine:
     """Owns one ``e2v_ctx``.  ``unet_cfg`` / ``vae_cfg`` mirror the reference configs."""
 
-    UNET, VAE = 1, 2
+    UNET, VAE, SEMANTIC = 1, 2, 4
 
-    def __init__(self, unet_cfg: UNetConfig = UNetConfig(), vae_cfg: VAEConfig = VAEConfig(), device: int = 0):
+    def __init__(self, unet_cfg: UNetConfig = UNetConfig(), vae_cfg: VAEConfig = VAEConfig(), device: int = 0,
+                 sem_cfg: SemanticConfig = SemanticConfig()):
         if not torch.cuda.is_available():
             raise RuntimeError("eeg2video_amd needs an AMD GPU (torch.cuda.is_available() is False); "
                                "there is no CPU path")
         self.lib = _lib.load()
-        self.unet_cfg, self.vae_cfg = unet_cfg, vae_cfg
+        self.unet_cfg, self.vae_cfg, self.sem_cfg = unet_cfg, vae_cfg, sem_cfg
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         torch.zeros(1, device=self.device)          # make sure torch has initialised the device's context
@@ -55,6 +56,7 @@ class Engine:
         cfg.vae_layers_per_block = vae_cfg.layers_per_block
         cfg.vae_norm_num_groups, cfg.vae_norm_eps = vae_cfg.norm_num_groups, vae_cfg.norm_eps
         cfg.vae_scaling_factor = vae_cfg.scaling_factor
+        cfg.sem_in_features, cfg.sem_hidden, cfg.sem_tokens = sem_cfg.in_features, sem_cfg.hidden, sem_cfg.tokens
         self._cfg = cfg
         ctx = C.c_void_p()
         st = self.lib.e2v_create(C.byref(cfg), device, C.byref(ctx))
@@ -197,6 +199,38 @@ class Engine:
             float(guidance_scale), float(eta), videos.data_ptr() if decode else None,
             lat_out.data_ptr() if return_latents else None, _stream()))
         return (videos, lat_out) if return_latents else videos
+
+    # ------------------------------------------------------------------ the steps either side of the path
+    def semantic_predict(self, eeg: torch.Tensor) -> torch.Tensor:
+        x = self._dev(eeg, "eeg")
+        if x.dim() != 2 or x.shape[1] != self.sem_cfg.in_features:
+            raise ValueError(f"expected eeg [B,{self.sem_cfg.in_features}], got {tuple(x.shape)}")
+        out = torch.empty((x.shape[0], self.sem_cfg.tokens * self.unet_cfg.cross_attention_dim), device=self.device,
+                          dtype=torch.float32)
+        self._check(self.lib.e2v_semantic_predict(self.ctx, x.data_ptr(), x.shape[0], out.data_ptr(), _stream()))
+        return out
+
+    def dana_noise(self, x0: torch.Tensor, eps_div: torch.Tensor, eps_same: torch.Tensor, t: Sequence[int],
+                   dynamic_beta: float, time_steps: int = 500) -> torch.Tensor:
+        """``[B,F,C,H,W]`` Seq2Seq latents + the two noise draws -> noised latents in the pipeline layout ``[B,C,F,H,W]``."""
+        x0, ed, es = self._dev(x0, "x_0"), self._dev(eps_div, "eps_div"), self._dev(eps_same, "eps_same")
+        b, f, c, h, w = x0.shape
+        if tuple(ed.shape) != (b, f, c, h, w) or tuple(es.shape) != (b, 1, c, h, w):
+            raise ValueError("noise shapes do not match x_0")
+        ts = np.ascontiguousarray(np.asarray(t, dtype=np.int64).reshape(-1))
+        if ts.size != b:
+            raise ValueError("one timestep per clip is required")
+        out = torch.empty((b, c, f, h, w), device=self.device, dtype=torch.float32)
+        self._check(self.lib.e2v_dana_noise(self.ctx, x0.data_ptr(), ed.data_ptr(), es.data_ptr(),
+                                            ts.ctypes.data_as(_lib.c_int64_p), int(time_steps), float(dynamic_beta), b, f, c,
+                                            h, w, out.data_ptr(), _stream()))
+        return out
+
+    def frames_to_uint8(self, videos: torch.Tensor) -> torch.Tensor:
+        v = self._dev(videos, "videos")
+        out = torch.empty(v.shape, device=self.device, dtype=torch.uint8)
+        self._check(self.lib.e2v_frames_to_uint8(self.ctx, v.data_ptr(), out.data_ptr(), v.numel(), _stream()))
+        return out
 
     # ------------------------------------------------------------------ kernel-level ops (channel-last tensors)
     def op_conv3x3(self, x0, w, bias=None, x1=None, *, n_img, Hs, Ws, Hi=None, Wi=None, stride=1, pad_lo=1, pad_hi=1,

@@ -112,6 +112,27 @@ class VAEConfig:
     scaling_factor: float = 0.18215
 
 
+@dataclass(frozen=True)
+class SemanticConfig:
+    """Semantic Predictor MLP ``CLIP`` (``EEG2Video/models/train_semantic_predictor.py:11-32``):
+    310 -> 10000 -> 10000 -> 10000 -> 10000 -> 77*768 with ReLU between."""
+    in_features: int = 310
+    hidden: int = 10000
+    tokens: int = 77
+
+
+TINY_SEMANTIC = SemanticConfig(in_features=22, hidden=96, tokens=7)
+
+
+def semantic_param_spec(cfg: SemanticConfig, cross_attention_dim: int) -> "OrderedDict[str, Tuple[int, ...]]":
+    """``nn.Sequential`` keys of the reference module: ``mlp.{0,2,4,6,8}.{weight,bias}``."""
+    spec: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    dims = [cfg.in_features, cfg.hidden, cfg.hidden, cfg.hidden, cfg.hidden, cfg.tokens * cross_attention_dim]
+    for i in range(5):
+        _lin(spec, f"mlp.{2 * i}", dims[i + 1], dims[i])
+    return spec
+
+
 #: tiny configs used by the parity tests (oracle finishes in well under a second).
 TINY_UNET = UNetConfig(sample_size=8, block_out_channels=(64, 128, 256, 256), cross_attention_dim=64)
 TINY_VAE = VAEConfig(block_out_channels=(32, 64, 64, 64), norm_num_groups=8)

@@ -64,6 +64,11 @@ typedef struct {
     int num_train_timesteps;                /* 1000 */
     double beta_start, beta_end;            /* 0.00085, 0.012, "scaled_linear" */
     int steps_offset;                       /* 1 (forced by pipeline_tuneeeg2video.py:59-71) */
+    /* Semantic Predictor MLP (EEG2Video/models/train_semantic_predictor.py:11-32):
+     * in -> hidden -> hidden -> hidden -> hidden -> sem_tokens * cross_attention_dim, ReLU between */
+    int sem_in_features;                    /* 310 */
+    int sem_hidden;                         /* 10000 */
+    int sem_tokens;                         /* 77 */
 } e2v_config;
 
 void e2v_default_config(e2v_config* cfg);
@@ -89,7 +94,8 @@ e2v_status e2v_load_tensor(e2v_ctx* ctx, const char* key, const void* host_data,
 int64_t e2v_num_expected_keys(const e2v_ctx* ctx);
 const char* e2v_expected_key(const e2v_ctx* ctx, int64_t i, int64_t* shape4, int* ndim);
 /* re-layout to the kernels' formats (tap-major convs, fused QKV / KV, GEGLU row interleave).
- * which: bit 0 = UNet, bit 1 = VAE; every expected key of the selected parts must have been loaded. */
+ * which: bit 0 = UNet, bit 1 = VAE, bit 2 = semantic predictor (keys "semantic.mlp.{0,2,4,6,8}.{weight,bias}");
+ * every expected key of the selected parts must have been loaded. */
 e2v_status e2v_finalize_weights(e2v_ctx* ctx, int which);
 
 /* ---- schedule (host, integer-exact) ---------------------------------------------------------------- */
@@ -137,6 +143,25 @@ e2v_status e2v_vae_encode(e2v_ctx* ctx, const float* images, int n, int H, int W
 e2v_status e2v_generate(e2v_ctx* ctx, const float* latents, const float* cond, const float* uncond, int Bu,
                         int B, int F, int h, int w, int T, int num_inference_steps, float guidance_scale,
                         float eta, float* videos, float* latents_out, e2v_stream stream);
+
+/* ---- the steps either side of the path -------------------------------------------------------- */
+/* rank 1 -- replaces CLIP.forward of the Semantic Predictor (EEG2Video/models/train_semantic_predictor.py:11-32, called
+ * at pipeline_tuneeeg2video.py:149): eeg [B, sem_in_features] -> embeddings [B, sem_tokens * cross_attention_dim]
+ * (the caller reshapes to [B,77,768], :150), all on device. */
+e2v_status e2v_semantic_predict(e2v_ctx* ctx, const float* eeg, int B, float* out, e2v_stream stream);
+
+/* rank 2 -- replaces Diffusion.forward of DANA (EEG2Video/models/DANA_module.py:52-72) given its random draws, fused with
+ * the latent layout fix 'a b c d e -> a c b d e' of inference_eeg2video.py:77,82:
+ *   out[b,c,f] = sqrt(abar_t_b) x0[b,f,c] + sqrt(1 - abar_t_b) (sqrt(1 - beta) eps_div[b,f,c] + sqrt(beta) eps_same[b,0,c])
+ * x0, eps_div [B,F,C,H,W]; eps_same [B,1,C,H,W]; host_t int64 [B] in [0, time_steps); linear betas 1e-4 .. 0.02 over
+ * time_steps (:42-52); out [B,C,F,H,W] (the pipeline's latent layout). */
+e2v_status e2v_dana_noise(e2v_ctx* ctx, const float* x0, const float* eps_div, const float* eps_same,
+                          const int64_t* host_t, int time_steps, float dynamic_beta, int B, int F, int C, int H, int W,
+                          float* out, e2v_stream stream);
+
+/* rank 3 -- replaces `(x * 255).numpy().astype(np.uint8)` of save_videos_grid (EEG2Video_New/Generation/tuneavideo/
+ * util.py:29) on the device, so that frames cross xGMI / PCIe as 1 byte per sample: videos in [0,1] -> uint8. */
+e2v_status e2v_frames_to_uint8(e2v_ctx* ctx, const float* videos, uint8_t* out, int64_t count, e2v_stream stream);
 
 /* Per-kernel-class timing with HIP events on the launch stream (used by bench.py for the roofline figures).
  * Between begin and end every kernel launch of the library is bracketed by an event pair and tagged with its

@@ -26,3 +26,4 @@ from .ddim import DDIMOracle  # noqa: F401
 from .unet3d import unet3d_forward  # noqa: F401
 from .vae import vae_decode, vae_encode  # noqa: F401
 from .pipeline import generate  # noqa: F401
+from .extras import dana_noise, frames_to_uint8, semantic_predictor  # noqa: F401

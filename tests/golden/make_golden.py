@@ -289,10 +289,57 @@ def tier2(out: dict) -> None:
     out["t2.tr.x"], out["t2.tr.cond"] = xt.numpy(), ct.numpy()
 
 
+def tier1_extras(out: dict) -> None:
+    """`CLIP` (semantic predictor) and DANA `Diffusion`, both import with torch alone."""
+    from eeg2video_amd.weights import SemanticConfig, semantic_param_spec
+    sys.path.insert(0, os.path.join(REF, "EEG2Video", "models"))
+    import train_semantic_predictor as ref_sem          # the reference file itself (no code runs at import)
+    import DANA_module as ref_dana
+
+    model = ref_sem.CLIP().eval()                       # 310 -> 10000 x4 -> 59136, 0.89 G parameters
+    spec = semantic_param_spec(SemanticConfig(), 768)
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == dict(spec), "CLIP key scheme differs"
+    sd = synth_state_dict(spec, seed=44, mode="reference_init")
+    model.load_state_dict({k: _t(v) for k, v in sd.items()}, strict=True)
+    eeg = _t(counter_normal(310, "t1.clip.eeg", (2, 310)))
+    with torch.no_grad():
+        y = model(eeg).numpy()
+    idx = (np.arange(2048, dtype=np.int64) * 7919) % y.shape[1]
+    out["x.clip.eeg"], out["x.clip.idx"] = eeg.numpy(), idx
+    out["x.clip.out_sampled"] = y[:, idx]
+    out["x.clip.out_l2"] = np.sqrt((y.astype(np.float64) ** 2).sum(axis=1))
+    del model, sd
+
+    diff = ref_dana.Diffusion(time_steps=500)
+    out["x.dana.sqrt_alphas_cumprod"] = diff.sqrt_alphas_cumprod.numpy()
+    out["x.dana.sqrt_one_minus_alphas_cumprod"] = diff.sqrt_one_minus_alphas_cumprod.numpy()
+    # Diffusion.forward draws t / noise itself and calls .cuda(); run it unmodified with the draws pinned
+    b, f, c, h, w = 3, 6, 4, 5, 8
+    x0 = _t(counter_normal(1, "x.dana.x0", (b, f, c, h, w)))
+    ed = _t(counter_normal(2, "x.dana.ed", (b, f, c, h, w)))
+    es = _t(counter_normal(3, "x.dana.es", (b, 1, c, h, w)))
+    t = torch.tensor([0, 137, 499])
+    saved = (torch.randint, torch.randn_like, torch.randn, torch.Tensor.cuda)
+    try:
+        torch.randint = lambda *a, **k: t.clone()
+        torch.randn_like = lambda *a, **k: ed.clone()
+        torch.randn = lambda *a, **k: es.clone()
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        diff.device = torch.device("cpu")
+        y = diff.forward(x0, 0.3)
+    finally:
+        torch.randint, torch.randn_like, torch.randn, torch.Tensor.cuda = saved
+    out["x.dana.x0"], out["x.dana.eps_div"], out["x.dana.eps_same"] = x0.numpy(), ed.numpy(), es.numpy()
+    out["x.dana.t"], out["x.dana.out_beta0.3"] = t.numpy(), y.numpy()
+
+
 def main() -> None:
-    t1, t2 = {}, {}
+    t1, t2, tx = {}, {}, {}
     tier1(t1)
     tier2(t2)
+    tier1_extras(tx)
+    np.savez_compressed(os.path.join(HERE, "reference_t1_extras.npz"), **tx)
+    print("reference_t1_extras.npz", os.path.getsize(os.path.join(HERE, "reference_t1_extras.npz")) // 1024, "KiB")
     np.savez_compressed(os.path.join(HERE, "reference_t1_resnet.npz"), **t1)
     np.savez_compressed(os.path.join(HERE, "reference_t2_unet_tiny.npz"), **t2)
     for name in ("reference_t1_resnet.npz", "reference_t2_unet_tiny.npz"):

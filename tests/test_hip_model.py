@@ -40,6 +40,8 @@ def test_key_scheme_matches_library(tiny):
     exp = pipe.unet.engine.expected_keys()
     spec = dict(unet_param_spec(TINY_UNET))
     spec.update({"vae." + k: v for k, v in vae_param_spec(TINY_VAE).items()})
+    from eeg2video_amd.weights import SemanticConfig, semantic_param_spec
+    spec.update({"semantic." + k: v for k, v in semantic_param_spec(SemanticConfig(), TINY_UNET.cross_attention_dim).items()})
     assert exp == spec
 
 

@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 from eeg2video_amd import _lib
-from eeg2video_amd.weights import UNetConfig, VAEConfig, unet_param_spec, vae_param_spec
+from eeg2video_amd.weights import (SemanticConfig, UNetConfig, VAEConfig, semantic_param_spec, unet_param_spec,
+                                   vae_param_spec)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -59,7 +60,8 @@ def test_key_scheme_matches_python_spec(lib, host_ctx):
         got[k] = tuple(shape[d] for d in range(nd.value))
     want = dict(unet_param_spec(UNetConfig()))
     want.update({"vae." + k: v for k, v in vae_param_spec(VAEConfig()).items()})
-    assert got == want and n == 798 + 248
+    want.update({"semantic." + k: v for k, v in semantic_param_spec(SemanticConfig(), 768).items()})
+    assert got == want and n == 798 + 248 + 10
 
 
 def test_ddim_timesteps_bit_exact(lib, host_ctx):

@@ -135,3 +135,32 @@ def test_sinusoid_known_values():
     assert abs(w[1] - 0.94406086) < 1e-7 and abs(w[159] - 1.0592537e-4) < 1e-10
     np.testing.assert_allclose(e[0, :160].numpy(), np.cos(w), rtol=1e-6, atol=1e-6)   # [cos, sin] (flip)
     np.testing.assert_allclose(e[0, 160:].numpy(), np.sin(w), rtol=1e-6, atol=1e-6)
+
+
+# ---- SURVEY 8(f) ranks 1-2, pinned by running the reference's own CLIP and Diffusion (tier 1) ----
+@pytest.fixture(scope="module")
+def tx(golden_dir):
+    return np.load(os.path.join(golden_dir, "reference_t1_extras.npz"))
+
+
+def test_t1_dana_schedule_and_forward(tx):
+    from oracle import dana_noise
+    betas = torch.linspace(0.0001, 0.02, 500)
+    ac = torch.cumprod(1.0 - betas, 0)
+    np.testing.assert_array_equal(torch.sqrt(ac).numpy(), tx["x.dana.sqrt_alphas_cumprod"])
+    np.testing.assert_array_equal(torch.sqrt(1 - ac).numpy(), tx["x.dana.sqrt_one_minus_alphas_cumprod"])
+    out = dana_noise(_t(tx["x.dana.x0"]), _t(tx["x.dana.eps_div"]), _t(tx["x.dana.eps_same"]), _t(tx["x.dana.t"]), 0.3)
+    ref = _t(tx["x.dana.out_beta0.3"]).permute(0, 2, 1, 3, 4)          # the caller's 'a b c d e -> a c b d e'
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_t1_semantic_predictor_full_size(tx):
+    """The reference's CLIP at its real size (0.89 G parameters, counter-RNG weights) against the oracle."""
+    from eeg2video_amd.weights import SemanticConfig, semantic_param_spec
+    from oracle import semantic_predictor
+    sd = {k: _t(v) for k, v in synth_state_dict(semantic_param_spec(SemanticConfig(), 768), seed=44,
+                                                 mode="reference_init").items()}
+    with torch.no_grad():
+        y = semantic_predictor(sd, _t(tx["x.clip.eeg"])).numpy()
+    np.testing.assert_allclose(y[:, tx["x.clip.idx"]], tx["x.clip.out_sampled"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.sqrt((y.astype(np.float64) ** 2).sum(1)), tx["x.clip.out_l2"], rtol=1e-6)
