@@ -33,7 +33,7 @@ class E2VConfig(C.Structure):
 
 
 E2V_OK, E2V_EINVAL, E2V_ESHAPE, E2V_ENOWEIGHT, E2V_EHIP, E2V_ESTATE = 0, -1, -2, -3, -4, -5
-E2V_F32, E2V_F16 = 0, 1
+E2V_F32, E2V_F16, E2V_BF16 = 0, 1, 2
 
 _ctx = C.c_void_p
 _stream = C.c_void_p
@@ -61,6 +61,7 @@ SIGNATURES = {
     "e2v_semantic_predict": (_i, [_ctx, _p, _i, _p, _stream]),
     "e2v_dana_noise": (_i, [_ctx, _p, _p, _p, c_int64_p, _i, _f, _i, _i, _i, _i, _i, _p, _stream]),
     "e2v_frames_to_uint8": (_i, [_ctx, _p, _p, _i64, _stream]),
+    "e2v_set_compute_dtype": (_i, [_ctx, _i]),
     "e2v_device_bytes": (_i64, [_ctx]),
     "e2v_profile_begin": (_i, [_ctx]),
     "e2v_profile_end": (_i64, [_ctx, C.c_char_p, _i64]),

@@ -214,6 +214,7 @@ e2v_status e2v_semantic_predict(e2v_ctx* c, const float* eeg, int B, float* out,
             IgemmArgs g;
             g.a0 = x.p; g.c0 = w.in; g.lda0 = w.in; g.w = w.w; g.ldw = w.in; g.bias = w.b;
             g.out = last ? out : y.p; g.ldc = w.out; g.M = B; g.N = w.out; g.taps = 1; g.relu = last ? 0 : 1;
+            g.bf16 = c->bf16_compute ? 1 : 0; g.w16 = w.w16;
             igemm(g, s);
             if (!last) x = std::move(y);
         }
@@ -274,6 +275,12 @@ int64_t e2v_profile_end(e2v_ctx* c, char* json, int64_t cap) {
     std::memcpy(json, s.data(), (size_t)n);
     json[n] = 0;
     return (int64_t)s.size();
+}
+
+e2v_status e2v_set_compute_dtype(e2v_ctx* c, int dtype) {
+    if (!c || (dtype != E2V_F32 && dtype != E2V_BF16)) return E2V_EINVAL;
+    c->bf16_compute = dtype == E2V_BF16;
+    return E2V_OK;
 }
 
 int64_t e2v_device_bytes(const e2v_ctx* c) { return c ? (int64_t)(c->weight_bytes + c->pool.bytes()) : 0; }
@@ -440,6 +447,12 @@ e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, 
         g.resid = resid; g.ldr = cout; g.M = n_img * Ho * Wo; g.N = cout; g.taps = 9;
         g.Ho = Ho; g.Wo = Wo; g.Hi = Hi; g.Wi = Wi; g.Hs = Hs; g.Ws = Ws; g.stride = stride; g.pad = pad_lo;
         if (Hi != Hs || Wi != Ws) { g.upsample = 1; g.ups_h = (float)Hs / (float)Hi; g.ups_w = (float)Ws / (float)Wi; }
+        Act w16;
+        if (c->bf16_compute) {
+            w16 = Act(c->pool, (int64_t)cout * 9, (cin + 1) / 2);
+            to_bf16(wp.p, w16.p, (size_t)cout * 9 * cin, s);
+            g.bf16 = 1; g.w16 = w16.p;
+        }
         igemm(g, s);
         E2V_HIP(hipGetLastError());
     });
@@ -467,6 +480,12 @@ e2v_status e2v_op_linear(e2v_ctx* c, const float* x, int ldx, int64_t M, int K, 
             g.w = wp.p; g.bias = bp.p; g.N = 2 * N; g.ldc = N; g.geglu = 1;
         } else {
             g.w = w; g.bias = bias; g.N = N; g.ldc = N; g.ldr = N;
+        }
+        Act w16;
+        if (c->bf16_compute) {
+            w16 = Act(c->pool, g.N, (K + 1) / 2);
+            to_bf16(g.w, w16.p, (size_t)g.N * K, s);
+            g.bf16 = 1; g.w16 = w16.p;
         }
         igemm(g, s);
         E2V_HIP(hipGetLastError());

@@ -23,8 +23,19 @@ static constexpr int LDS_LD = 36;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int BM, int BN, int WGM, int WGN, int ABL, int NBUF>
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// BF = false: fp32 operands, v_mfma_f32_32x32x2_f32, 32 k per stage (the parity configuration).
+// BF = true : bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation over fp32 activations in HBM: the A tile is
+//             rounded to bf16 on its way into LDS, weights are pre-converted (p.w16), 64 k per stage.  LDS rows are
+//             144 bytes in both modes and a lane's fragment is the same 16 bytes (4 fp32 / 8 bf16), so the fragment
+//             reads, the schedule and the epilogue are shared.
+template <int BM, int BN, int WGM, int WGN, int ABL, int NBUF, bool BF = false>
 __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, const int n0, float* smem) {
+    constexpr int BKE = BF ? 64 : 32;               // k elements per stage
+    constexpr int KH = BF ? 2 : 1;                  // 32-float pieces of an A row per stage
+    constexpr int ESZ = BF ? 2 : 4;                 // bytes per weight element
     constexpr int NT = 64 * WGM * WGN;              // threads; waves are laid out WGM x WGN over the tile
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -40,13 +51,14 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
 
     const float* __restrict__ a0 = p.a0 + (size_t)blockIdx.z * p.sa0;
     const float* __restrict__ a1 = p.a1;
-    const float* __restrict__ w = p.w + (size_t)blockIdx.z * p.sw;
+    const char* __restrict__ w = BF ? reinterpret_cast<const char*>(p.w16) + (size_t)blockIdx.z * p.sw * 2
+                                    : reinterpret_cast<const char*>(p.w + (size_t)blockIdx.z * p.sw);
     float* __restrict__ out = p.out + (size_t)blockIdx.z * p.sout;
 
     const int Ctot = p.c0 + p.c1;
     // K is walked as segments (tap, source): all channels of source 0 at tap 0, then source 1, then tap 1 ...
     // A segment is ceil(c/32) k-steps; its last step is masked to the segment's channel count.
-    const int steps0 = (p.c0 + BK - 1) / BK, steps1 = (p.c1 + BK - 1) / BK;
+    const int steps0 = (p.c0 + BKE - 1) / BKE, steps1 = (p.c1 + BKE - 1) / BKE;
     const int nk = p.taps * (steps0 + steps1);
 
     const int c4 = tid & 7;
@@ -77,7 +89,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
     for (int j = 0; j < BR; ++j) {
         const int n = n0 + r0 + RPP * j;
         b_ok[j] = n < p.N;
-        b_row[j] = (size_t)(b_ok[j] ? n : 0) * p.ldw + c4 * 4;
+        b_row[j] = (size_t)(b_ok[j] ? n : 0) * p.ldw + c4 * (16 / ESZ);
     }
 
     // Gather state of the NEXT tile to load.  Inside a segment a k-step only bumps eight pointers by 32 floats;
@@ -87,7 +99,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
     // and the loads + pointer bumps share one basic block with the MFMAs of the current tile.
     const float* __restrict__ zeros = p.zeros;
     const float* pa[AR];
-    const float* pb[BR];
+    const char* pb[BR];
     bool va[AR];
     int seg_tap = 0, seg_src = 0, cb = 0, cseg = p.c0;
     bool done = false;
@@ -111,24 +123,28 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
         }
         const size_t koff = (size_t)seg_tap * Ctot + (seg_src ? p.c0 : 0);
 #pragma unroll
-        for (int j = 0; j < BR; ++j) pb[j] = w + b_row[j] + koff;
+        for (int j = 0; j < BR; ++j) pb[j] = w + (b_row[j] + koff) * ESZ;
     };
-    f32x4 ra[AR], rb[BR];
+    f32x4 ra[AR * KH], rb[BR];
     auto issue_loads = [&]() {
-        const bool cok = !done && (cb + c4 * 4 < cseg);
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const float* src = (va[i] && cok) ? pa[i] : zeros;
-            ra[i] = *reinterpret_cast<const f32x4*>(src);
-            pa[i] += BK;
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+                const bool cok = !done && (cb + kh * 32 + c4 * 4 < cseg);
+                const float* src = (va[i] && cok) ? pa[i] + kh * 32 : zeros;
+                ra[i * KH + kh] = *reinterpret_cast<const f32x4*>(src);
+            }
+            pa[i] += BKE;
         }
+        const bool cokb = !done && (cb + c4 * (16 / ESZ) < cseg);
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
-            const float* src = (b_ok[j] && cok) ? pb[j] : zeros;
+            const char* src = (b_ok[j] && cokb) ? pb[j] : reinterpret_cast<const char*>(zeros);
             rb[j] = *reinterpret_cast<const f32x4*>(src);
-            pb[j] += BK;
+            pb[j] += 128;                                   // 32 fp32 or 64 bf16
         }
-        cb += BK;
+        cb += BKE;
     };
     auto advance_segment = [&]() {           // uniform: every lane sees the same cb / cseg
         if (cb >= cseg) {
@@ -147,7 +163,16 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
         float* A = As + buf * BM * LDS_LD;
         float* B = Bs + buf * BN * LDS_LD;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(A + (r0 + RPP * i) * LDS_LD + c4 * 4) = ra[i];
+        for (int i = 0; i < AR; ++i) {
+            if constexpr (BF) {
+#pragma unroll
+                for (int kh = 0; kh < KH; ++kh)            // 4 fp32 -> 4 bf16 (v_cvt_pk_bf16_f32), 8 bytes at k = 32 kh + 4 c4
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(A + (r0 + RPP * i) * LDS_LD) + kh * 64 + c4 * 8) =
+                        __builtin_convertvector(ra[i * KH + kh], bf16x4);
+            } else {
+                *reinterpret_cast<f32x4*>(A + (r0 + RPP * i) * LDS_LD + c4 * 4) = ra[i];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(B + (r0 + RPP * j) * LDS_LD + c4 * 4) = rb[j];
     };
@@ -182,15 +207,25 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
             bf[set][ni] = *reinterpret_cast<const f32x4*>(Bfr + buf * BN * LDS_LD + ni * 32 * LDS_LD + g * 8);
     };
     auto mma = [&](int set) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
+        if constexpr (BF) {        // one 16-deep bf16 MFMA per tile: the lane's 16 bytes are k = 16 g + 8 h .. + 7
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi][s], bf[set][ni][s], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[set][mi]),
+                                                                          __builtin_bit_cast(bf16x8, bf[set][ni]),
+                                                                          acc[mi][ni], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi][s], bf[set][ni][s], acc[mi][ni], 0, 0, 0);
+        }
     };
-    static_assert(BK == 32, "the k-step below is written for four k-groups of 8");
+    static_assert(BK == 32, "the k-step below is written for four fragment groups of 32 bytes per row");
     read_frags(0, 0, 0);
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = NBUF == 2 ? (ks & 1) : 0;
@@ -268,7 +303,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
 // tiles and the ragged last round runs as half-size tiles (L1: 5 rounds -> 4.5, L2: 3 -> 2.5).
 // XCD-aware order: the 8 XCDs are dealt blocks round-robin; each XCD gets a contiguous run of tiles (columns
 // fastest), so the column tiles that share one gathered A tile hit the same L2.
-template <int ABL>
+template <int ABL, bool BF>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // XCD x = blockIdx % 8 owns the contiguous row blocks [x*nbm/8, (x+1)*nbm/8); the last `tail` of them are cut
@@ -283,14 +318,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     if (loc < n1) {
         const int r = loc / per1, j = loc - r * per1;
         if (j < p.w1)
-            igemm_tile<128, 128, 2, 2, ABL, 2>(p, rb_lo + r, j * 128, smem);
+            igemm_tile<128, 128, 2, 2, ABL, 2, BF>(p, rb_lo + r, j * 128, smem);
         else
-            igemm_tile<128, 64, 2, 2, ABL, 2>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem);
+            igemm_tile<128, 64, 2, 2, ABL, 2, BF>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem);
     } else {
         const int t = loc - n1;
         if (t >= tail * p.s2) return;                     // padding block of the 8 x max-chunk grid
         const int r = t / p.s2;
-        igemm_tile<128, 64, 2, 2, ABL, 2>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem);
+        igemm_tile<128, 64, 2, 2, ABL, 2, BF>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem);
     }
 }
 
@@ -305,12 +340,12 @@ __global__ __launch_bounds__(256) void igemm_kernel_single(const IgemmArgs p) {
     igemm_tile<128, BN, 2, 2, 0, 2>(p, tile / nbn, (tile % nbn) * BN, smem);
 }
 
-template <int ABL>
+template <int ABL, bool BF = false>
 static void launch_igemm(const IgemmArgs& a, int ntiles, const char* cls, hipStream_t s) {
     static bool configured = false;
     constexpr size_t smem = (size_t)2 * (128 + 128) * LDS_LD * sizeof(float);
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<ABL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<ABL, BF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         configured = true;
     }
@@ -325,7 +360,7 @@ static void launch_igemm(const IgemmArgs& a, int ntiles, const char* cls, hipStr
                  std::to_string(a.rb1) + " w" + std::to_string(a.w1) + " s" + std::to_string(a.s1);
     ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
                  4.0 * a.batch * (rows_in * (a.c0 + a.c1) + (double)a.N * K + (double)a.M * (a.geglu ? a.N / 2 : a.N)), s);
-    hipLaunchKernelGGL((igemm_kernel<ABL>), grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL((igemm_kernel<ABL, BF>), grid, dim3(256), smem, s, a);
 }
 
 // 256 zero bytes per device: the source of every masked 16-byte load
@@ -360,7 +395,8 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
     a.s1 = rem == 0 ? 0 : (rem <= 64 ? 1 : 0);
     if (rem > 64) a.w1 += 1;                                 // 65..127 leftover columns: one more (masked) wide tile
     a.rb1 = nbm;
-    const char* cls = "igemm_f32";
+    const bool use_bf16 = a.bf16 && a.w16 && a.c0 % 8 == 0 && a.c1 % 8 == 0 && a.ldw % 8 == 0;
+    const char* cls = use_bf16 ? "igemm_bf16" : "igemm_f32";
     if (a.geglu) {                                           // the GEGLU epilogue pairs the two 32-column halves of a wave
         a.w1 = (a.N + 127) / 128; a.s1 = 0;
     } else if (a.w1 == 0) {                                  // N <= 64
@@ -392,7 +428,7 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
         ntiles = t > ntiles ? t : ntiles;
     }
     ntiles *= 8;
-    if (sched == 2 && !a.geglu && abl == 0) {               // A/B reference: one tile shape per launch
+    if (sched == 2 && !a.geglu && abl == 0 && !use_bf16) {               // A/B reference: one tile shape per launch
         const long n128 = (a.N + 127) / 128 * 128;
         const bool narrow = (double)(n128 - a.N) > 0.12 * (double)n128;
         static bool cfgd = false;
@@ -407,6 +443,7 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
         else hipLaunchKernelGGL((igemm_kernel_single<128>), dim3(nb, 1, a.batch), dim3(256), 73728, s, a);
         return;
     }
+    if (use_bf16 && abl == 0) { launch_igemm<0, true>(a, ntiles, cls, s); return; }
     if (abl == 1) launch_igemm<1>(a, ntiles, cls, s);
     else if (abl == 2) launch_igemm<2>(a, ntiles, cls, s);
     else launch_igemm<0>(a, ntiles, cls, s);
@@ -426,6 +463,15 @@ void pack_conv3x3(const float* w, float* o, int cout, int cin, int cin_pad, hipS
     const size_t total = (size_t)cout * 9 * cin_pad;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(256), 0, s, w, o, cout, cin, cin_pad);
+}
+
+__global__ void to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (__bf16)in[i];
+}
+void to_bf16(const float* in, void* out, size_t n, hipStream_t s) {
+    if (!n) return;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(blocks), dim3(256), 0, s, in, static_cast<__bf16*>(out), n);
 }
 
 __global__ void copy_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows,

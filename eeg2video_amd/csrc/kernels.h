@@ -38,6 +38,8 @@ struct IgemmArgs {
     int geglu = 0;                 // W rows packed [32 value | 32 gate] per 64: out[m][n/2] = v * gelu(g)
     int batch = 1;                 // blockIdx.z; strides in floats
     long long sa0 = 0, sw = 0, sout = 0;
+    int bf16 = 0;                  // 1: multiply in bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate); needs w16
+    const void* w16 = nullptr;     // the same packed weights rounded to bf16
     const float* zeros = nullptr;  // filled by the launcher: 16+ zero bytes, the source of masked loads
     int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, tail_rb = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
 };
@@ -46,6 +48,7 @@ void igemm(const IgemmArgs& a, hipStream_t s);
 // weight re-layout helpers (one-off, at finalize)
 void pack_conv3x3(const float* w_oihw, float* w_packed, int cout, int cin, int cin_pad, hipStream_t s);
 void copy_rows(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t s);
+void to_bf16(const float* in, void* out_bf16, size_t n, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // normalisation (norm.hip)

@@ -160,10 +160,15 @@ struct Packer {
         E2V_REQUIRE(it->second.loaded, E2V_ENOWEIGHT, "state-dict key not loaded: " + k);
         return it->second;
     }
+    const void* half(const float* w, size_t n) {             // bf16 copy of a (packed) weight for the bf16-MFMA mode
+        float* d = c->dev_alloc((n + 1) / 2);
+        to_bf16(w, d, n, s);
+        return d;
+    }
     NormW norm(const std::string& n) { return NormW{t(n + ".weight").d, t(n + ".bias").d, (int)t(n + ".weight").shape[0]}; }
     LinW lin(const std::string& n, bool bias = true) {       // Linear or 1x1 conv: [out][in] as it is
         const WTensor& w = t(n + ".weight");
-        return LinW{w.d, bias ? t(n + ".bias").d : nullptr, (int)w.shape[1], (int)w.shape[0]};
+        return LinW{w.d, bias ? t(n + ".bias").d : nullptr, (int)w.shape[1], (int)w.shape[0], half(w.d, w.numel)};
     }
     ConvW conv3(const std::string& n) {                      // [O][I][3][3] -> [O][tap][I padded to 4]
         const WTensor& w = t(n + ".weight");
@@ -171,7 +176,7 @@ struct Packer {
         const int cp = (ci + 3) / 4 * 4;
         float* d = c->dev_alloc((size_t)co * 9 * cp);
         pack_conv3x3(w.d, d, co, ci, cp, s);
-        return ConvW{d, t(n + ".bias").d, ci, cp, co};
+        return ConvW{d, t(n + ".bias").d, ci, cp, co, half(d, (size_t)co * 9 * cp)};
     }
     LinW fuse_rows(const std::vector<std::string>& names, bool bias) {   // stack Linear weights along `out`
         int in = 0, out = 0;
@@ -185,7 +190,7 @@ struct Packer {
             if (bias) copy_rows(t(n + ".bias").d, (int)w.shape[0], b + r, (int)w.shape[0], 1, (int)w.shape[0], s);
             r += (int)w.shape[0];
         }
-        return LinW{d, b, in, out};
+        return LinW{d, b, in, out, half(d, (size_t)out * in)};
     }
     LinW geglu(const std::string& n) {        // rows [value 0..4C) | gate 0..4C)] -> per 64: [32 value | 32 gate]
         const WTensor& w = t(n + ".weight");
@@ -200,7 +205,7 @@ struct Packer {
             copy_rows(bsrc.d + q * 32, 32, b + q * 64, 32, 1, 32, s);
             copy_rows(bsrc.d + half + q * 32, 32, b + q * 64 + 32, 32, 1, 32, s);
         }
-        return LinW{d, b, in, out};
+        return LinW{d, b, in, out, this->half(d, (size_t)out * in)};
     }
     ResW resnet(const std::string& p, bool temb) {
         ResW r;
@@ -405,6 +410,7 @@ struct Runner {
         g.a0 = a; g.c0 = K0; g.lda0 = lda; g.a1 = a1; g.c1 = c1; g.lda1 = lda1;
         g.w = w.w; g.ldw = w.in; g.out = out.p; g.ldc = out.C; g.bias = w.b;
         g.resid = resid; g.ldr = ldr; g.M = (int)M; g.N = w.out; g.taps = 1; g.geglu = geglu ? 1 : 0;
+        g.bf16 = c->bf16_compute ? 1 : 0; g.w16 = w.w16;
         igemm(g, s);
         return out;
     }
@@ -420,6 +426,7 @@ struct Runner {
         g.rowbias = rowbias; g.rb_ld = w.cout; g.rows_per_sample = rows_per_sample;
         g.resid = resid; g.ldr = w.cout;
         g.M = (int)out.rows; g.N = w.cout; g.taps = 9;
+        g.bf16 = c->bf16_compute ? 1 : 0; g.w16 = w.w16;
         g.Ho = Ho; g.Wo = Wo; g.Hi = Hi; g.Wi = Wi; g.Hs = geo.H; g.Ws = geo.W; g.stride = stride; g.pad = pad;
         if (Hi != geo.H || Wi != geo.W) {
             g.upsample = 1;

@@ -13,8 +13,8 @@
 namespace e2v {
 
 struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
-struct LinW { const float* w = nullptr; const float* b = nullptr; int in = 0, out = 0; };
-struct ConvW { const float* w = nullptr; const float* b = nullptr; int cin = 0, cin_pad = 0, cout = 0; };
+struct LinW { const float* w = nullptr; const float* b = nullptr; int in = 0, out = 0; const void* w16 = nullptr; };
+struct ConvW { const float* w = nullptr; const float* b = nullptr; int cin = 0, cin_pad = 0, cout = 0; const void* w16 = nullptr; };
 
 struct ResW {
     NormW n1, n2;
@@ -82,6 +82,7 @@ struct e2v_ctx {
     e2v::UNetW unet;
     e2v::VAEW vae;
     bool unet_ready = false, vae_ready = false, sem_ready = false;
+    bool bf16_compute = false;                                   // e2v_set_compute_dtype: bf16 MFMA for convs / linears
     std::vector<e2v::LinW> sem;                                  // semantic predictor layers (first one K-padded to 4)
     int sem_in_pad = 0;
     std::vector<float> alphas;                                   // host alpha-bar table

@@ -109,6 +109,11 @@ class Engine:
         self._check(self.lib.e2v_finalize_weights(self.ctx, which))
         self.ready |= which
 
+    def set_compute_dtype(self, dtype: str) -> None:
+        """'fp32' (default, parity configuration) or 'bf16' (bf16 MFMA with fp32 accumulate for convs / linears)."""
+        code = {"fp32": _lib.E2V_F32, "f32": _lib.E2V_F32, "bf16": _lib.E2V_BF16}[dtype]
+        self._check(self.lib.e2v_set_compute_dtype(self.ctx, code))
+
     def device_bytes(self) -> int:
         return int(self.lib.e2v_device_bytes(self.ctx))
 

@@ -38,7 +38,7 @@ typedef enum {
     E2V_ESTATE = -5      /* call order (weights not finalized, ...) */
 } e2v_status;
 
-typedef enum { E2V_F32 = 0, E2V_F16 = 1 } e2v_dtype;
+typedef enum { E2V_F32 = 0, E2V_F16 = 1, E2V_BF16 = 2 } e2v_dtype;
 
 /* Mirror of the UNet3DConditionModel ctor kwargs the path uses (EEG2Video/models/unet.py:41-78) and of
  * the AutoencoderKL config (diffusers 0.11.1 vae/config.json).  e2v_default_config()
@@ -170,6 +170,11 @@ e2v_status e2v_frames_to_uint8(e2v_ctx* ctx, const float* videos, uint8_t* out, 
  * (NUL-terminated, truncated to `cap`); it returns the untruncated length or -1. */
 e2v_status e2v_profile_begin(e2v_ctx* ctx);
 int64_t e2v_profile_end(e2v_ctx* ctx, char* json, int64_t cap);
+
+/* Arithmetic of the convolutions / linears (everything else stays fp32): E2V_F32 (default; fp32 MFMA, the parity
+ * configuration of BASELINE configs[1]) or E2V_BF16 (BASELINE configs[2]: bf16 MFMA with fp32 accumulation, fp32
+ * activations in HBM, fp32 GroupNorm / LayerNorm / softmax).  Takes effect for the following calls. */
+e2v_status e2v_set_compute_dtype(e2v_ctx* ctx, int dtype);
 
 /* bytes of device memory currently held by the ctx (weights + cached workspace) */
 int64_t e2v_device_bytes(const e2v_ctx* ctx);

@@ -215,3 +215,29 @@ def test_cfg_guidance_one_is_identity(tiny):
     a = eng.ddim_cfg_step(eu, ec, x, 1.0, 501, 481)
     b = eng.ddim_cfg_step(ec, None, x, 1.0, 501, 481)
     assert (a - b).abs().max().item() < 1e-6
+
+
+def test_bf16_compute_mode_unet_and_generate(tiny):
+    """BASELINE configs[2]: bf16 MFMA (fp32 accumulate) for convs / linears, everything else fp32.  bf16 keeps 8 mantissa
+    bits, so the tolerance is 5e-2 of the tensor scale (the fp32 mode's is 1e-4)."""
+    from oracle import generate, unet3d_forward
+    pipe, usd, vsd = tiny
+    eng = pipe.unet.engine
+    x = _t(counter_normal(5, "x", (2, 4, 3, 9, 12)))
+    cond = _t(counter_normal(6, "c", (2, 11, TINY_UNET.cross_attention_dim)))
+    ref = unet3d_forward(usd, TINY_UNET, x, 301, cond)
+    y32 = pipe.unet(x.cuda(), 301, cond.cuda()).sample
+    try:
+        eng.set_compute_dtype("bf16")
+        y16 = pipe.unet(x.cuda(), 301, cond.cuda()).sample
+        e = rel_err(y16, ref)
+        assert 1e-5 < e < 5e-2, e                                   # really ran in bf16, and is still close
+        lat = _t(counter_normal(13, "lat", (1, 4, 3, 8, 12)))
+        c1 = _t(counter_normal(14, "cond", (1, 9, TINY_UNET.cross_attention_dim)))
+        u1 = _t(counter_normal(15, "unc", (1, 9, TINY_UNET.cross_attention_dim)))
+        vid = eng.generate(lat.cuda(), c1.cuda(), u1.cuda(), 4, 7.5, 0.0)
+        refv = generate(usd, TINY_UNET, vsd, TINY_VAE, lat, c1, u1, 4, 7.5)
+        assert (vid.cpu() - refv).abs().max().item() < 0.1 and torch.isfinite(vid).all()
+    finally:
+        eng.set_compute_dtype("fp32")
+    assert torch.equal(pipe.unet(x.cuda(), 301, cond.cuda()).sample, y32)     # back to the parity configuration

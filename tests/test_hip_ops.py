@@ -207,3 +207,27 @@ def test_temporal_attention(eng, d, f, hw):
     ref = ref.reshape(n, hw, f, c).permute(0, 2, 1, 3).reshape(n * f * hw, c)
     y = eng.op_temporal_attention(qkv.cuda(), n=n, F=f, HW=hw, heads=heads, D=d, scale=d ** -0.5)
     close(y, ref, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------ bf16 MFMA mode (BASELINE configs[2]) -------------
+def test_bf16_conv_and_linear(eng):
+    """bf16 multiply / fp32 accumulate: compared with the same op on bf16-rounded operands in fp32 (tight), and with
+    the fp32 op (loose: bf16 has 8 mantissa bits)."""
+    rb = lambda t: t.to(torch.bfloat16).float()
+    try:
+        eng.set_compute_dtype("bf16")
+        n, c, h, w = 2, 64, 9, 12
+        x, wt, b = rnd(n, c, h, w, seed=60), rnd(128, c, 3, 3, seed=61, scale=0.1), rnd(128, seed=62)
+        y = from_cl(eng.op_conv3x3(to_cl(x).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=h, Ws=w), n, h, w)
+        close(y, F.conv2d(rb(x), rb(wt), b, padding=1), rtol=1e-4, atol=1e-4)
+        close(y, F.conv2d(x, wt, b, padding=1), rtol=2e-2, atol=2e-2)
+        xl, wl, bl, r = rnd(300, 320, seed=63), rnd(960, 320, seed=64, scale=0.05), rnd(960, seed=65), rnd(300, 960, seed=66)
+        close(eng.op_linear(xl.cuda(), wl.cuda(), bl.cuda(), r.cuda()), F.linear(rb(xl), rb(wl), bl) + r, rtol=1e-4, atol=1e-4)
+        xg, wg, bg = rnd(200, 64, seed=67), rnd(512, 64, seed=68, scale=0.1), rnd(512, seed=69)
+        hh, gg = F.linear(rb(xg), rb(wg), bg).chunk(2, dim=-1)
+        close(eng.op_linear(xg.cuda(), wg.cuda(), bg.cuda(), geglu=True), hh * F.gelu(gg), rtol=1e-4, atol=1e-4)
+        # a shape the bf16 kernel does not take (K = 36: input channels not a multiple of 8) silently stays fp32
+        x4, w4 = rnd(1, 4, 5, 6, seed=70), rnd(64, 4, 3, 3, seed=71)
+        close(from_cl(eng.op_conv3x3(to_cl(x4).cuda(), w4.cuda(), n_img=1, Hs=5, Ws=6), 1, 5, 6), F.conv2d(x4, w4, padding=1))
+    finally:
+        eng.set_compute_dtype("fp32")

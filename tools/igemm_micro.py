@@ -6,6 +6,7 @@ from eeg2video_amd.engine import Engine
 from eeg2video_amd.weights import TINY_UNET, TINY_VAE
 
 eng = Engine(TINY_UNET, TINY_VAE, 0)
+eng.set_compute_dtype(os.environ.get("DTYPE", "fp32"))
 reps = int(os.environ.get("REPS", "5"))
 only = os.environ.get("ONLY", "")
 shapes = [
