@@ -83,6 +83,7 @@ struct AttnArgs {
     int mode = 0;      // 0: sparse-causal self-attention, keys = [frame 0 ; frame max(f-1,0)] (attention.py:292-301)
                        // 1: keys shared by all frames of a sample (cross-attention to the 77 cond tokens)
     float scale = 1.f;
+    int bf16 = 0;      // 1: bf16 MFMA for QK^T and PV (fp32 softmax / accumulate)
 };
 void flash_attention(const AttnArgs& a, hipStream_t s);
 // temporal self-attention over the F frames of every pixel (attention.py:261-267), qkv = [n*F*HW][3C]

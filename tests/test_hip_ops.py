@@ -231,3 +231,34 @@ def test_bf16_conv_and_linear(eng):
         close(from_cl(eng.op_conv3x3(to_cl(x4).cuda(), w4.cuda(), n_img=1, Hs=5, Ws=6), 1, 5, 6), F.conv2d(x4, w4, padding=1))
     finally:
         eng.set_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("d,nq,f,n,mode", [(8, 108, 3, 2, 0), (16, 30, 4, 1, 0), (32, 9, 3, 2, 0), (40, 200, 6, 1, 0), (80, 144, 3, 1, 0),
+                                           (160, 40, 6, 2, 0), (64, 70, 2, 1, 0), (40, 300, 3, 2, 1), (160, 40, 3, 2, 1)])
+def test_bf16_attention(eng, d, nq, f, n, mode):
+    """bf16 MFMA attention (configs[2]): Q, K, V, P rounded to bf16, fp32 softmax / accumulate; tolerance 2e-2 of the
+    output scale against the fp32 reference."""
+    heads = 8 if d != 160 else 4
+    c = heads * d
+    try:
+        eng.set_compute_dtype("bf16")
+        if mode == 0:
+            qkv = rnd(n * f * nq, 3 * c, seed=80)
+            q, k, v = (qkv[:, i * c:(i + 1) * c].reshape(n * f, nq, c) for i in range(3))
+            former = torch.arange(f) - 1
+            former[0] = 0
+            gather = lambda t: torch.cat([t.reshape(n, f, nq, c)[:, [0] * f], t.reshape(n, f, nq, c)[:, former]], dim=2).reshape(n * f, 2 * nq, c)
+            ref = _unheads(_ref_attn(_heads(q, heads), _heads(gather(k), heads), _heads(gather(v), heads), d ** -0.5), heads)
+            g = qkv.cuda()
+            y = eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5)
+        else:
+            nk = 77
+            q, kv = rnd(n * f * nq, c, seed=81), rnd(n * nk, 2 * c, seed=82)
+            k, v = kv[:, :c].reshape(n, nk, c), kv[:, c:].reshape(n, nk, c)
+            rep = lambda t: t.repeat_interleave(f, 0)
+            ref = _unheads(_ref_attn(_heads(q.reshape(n * f, nq, c), heads), _heads(rep(k), heads), _heads(rep(v), heads), d ** -0.5), heads)
+            gq, gkv = q.cuda(), kv.cuda()
+            y = eng.op_attention(gq, gkv[:, :c], gkv[:, c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nk, mode=1, scale=d ** -0.5)
+        close(y.reshape(n * f, nq, c), ref, rtol=2e-2, atol=2e-2)
+    finally:
+        eng.set_compute_dtype("fp32")
