@@ -181,7 +181,7 @@ def main() -> int:
         pmc = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")     # written from a rocprofv3 --pmc pass
         if os.path.isfile(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch") if (B == 8 and args.dtype == "fp32") else None
             except Exception:
                 traffic = None
         if dom in HBM_BOUND:
