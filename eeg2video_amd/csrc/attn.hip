@@ -570,13 +570,103 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
     }
 }
 
+// LDS-staged version: a block stages q, k, v of PB pixels x F frames for a slab of CS channels (whole heads) with fully
+// coalesced row reads, then one thread per (pixel, head, query frame) works out of LDS.  HBM sees every byte once.
+__global__ __launch_bounds__(128) void temporal_attn_lds_kernel(const float* __restrict__ qkv, int ld, float* __restrict__ out,
+                                                                int ldo, int F, int HW, int C, int D, float scale, int PB,
+                                                                int CS, int npg) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // [F][PB][q | k | v][CS]
+    const int smp = blockIdx.x / npg, p0 = (blockIdx.x - smp * npg) * PB;
+    const int c_base = blockIdx.y * CS;
+    const int CQ = CS / 4;
+    const int total = F * PB * 3 * CQ;
+    for (int idx = threadIdx.x; idx < total; idx += 128) {
+        const int c4 = idx % CQ;
+        int r = idx / CQ;
+        const int part = r % 3; r /= 3;
+        const int pp = r % PB;
+        const int f = r / PB;
+        const int pix = p0 + pp;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pix < HW) v = *reinterpret_cast<const f32x4*>(qkv + ((size_t)(smp * F + f) * HW + pix) * ld + part * C + c_base + c4 * 4);
+        *reinterpret_cast<f32x4*>(sm + (size_t)idx * 4) = v;
+    }
+    __syncthreads();
+    const int hs = CS / D;
+    const int items = PB * hs * F;
+    for (int item = threadIdx.x; item < items; item += 128) {
+        const int i = item % F;
+        const int hh = (item / F) % hs;
+        const int pp = item / (F * hs);
+        const int pix = p0 + pp;
+        if (pix >= HW) continue;
+        const size_t fs = (size_t)PB * 3 * CS;                          // frame stride in LDS
+        const float* q = sm + ((size_t)(i * PB + pp) * 3) * CS + hh * D;
+        const float* k = sm + ((size_t)pp * 3 + 1) * CS + hh * D;
+        const float* v = sm + ((size_t)pp * 3 + 2) * CS + hh * D;
+        float s[FMAX];
+#pragma unroll
+        for (int jf = 0; jf < FMAX; ++jf) s[jf] = 0.f;
+        for (int c = 0; c < D; c += 4) {
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(q + c);
+#pragma unroll
+            for (int jf = 0; jf < FMAX; ++jf)
+                if (jf < F) {
+                    const f32x4 kv = *reinterpret_cast<const f32x4*>(k + jf * fs + c);
+                    s[jf] += qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
+                }
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int jf = 0; jf < FMAX; ++jf)
+            if (jf < F) {
+                s[jf] *= scale;
+                m = fmaxf(m, s[jf]);
+            }
+        float l = 0.f;
+#pragma unroll
+        for (int jf = 0; jf < FMAX; ++jf)
+            if (jf < F) {
+                s[jf] = expf(s[jf] - m);
+                l += s[jf];
+            }
+        const float inv = 1.0f / l;
+        float* op = out + ((size_t)(smp * F + i) * HW + pix) * ldo + c_base + hh * D;
+        for (int c = 0; c < D; c += 4) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jf = 0; jf < FMAX; ++jf)
+                if (jf < F) {
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(v + jf * fs + c);
+                    o += vv * (s[jf] * inv);
+                }
+            *reinterpret_cast<f32x4*>(op + c) = o;
+        }
+    }
+}
+
 void temporal_attention(const float* qkv, int ld, float* out, int ldo, int n, int F, int HW, int heads, int D, float scale,
                         hipStream_t s) {
     const size_t total = (size_t)n * HW * heads * F;
     if (!total) return;
     ProfScope ps("temporal_attn", 4.0 * total * F * D, 4.0 * 4.0 * (double)n * F * HW * heads * D, s);
-    hipLaunchKernelGGL(temporal_attn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv, ld, out, ldo, n, F, HW,
-                       heads, D, scale);
+    const int C = heads * D;
+    // slab of whole heads and pixel count such that the staged q/k/v fit 48 KB (3 blocks per CU)
+    int hs = heads;
+    while (hs > 1 && (size_t)F * 3 * hs * D * 4 > 48 * 1024) hs = (hs + 1) / 2;
+    while (heads % hs) --hs;
+    const int CS = hs * D;
+    int PB = (int)((48 * 1024) / ((size_t)F * 3 * CS * 4));
+    PB = PB < 1 ? 1 : (PB > 8 ? 8 : PB);
+    const size_t smem = (size_t)F * PB * 3 * CS * 4;
+    if (smem > 64 * 1024) {           // does not fit the default LDS window: per-thread global version
+        hipLaunchKernelGGL(temporal_attn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv, ld, out, ldo, n, F, HW,
+                           heads, D, scale);
+        return;
+    }
+    const int npg = (HW + PB - 1) / PB;
+    hipLaunchKernelGGL(temporal_attn_lds_kernel, dim3((unsigned)(n * npg), C / CS), dim3(128), smem, s, qkv, ld, out, ldo, F, HW, C,
+                       D, scale, PB, CS, npg);
 }
 
 // ---- row softmax in place (single-head VAE attention, 2304 keys, fp32 as the dep computes it) ----------

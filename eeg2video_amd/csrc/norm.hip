@@ -42,8 +42,18 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     for (int q0 = 0; q0 < CQ; q0 += QT) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
         if (r < R) {
-            for (int pr = p0 + r; pr < p1; pr += R) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)pr * ld + (q0 + q) * 4);
+            const float* col = base + (q0 + q) * 4;
+            int pr = p0 + r;
+            for (; pr + 3 * R < p1; pr += 4 * R) {          // four rows in flight per thread
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(col + (size_t)pr * ld);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(col + (size_t)(pr + R) * ld);
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(col + (size_t)(pr + 2 * R) * ld);
+                const f32x4 v3 = *reinterpret_cast<const f32x4*>(col + (size_t)(pr + 3 * R) * ld);
+                s += (v0 + v1) + (v2 + v3);
+                ss += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+            }
+            for (; pr < p1; pr += R) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(col + (size_t)pr * ld);
                 s += v;
                 ss += v * v;
             }
@@ -108,15 +118,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const int Ctot = c0 + c1;
     const int CQ = Ctot / 4;
     const size_t total = rows * CQ;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t row = i / CQ;
-        const int c = (int)(i - row * CQ) * 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    auto one = [&](size_t i, f32x4& v, f32x4& a, f32x4& b, size_t& row, int& c) {
+        row = i / CQ;
+        c = (int)(i - row * CQ) * 4;
         const int slab = (int)(row / P);
-        const f32x4 v = (c < c0) ? *reinterpret_cast<const f32x4*>(x0 + row * ld0 + c)
-                                 : *reinterpret_cast<const f32x4*>(x1 + row * ld1 + (c - c0));
+        v = (c < c0) ? *reinterpret_cast<const f32x4*>(x0 + row * ld0 + c)
+                     : *reinterpret_cast<const f32x4*>(x1 + row * ld1 + (c - c0));
         const float* sc = scsh + ((size_t)slab * Ctot + c) * 2;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(sc);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(sc + 4);
+        a = *reinterpret_cast<const f32x4*>(sc);
+        b = *reinterpret_cast<const f32x4*>(sc + 4);
+    };
+    auto fin = [&](const f32x4& v, const f32x4& a, const f32x4& b, size_t row, int c) {
         f32x4 y;
         y[0] = v[0] * a[0] + a[1];
         y[1] = v[1] * a[2] + a[3];
@@ -127,6 +140,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             for (int e = 0; e < 4; ++e) y[e] = silu_f(y[e]);
         }
         *reinterpret_cast<f32x4*>(out + row * ldo + c) = y;
+    };
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i + stride < total; i += 2 * stride) {           // two elements in flight per thread
+        f32x4 v0, a0, b0, v1, a1, b1;
+        size_t r0, r1;
+        int cc0, cc1;
+        one(i, v0, a0, b0, r0, cc0);
+        one(i + stride, v1, a1, b1, r1, cc1);
+        fin(v0, a0, b0, r0, cc0);
+        fin(v1, a1, b1, r1, cc1);
+    }
+    if (i < total) {
+        f32x4 v, a, b;
+        size_t r;
+        int cc;
+        one(i, v, a, b, r, cc);
+        fin(v, a, b, r, cc);
     }
 }
 
@@ -149,7 +179,7 @@ void groupnorm(const GroupNormArgs& a, hipStream_t s) {
                        a.P, a.eps, a.gamma, a.beta, a.ws_scale);
     const size_t rows = (size_t)a.samples * a.P;
     const size_t total = rows * (Ctot / 4);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const int blocks = (int)((total + 511) / 512 < 16384 ? (total + 511) / 512 : 16384);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, s, a.x0, a.x1, a.c0, a.c1, a.ld0, a.ld1, a.ws_scale,
                        a.out, a.ldo, a.P, rows, a.silu);
 }
