@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libeeg2video_hip.so")
+LIB_PATH = os.environ.get("E2V_LIB_PATH") or os.path.join(_HERE, "lib", "libeeg2video_hip.so")   # override: A/B of two builds
 
 c_int64_p = C.POINTER(C.c_int64)
 c_float_p = C.c_void_p          # device pointers travel as integers (tensor.data_ptr())

@@ -213,7 +213,7 @@ e2v_status e2v_semantic_predict(e2v_ctx* c, const float* eeg, int B, float* out,
             if (!last) y = Act(c->pool, B, w.out);
             IgemmArgs g;
             g.a0 = x.p; g.c0 = w.in; g.lda0 = w.in; g.w = w.w; g.ldw = w.in; g.bias = w.b;
-            g.out = last ? out : y.p; g.ldc = w.out; g.M = B; g.N = w.out; g.taps = 1; g.relu = last ? 0 : 1;
+            g.out = last ? out : y.p; g.ldc = w.out; g.M = B; g.N = w.out; g.taps = 1; g.relu = last ? 0 : 1; g.ldw16 = w.in;
             g.bf16 = c->bf16_compute ? 1 : 0; g.w16 = w.w16;
             igemm(g, s);
             if (!last) x = std::move(y);
@@ -438,20 +438,24 @@ e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, 
         E2V_REQUIRE(x0 && w_oihw && out && c0 % 4 == 0 && c1 % 4 == 0 && c0 > 0, E2V_EINVAL, "bad conv arguments");
         hipStream_t s = S(stream);
         const int cin = c0 + c1;
-        Act wp(c->pool, (int64_t)cout * 9, cin);
-        pack_conv3x3(w_oihw, wp.p, cout, cin, cin, s);
+        E2V_REQUIRE(c1 == 0 || c0 % 32 == 0, E2V_ESHAPE, "conv: the concat seam must be a multiple of 32 channels");
+        const int ld32 = conv3x3_packed_ld(cin, 32), ld64 = conv3x3_packed_ld(cin, 64);
+        Act wp(c->pool, cout, ld32);
+        pack_conv3x3(w_oihw, wp.p, cout, cin, 32, s);
         IgemmArgs g;
         g.a0 = x0; g.c0 = c0; g.lda0 = c0; g.a1 = x1; g.c1 = c1; g.lda1 = c1;
-        g.w = wp.p; g.ldw = 9 * cin; g.out = out; g.ldc = cout; g.bias = bias;
+        g.w = wp.p; g.ldw = ld32; g.out = out; g.ldc = cout; g.bias = bias;
         g.rowbias = rowbias; g.rb_ld = cout; g.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
         g.resid = resid; g.ldr = cout; g.M = n_img * Ho * Wo; g.N = cout; g.taps = 9;
         g.Ho = Ho; g.Wo = Wo; g.Hi = Hi; g.Wi = Wi; g.Hs = Hs; g.Ws = Ws; g.stride = stride; g.pad = pad_lo;
         if (Hi != Hs || Wi != Ws) { g.upsample = 1; g.ups_h = (float)Hs / (float)Hi; g.ups_w = (float)Ws / (float)Wi; }
-        Act w16;
+        Act w64, w16;
         if (c->bf16_compute) {
-            w16 = Act(c->pool, (int64_t)cout * 9, (cin + 1) / 2);
-            to_bf16(wp.p, w16.p, (size_t)cout * 9 * cin, s);
-            g.bf16 = 1; g.w16 = w16.p;
+            w64 = Act(c->pool, cout, ld64);
+            pack_conv3x3(w_oihw, w64.p, cout, cin, 64, s);
+            w16 = Act(c->pool, cout, (ld64 + 1) / 2);
+            to_bf16(w64.p, w16.p, (size_t)cout * ld64, s);
+            g.bf16 = 1; g.w16 = w16.p; g.ldw16 = ld64;
         }
         igemm(g, s);
         E2V_HIP(hipGetLastError());
@@ -485,7 +489,7 @@ e2v_status e2v_op_linear(e2v_ctx* c, const float* x, int ldx, int64_t M, int K, 
         if (c->bf16_compute) {
             w16 = Act(c->pool, g.N, (K + 1) / 2);
             to_bf16(g.w, w16.p, (size_t)g.N * K, s);
-            g.bf16 = 1; g.w16 = w16.p;
+            g.bf16 = 1; g.w16 = w16.p; g.ldw16 = K;
         }
         igemm(g, s);
         E2V_HIP(hipGetLastError());

@@ -55,111 +55,126 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
                                     : reinterpret_cast<const char*>(p.w + (size_t)blockIdx.z * p.sw);
     float* __restrict__ out = p.out + (size_t)blockIdx.z * p.sout;
 
-    const int Ctot = p.c0 + p.c1;
-    // K is walked as segments (tap, source): all channels of source 0 at tap 0, then source 1, then tap 1 ...
-    // A segment is ceil(c/32) k-steps; its last step is masked to the segment's channel count.
+    // K order: source (the two halves of a channel concat) > 32/64-channel chunk > tap.  The 9 taps of one channel chunk
+    // run back to back, so the (shifted) re-reads of the same input rows hit L1 / L2 instead of going back out to the
+    // fabric one full channel sweep later; weights are packed [N][tap][C], any order reads each byte once.
     const int steps0 = (p.c0 + BKE - 1) / BKE, steps1 = (p.c1 + BKE - 1) / BKE;
     const int nk = p.taps * (steps0 + steps1);
 
     const int c4 = tid & 7;
     const int r0 = tid >> 3;
 
-    // Per-thread A row descriptors.  Linear / 1x1 (taps == 1) is the degenerate conv with a 1 x M map
-    // (the launcher sets Ho = Hi = Hs = 1, Wo = Wi = Ws = M, pad = 0), so one gather serves both.
-    int a_img[AR], a_y[AR], a_x[AR];
-    bool a_ok[AR];
+    // Gather table in LDS: source pixel of (tap, tile row), ~0u for zero padding and rows >= M.  It folds the conv
+    // geometry -- padding, stride, the fp32-scale nearest resize of Upsample3D (resnet.py:58-61) -- out of the k-loop;
+    // a linear / 1x1 layer is the degenerate 1 x M map (pixel = row).  Per k-step a thread then needs, per row, one
+    // LDS word, one compare, one 64-bit multiply-add and a pointer select: masked elements read 16 zero bytes through
+    // that select, made BEFORE the load, so the loaded registers are untouched until the LDS store and the whole k-step
+    // is one basic block (on gfx950 VALU work is not hidden behind the fp32 MFMA: fewer instructions = more TFLOP/s).
+    unsigned* tab = reinterpret_cast<unsigned*>(smem + NBUF * (BM + BN) * LDS_LD);
+    // Block-relative addressing: every load of the block is  base (SGPR descriptor) + 32-bit byte offset, with the
+    // base moved to the first image (conv) / first row (linear) the block touches, so that offsets stay far below the
+    // 2 GB window of the descriptor whatever the tensor size.  Masked elements use an offset outside the window: the
+    // buffer unit returns zeros for them, no pointer select and no 64-bit arithmetic per load.
+    const int hw_out = p.Ho * p.Wo, hw_in = p.Hs * p.Ws;
+    const int img0 = p.taps == 1 ? 0 : (bm * BM) / hw_out;
+    const size_t row_base = p.taps == 1 ? (size_t)bm * BM : (size_t)img0 * hw_in;
     {
-        const int hw = p.Ho * p.Wo;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int m = bm * BM + r0 + RPP * i;
-            a_ok[i] = m < p.M;
-            const int mm = a_ok[i] ? m : 0;
-            const int img = mm / hw;
-            const int rem = mm - img * hw;
-            const int oy = rem / p.Wo;
-            a_img[i] = img;
-            a_y[i] = oy * p.stride - p.pad;
-            a_x[i] = (rem - oy * p.Wo) * p.stride - p.pad;
+        for (int e = tid; e < p.taps * BM; e += NT) {
+            const int tap = e / BM, row = e - tap * BM;
+            const int m = bm * BM + row;
+            unsigned pix = ~0u;
+            if (m < p.M) {
+                if (p.taps == 1) {
+                    pix = (unsigned)row;
+                } else {
+                    const int img = m / hw_out;
+                    const int rem = m - img * hw_out;
+                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                    const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;          // tap < 9
+                    const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+                    if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
+                        int sy = iy, sx = ix;
+                        if (p.upsample) {      // torch nearest: src = min(floor(dst * (in/out)), in - 1), fp32 scale
+                            sy = min((int)floorf((float)iy * p.ups_h), p.Hs - 1);
+                            sx = min((int)floorf((float)ix * p.ups_w), p.Ws - 1);
+                        }
+                        pix = (unsigned)(((img - img0) * p.Hs + sy) * p.Ws + sx);
+                    }
+                }
+            }
+            tab[e] = pix;
         }
     }
-    size_t b_row[BR];
-    bool b_ok[BR];
+    constexpr unsigned OOB = 0x80000000u;                   // beyond the descriptor window (with or without soffset): reads zeros
+    const float* const a0b = a0 + row_base * p.lda0;
+    const float* const a1b = p.c1 > 0 ? a1 + row_base * p.lda1 : a0b;
+    // descriptor of the current source, rebuilt from a pointer forced into SGPRs (a select between two ready-made
+    // descriptors makes hipcc wrap every load in a waterfall loop: it cannot prove the selected one wave-uniform)
+    auto rsrc_of = [](const void* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, 0x7FFFFFF0,
+                                                 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(w + (size_t)n0 * p.ldw * ESZ), (short)0, 0x7FFFFFF0, 0x00020000);
+    unsigned b_off[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-        const int n = n0 + r0 + RPP * j;
-        b_ok[j] = n < p.N;
-        b_row[j] = (size_t)(b_ok[j] ? n : 0) * p.ldw + c4 * (16 / ESZ);
+        const int r = r0 + RPP * j;
+        b_off[j] = (n0 + r < p.N) ? (unsigned)(r * p.ldw * ESZ + c4 * 16) : OOB;
     }
+    __syncthreads();
 
-    // Gather state of the NEXT tile to load.  Inside a segment a k-step only bumps eight pointers by 32 floats;
-    // the per-row pixel / padding arithmetic runs once per segment (every >= c/32 steps), behind a uniform branch
-    // that sits AFTER the MFMAs.  Masked elements (zero padding, rows >= M, channels >= c) read 16 zero bytes
-    // through a pointer select made BEFORE the load, so the loaded registers are not touched until the LDS store
-    // and the loads + pointer bumps share one basic block with the MFMAs of the current tile.
-    const float* __restrict__ zeros = p.zeros;
-    const float* pa[AR];
-    const char* pb[BR];
-    bool va[AR];
-    int seg_tap = 0, seg_src = 0, cb = 0, cseg = p.c0;
+    // state of the NEXT tile to load (all wave-uniform except pixn)
+    int k_src = 0, k_cb = 0, k_tap = 0, cseg = p.c0, ldb = p.lda0 * 4;
     bool done = false;
-    auto enter_segment = [&]() {
-        const int ky = (seg_tap * 11) >> 5, kx = seg_tap - 3 * ky;          // tap < 9
-        cseg = seg_src ? p.c1 : p.c0;
-        const float* base = seg_src ? a1 : a0;
-        const int ld = seg_src ? p.lda1 : p.lda0;
+    unsigned pixn[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) pixn[i] = tab[r0 + RPP * i];
+    // two register sets: the loads of tile ks+2 are issued while tile ks+1 still sits in the other set, so a load has a
+    // k-step and a half (~6000 cycles at 2 waves per SIMD) to come back before its LDS store needs it
+    f32x4 rga[2][AR * KH], rgb[2][BR];
+    auto issue_loads = [&](f32x4 (&ra)[AR * KH], f32x4 (&rb)[BR]) {
+        const unsigned colb = (unsigned)(k_cb + c4 * 4) * 4u;
+        const __amdgpu_buffer_rsrc_t rsa = rsrc_of(k_src ? a1b : a0b);
+        // bitwise (not short-circuit) conditions: the offset arithmetic stays branch-free -- one 24-bit multiply-add,
+        // one compare and one select per row (block-relative pixel indices and row strides are < 2^24)
+        const bool cok0 = (!done) & (k_cb + c4 * 4 < cseg);
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            int sy = ok ? iy : 0, sx = ok ? ix : 0;
-            if (p.upsample) {      // torch nearest (resnet.py:58-61): src = min(floor(dst * (in/out)), in - 1), fp32 scale
-                sy = min((int)floorf((float)sy * p.ups_h), p.Hs - 1);
-                sx = min((int)floorf((float)sx * p.ups_w), p.Ws - 1);
-            }
-            const size_t pix = ((size_t)a_img[i] * p.Hs + sy) * p.Ws + sx;
-            pa[i] = base + pix * ld + c4 * 4;
-            va[i] = ok;
-        }
-        const size_t koff = (size_t)seg_tap * Ctot + (seg_src ? p.c0 : 0);
-#pragma unroll
-        for (int j = 0; j < BR; ++j) pb[j] = w + (b_row[j] + koff) * ESZ;
-    };
-    f32x4 ra[AR * KH], rb[BR];
-    auto issue_loads = [&]() {
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
+            const unsigned rowb = __umul24(pixn[i], (unsigned)ldb) + colb;
+            const bool rok = (pixn[i] != ~0u) & cok0;
 #pragma unroll
             for (int kh = 0; kh < KH; ++kh) {
-                const bool cok = !done && (cb + kh * 32 + c4 * 4 < cseg);
-                const float* src = (va[i] && cok) ? pa[i] + kh * 32 : zeros;
-                ra[i * KH + kh] = *reinterpret_cast<const f32x4*>(src);
+                const bool ok = kh == 0 ? rok : (rok & (k_cb + kh * 32 + c4 * 4 < cseg));
+                ra[i * KH + kh] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, ok ? rowb + kh * 128 : OOB, 0, 0));
             }
-            pa[i] += BKE;
         }
-        const bool cokb = !done && (cb + c4 * (16 / ESZ) < cseg);
+        const bool cokb = (!done) & (k_cb + c4 * (16 / ESZ) < cseg);
+        const int cbase = (k_src ? p.c0 : 0) + k_cb;                               // channel of this k-step in the concat
+        const int koffb = (p.taps == 1 ? cbase : (cbase / BKE * 9 + k_tap) * BKE) * ESZ;   // wave-uniform: rides in soffset
 #pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            const char* src = (b_ok[j] && cokb) ? pb[j] : reinterpret_cast<const char*>(zeros);
-            rb[j] = *reinterpret_cast<const f32x4*>(src);
-            pb[j] += 128;                                   // 32 fp32 or 64 bf16
-        }
-        cb += BKE;
+        for (int j = 0; j < BR; ++j)
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, cokb ? b_off[j] : OOB, koffb, 0));
+        // advance (tap fastest, then chunk, then source) -- scalar selects, no branch
+        const int t2 = k_tap + 1;
+        const bool wrap_t = t2 == p.taps;
+        k_tap = wrap_t ? 0 : t2;
+        const int cb2 = wrap_t ? k_cb + BKE : k_cb;
+        const bool wrap = cb2 >= cseg;
+        k_cb = wrap ? 0 : cb2;
+        const bool more = k_src == 0 && p.c1 > 0;
+        done = done || (wrap && !more);
+        k_src = (wrap && more) ? 1 : k_src;
+        cseg = k_src ? p.c1 : p.c0;
+        ldb = (k_src ? p.lda1 : p.lda0) * 4;
+        // pixel indices of the tile after this one: consumed one k-step from now, so the LDS latency is off the path
+#pragma unroll
+        for (int i = 0; i < AR; ++i) pixn[i] = tab[k_tap * BM + r0 + RPP * i];
     };
-    auto advance_segment = [&]() {           // uniform: every lane sees the same cb / cseg
-        if (cb >= cseg) {
-            cb = 0;
-            if (seg_src == 0 && p.c1 > 0) {
-                seg_src = 1;
-            } else {
-                seg_src = 0;
-                ++seg_tap;
-            }
-            done = seg_tap >= p.taps;
-            if (!done) enter_segment();
-        }
-    };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const f32x4 (&ra)[AR * KH], const f32x4 (&rb)[BR]) {
         float* A = As + buf * BM * LDS_LD;
         float* B = Bs + buf * BN * LDS_LD;
 #pragma unroll
@@ -185,10 +200,9 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    enter_segment();
-    issue_loads();
-    advance_segment();
-    store_tile(0);
+    issue_loads(rga[0], rgb[0]);                // tile 0
+    issue_loads(rga[1], rgb[1]);                // tile 1 (all-zero dummy loads if nk == 1)
+    store_tile(0, rga[0], rgb[0]);
     __syncthreads();
 
     // Fragment double-buffering across the barrier: the last k-group of tile ks is multiplied AFTER the barrier
@@ -225,31 +239,34 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi][s], bf[set][ni][s], acc[mi][ni], 0, 0, 0);
         }
     };
-    static_assert(BK == 32, "the k-step below is written for four fragment groups of 32 bytes per row");
+    static_assert(BK == 32 && NBUF == 2, "the k-step below is written for two LDS buffers and four fragment groups of 32 bytes per row");
     read_frags(0, 0, 0);
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = NBUF == 2 ? (ks & 1) : 0;
-        const int nbuf = NBUF == 2 ? (buf ^ 1) : 0;
-        if (ABL == 0) issue_loads();            // tile ks+1 (all-zero dummy loads behind the last tile)
-        // keep the eight loads at the head of the k-step (their latency then hides behind the MFMAs below);
-        // left alone the scheduler sinks them to the end of the block, right in front of the waiting LDS stores
+    // one k-step; P = ks & 1 is a template constant (the loop is unrolled by two), so LDS buffer and register set are static
+    auto kstep = [&](auto Pc) {
+        constexpr int P = decltype(Pc)::value;
+        if (ABL == 0) issue_loads(rga[P], rgb[P]);      // tile ks+2 (all-zero dummy loads behind the last tile)
+        // keep the loads at the head of the k-step; left alone the scheduler sinks them to the end of the block
         __builtin_amdgcn_sched_barrier(0);
-        read_frags(1, buf, 1);
+        read_frags(1, P, 1);
         mma(0);
-        read_frags(0, buf, 2);
+        read_frags(0, P, 2);
         mma(1);
-        read_frags(1, buf, 3);
+        read_frags(1, P, 3);
         mma(0);
-        if (ABL == 0) advance_segment();
         if (ABL != 2) {
-            if (NBUF == 1) __syncthreads();      // single LDS buffer: everyone has finished reading it
-            store_tile(nbuf);
+            store_tile(P ^ 1, rga[P ^ 1], rgb[P ^ 1]);  // tile ks+1, loaded one k-step ago
             __syncthreads();
         }
-        read_frags(0, nbuf, 0);                 // first fragments of tile ks+1 ...
+        read_frags(0, P ^ 1, 0);                // first fragments of tile ks+1 ...
         __builtin_amdgcn_sched_barrier(0);
         mma(1);                                 // ... land while the last k-group of tile ks is multiplied
+    };
+    int ks = 0;
+    for (; ks + 1 < nk; ks += 2) {
+        kstep(std::integral_constant<int, 0>{});
+        kstep(std::integral_constant<int, 1>{});
     }
+    if (ks < nk) kstep(std::integral_constant<int, 0>{});
 
     // epilogue: C/D layout of the 32x32 MFMA -- column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const int col = lane & 31;
@@ -343,7 +360,7 @@ __global__ __launch_bounds__(256) void igemm_kernel_single(const IgemmArgs p) {
 template <int ABL, bool BF = false>
 static void launch_igemm(const IgemmArgs& a, int ntiles, const char* cls, hipStream_t s) {
     static bool configured = false;
-    constexpr size_t smem = (size_t)2 * (128 + 128) * LDS_LD * sizeof(float);
+    constexpr size_t smem = (size_t)2 * (128 + 128) * LDS_LD * sizeof(float) + 9 * 128 * sizeof(unsigned);   // tiles + gather table
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<ABL, BF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -395,7 +412,9 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
     a.s1 = rem == 0 ? 0 : (rem <= 64 ? 1 : 0);
     if (rem > 64) a.w1 += 1;                                 // 65..127 leftover columns: one more (masked) wide tile
     a.rb1 = nbm;
-    const bool use_bf16 = a.bf16 && a.w16 && a.c0 % 8 == 0 && a.c1 % 8 == 0 && a.ldw % 8 == 0;
+    const bool use_bf16 = a.bf16 && a.w16 && a.c0 % 8 == 0 && a.c1 % 8 == 0 && a.ldw16 % 8 == 0 &&
+                          (a.c1 == 0 || a.c0 % 64 == 0 || a.taps == 1);
+    if (use_bf16) a.ldw = a.ldw16;
     const char* cls = use_bf16 ? "igemm_bf16" : "igemm_f32";
     if (a.geglu) {                                           // the GEGLU epilogue pairs the two 32-column halves of a wave
         a.w1 = (a.N + 127) / 128; a.s1 = 0;
@@ -433,14 +452,14 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
         const bool narrow = (double)(n128 - a.N) > 0.12 * (double)n128;
         static bool cfgd = false;
         if (!cfgd) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel_single<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel_single<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel_single<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 78336);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel_single<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 78336);
             cfgd = true;
         }
         const int nb = nbm * (narrow ? (a.N + 63) / 64 : (a.N + 127) / 128);
         ProfScope ps(narrow ? "igemm_f32_128x64" : "igemm_f32_128x128", 2.0 * a.M * a.N * (double)a.taps * (a.c0 + a.c1) * a.batch, 0.0, s);
-        if (narrow) hipLaunchKernelGGL((igemm_kernel_single<64>), dim3(nb, 1, a.batch), dim3(256), 55296, s, a);
-        else hipLaunchKernelGGL((igemm_kernel_single<128>), dim3(nb, 1, a.batch), dim3(256), 73728, s, a);
+        if (narrow) hipLaunchKernelGGL((igemm_kernel_single<64>), dim3(nb, 1, a.batch), dim3(256), 78336, s, a);
+        else hipLaunchKernelGGL((igemm_kernel_single<128>), dim3(nb, 1, a.batch), dim3(256), 78336, s, a);
         return;
     }
     if (use_bf16 && abl == 0) { launch_igemm<0, true>(a, ntiles, cls, s); return; }
@@ -450,19 +469,27 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
 }
 
 // ---- one-off weight re-layout ---------------------------------------------------------------------
-__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ o, int cout, int cin, int cin_pad) {
-    const size_t total = (size_t)cout * 9 * cin_pad;
+// [O][I][3][3] -> [O][chunk][tap][bke]: the k order the kernel walks (channel chunk > tap), so that every k-step reads the
+// next 128 contiguous bytes of each weight row; channels beyond I are zero (a ragged last chunk costs no masking).
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ o, int cout, int cin, int bke) {
+    const int nq = (cin + bke - 1) / bke;
+    const size_t per = (size_t)nq * 9 * bke;
+    const size_t total = (size_t)cout * per;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = i % cin_pad;
-        const int tap = (i / cin_pad) % 9;
-        const int oc = i / ((size_t)cin_pad * 9);
+        const int oc = i / per;
+        const size_t r = i - (size_t)oc * per;
+        const int e = r % bke;
+        const int tap = (r / bke) % 9;
+        const int q = r / ((size_t)bke * 9);
+        const int c = q * bke + e;
         o[i] = (c < cin) ? w[((size_t)oc * cin + c) * 9 + tap] : 0.f;
     }
 }
-void pack_conv3x3(const float* w, float* o, int cout, int cin, int cin_pad, hipStream_t s) {
-    const size_t total = (size_t)cout * 9 * cin_pad;
+int conv3x3_packed_ld(int cin, int bke) { return (cin + bke - 1) / bke * 9 * bke; }
+void pack_conv3x3(const float* w, float* o, int cout, int cin, int bke, hipStream_t s) {
+    const size_t total = (size_t)cout * conv3x3_packed_ld(cin, bke);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(256), 0, s, w, o, cout, cin, cin_pad);
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(256), 0, s, w, o, cout, cin, bke);
 }
 
 __global__ void to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n) {

@@ -19,8 +19,9 @@ struct IgemmArgs {
     const float* a0 = nullptr; const float* a1 = nullptr;
     int c0 = 0, c1 = 0;            // channels taken from a0 / a1 (multiples of 4)
     int lda0 = 0, lda1 = 0;        // row strides (floats)
-    const float* w = nullptr;      // packed [N][taps*(c0+c1)]
+    const float* w = nullptr;      // linear: [N][K]; 3x3: [N][chunk of 32][tap][32] (pack_conv3x3)
     int ldw = 0;
+    int ldw16 = 0;                 // row length of w16 (3x3: chunks of 64)
     float* out = nullptr; int ldc = 0;
     const float* bias = nullptr;       // [N]
     const float* rowbias = nullptr;    // [samples][rb_ld] (time embedding added after conv1, resnet.py:186)
@@ -46,7 +47,9 @@ struct IgemmArgs {
 void igemm(const IgemmArgs& a, hipStream_t s);
 
 // weight re-layout helpers (one-off, at finalize)
-void pack_conv3x3(const float* w_oihw, float* w_packed, int cout, int cin, int cin_pad, hipStream_t s);
+// [O][I][3][3] -> [O][ceil(I/bke)][9][bke] (bke = 32 for the fp32 kernel, 64 for the bf16 one); row length below
+int conv3x3_packed_ld(int cin, int bke);
+void pack_conv3x3(const float* w_oihw, float* w_packed, int cout, int cin, int bke, hipStream_t s);
 void copy_rows(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t s);
 void to_bf16(const float* in, void* out_bf16, size_t n, hipStream_t s);
 

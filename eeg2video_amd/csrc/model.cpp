@@ -170,13 +170,21 @@ struct Packer {
         const WTensor& w = t(n + ".weight");
         return LinW{w.d, bias ? t(n + ".bias").d : nullptr, (int)w.shape[1], (int)w.shape[0], half(w.d, w.numel)};
     }
-    ConvW conv3(const std::string& n) {                      // [O][I][3][3] -> [O][tap][I padded to 4]
+    ConvW conv3(const std::string& n) {                      // [O][I][3][3] -> [O][chunk][tap][32] (+ a bf16 copy in chunks of 64)
         const WTensor& w = t(n + ".weight");
         const int co = (int)w.shape[0], ci = (int)w.shape[1];
         const int cp = (ci + 3) / 4 * 4;
-        float* d = c->dev_alloc((size_t)co * 9 * cp);
-        pack_conv3x3(w.d, d, co, ci, cp, s);
-        return ConvW{d, t(n + ".bias").d, ci, cp, co, half(d, (size_t)co * 9 * cp)};
+        const int ld32 = conv3x3_packed_ld(ci, 32), ld64 = conv3x3_packed_ld(ci, 64);
+        float* d = c->dev_alloc((size_t)co * ld32);
+        pack_conv3x3(w.d, d, co, ci, 32, s);
+        float* tmp = nullptr;
+        E2V_HIP(hipMalloc((void**)&tmp, (size_t)co * ld64 * sizeof(float)));
+        pack_conv3x3(w.d, tmp, co, ci, 64, s);
+        float* d16 = c->dev_alloc(((size_t)co * ld64 + 1) / 2);
+        to_bf16(tmp, d16, (size_t)co * ld64, s);
+        E2V_HIP(hipStreamSynchronize(s));
+        (void)hipFree(tmp);
+        return ConvW{d, t(n + ".bias").d, ci, cp, co, d16, ld32, ld64};
     }
     LinW fuse_rows(const std::vector<std::string>& names, bool bias) {   // stack Linear weights along `out`
         int in = 0, out = 0;
@@ -408,7 +416,7 @@ struct Runner {
         Act out(pool(), M, geglu ? w.out / 2 : w.out);
         IgemmArgs g;
         g.a0 = a; g.c0 = K0; g.lda0 = lda; g.a1 = a1; g.c1 = c1; g.lda1 = lda1;
-        g.w = w.w; g.ldw = w.in; g.out = out.p; g.ldc = out.C; g.bias = w.b;
+        g.w = w.w; g.ldw = w.in; g.ldw16 = w.in; g.out = out.p; g.ldc = out.C; g.bias = w.b;
         g.resid = resid; g.ldr = ldr; g.M = (int)M; g.N = w.out; g.taps = 1; g.geglu = geglu ? 1 : 0;
         g.bf16 = c->bf16_compute ? 1 : 0; g.w16 = w.w16;
         igemm(g, s);
@@ -422,7 +430,8 @@ struct Runner {
         Act out(pool(), (int64_t)geo.nimg * Ho * Wo, w.cout);
         IgemmArgs g;
         g.a0 = x0; g.c0 = c0; g.lda0 = c0; g.a1 = x1; g.c1 = c1; g.lda1 = c1;
-        g.w = w.w; g.ldw = 9 * w.cin_pad; g.out = out.p; g.ldc = w.cout; g.bias = w.b;
+        E2V_REQUIRE(c1 == 0 || c0 % 32 == 0, E2V_ESHAPE, "conv: the concat seam must be a multiple of 32 channels");
+        g.w = w.w; g.ldw = w.ldw; g.ldw16 = w.ldw16; g.out = out.p; g.ldc = w.cout; g.bias = w.b;
         g.rowbias = rowbias; g.rb_ld = w.cout; g.rows_per_sample = rows_per_sample;
         g.resid = resid; g.ldr = w.cout;
         g.M = (int)out.rows; g.N = w.cout; g.taps = 9;

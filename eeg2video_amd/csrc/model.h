@@ -14,7 +14,7 @@ namespace e2v {
 
 struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
 struct LinW { const float* w = nullptr; const float* b = nullptr; int in = 0, out = 0; const void* w16 = nullptr; };
-struct ConvW { const float* w = nullptr; const float* b = nullptr; int cin = 0, cin_pad = 0, cout = 0; const void* w16 = nullptr; };
+struct ConvW { const float* w = nullptr; const float* b = nullptr; int cin = 0, cin_pad = 0, cout = 0; const void* w16 = nullptr; int ldw = 0, ldw16 = 0; };
 
 struct ResW {
     NormW n1, n2;
