@@ -62,6 +62,7 @@ SIGNATURES = {
     "e2v_dana_noise": (_i, [_ctx, _p, _p, _p, c_int64_p, _i, _f, _i, _i, _i, _i, _i, _p, _stream]),
     "e2v_frames_to_uint8": (_i, [_ctx, _p, _p, _i64, _stream]),
     "e2v_set_compute_dtype": (_i, [_ctx, _i]),
+    "e2v_set_conv_algo": (_i, [_ctx, _i]),
     "e2v_device_bytes": (_i64, [_ctx]),
     "e2v_profile_begin": (_i, [_ctx]),
     "e2v_profile_end": (_i64, [_ctx, C.c_char_p, _i64]),

@@ -110,6 +110,9 @@ e2v_status e2v_create(const e2v_config* cfg, int device, e2v_ctx** out) {
         c->device = device;
         c->expected_keys();
         make_alphas(c);
+        if (const char* e = std::getenv("E2V_CONV_ALGO")) c->conv_algo = std::atoi(e);
+        if (const char* e = std::getenv("E2V_WINO_MIN_C")) c->wino_min_c = std::atoi(e);
+        if (const char* e = std::getenv("E2V_WINO_WS_MB")) c->wino_ws_floats = (size_t)std::atol(e) * (1u << 18);
     });
     if (st != E2V_OK) { delete c; return st; }
     *out = c;
@@ -283,6 +286,12 @@ e2v_status e2v_set_compute_dtype(e2v_ctx* c, int dtype) {
     return E2V_OK;
 }
 
+e2v_status e2v_set_conv_algo(e2v_ctx* c, int algo) {
+    if (!c || algo < E2V_CONV_AUTO || algo > E2V_CONV_WINOGRAD) return E2V_EINVAL;
+    c->conv_algo = algo;
+    return E2V_OK;
+}
+
 int64_t e2v_device_bytes(const e2v_ctx* c) { return c ? (int64_t)(c->weight_bytes + c->pool.bytes()) : 0; }
 
 // ---------------------------------------------------------------------------------------------------
@@ -439,6 +448,25 @@ e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, 
         hipStream_t s = S(stream);
         const int cin = c0 + c1;
         E2V_REQUIRE(c1 == 0 || c0 % 32 == 0, E2V_ESHAPE, "conv: the concat seam must be a multiple of 32 channels");
+        const bool wino_shape = stride == 1 && pad_lo == 1 && Hi == Ho && Wi == Wo && cout % 4 == 0 && !c->bf16_compute;
+        if (wino_shape && (c->conv_algo == E2V_CONV_WINOGRAD ||
+                           (c->conv_algo == E2V_CONV_AUTO && std::min(cin, cout) >= c->wino_min_c))) {
+            Act u(c->pool, (int64_t)16 * cout, cin);
+            wino_pack_weights(w_oihw, u.p, cout, cin, s);
+            WinoArgs a;
+            a.x0 = x0; a.c0 = c0; a.ld0 = c0; a.x1 = x1; a.c1 = c1; a.ld1 = c1;
+            a.nimg = n_img; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo;
+            if (Hi != Hs || Wi != Ws) { a.upsample = 1; a.ups_h = (float)Hs / (float)Hi; a.ups_w = (float)Ws / (float)Wi; }
+            a.U = u.p; a.N = cout; a.out = out; a.ldc = cout; a.bias = bias;
+            a.rowbias = rowbias; a.rb_ld = cout; a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+            a.resid = resid; a.ldr = cout;
+            const int chunk = wino_chunk_images(a, c->wino_ws_floats);
+            const size_t need = wino_workspace_floats(a, chunk);
+            Act ws(c->pool, (int64_t)((need + 1023) / 1024), 1024);
+            wino_conv3x3(a, ws.p, chunk, s);
+            E2V_HIP(hipGetLastError());
+            return;
+        }
         const int ld32 = conv3x3_packed_ld(cin, 32), ld64 = conv3x3_packed_ld(cin, 64);
         Act wp(c->pool, cout, ld32);
         pack_conv3x3(w_oihw, wp.p, cout, cin, 32, s);

@@ -54,6 +54,28 @@ void copy_rows(const float* src, int ld_src, float* dst, int ld_dst, int rows, i
 void to_bf16(const float* in, void* out_bf16, size_t n, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) for the stride-1, pad-1 3x3 convolutions (wino.hip); output map = logical input map
+// ---------------------------------------------------------------------------------------
+struct WinoArgs {
+    const float* x0 = nullptr; const float* x1 = nullptr;      // channel-last sources (x1: concatenated skip)
+    int c0 = 0, c1 = 0, ld0 = 0, ld1 = 0;
+    int nimg = 0, Hs = 1, Ws = 1;                              // physical source map
+    int Ho = 1, Wo = 1;                                        // output map (= source map, or 2x with upsample)
+    int upsample = 0; float ups_h = 1.f, ups_w = 1.f;
+    const float* gn_scsh = nullptr; int gn_P = 1; int gn_silu = 0;   // fused GroupNorm affine (+ SiLU) on the way in
+    const float* U = nullptr;                                  // [16][N][c0+c1] (wino_pack_weights)
+    int N = 0;
+    float* out = nullptr; int ldc = 0;
+    const float* bias = nullptr;
+    const float* rowbias = nullptr; int rb_ld = 0; int rows_per_sample = 1;
+    const float* resid = nullptr; int ldr = 0;
+};
+void wino_pack_weights(const float* w_oihw, float* U, int cout, int cin, hipStream_t s);
+size_t wino_workspace_floats(const WinoArgs& a, int nimg);       // V + M for `nimg` images
+int wino_chunk_images(const WinoArgs& a, size_t max_floats);     // images per pass so that the workspace fits
+void wino_conv3x3(const WinoArgs& a, float* workspace, int chunk_images, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
 // normalisation (norm.hip)
 // ---------------------------------------------------------------------------------------
 // GroupNorm over `samples` slabs of P rows.  Statistics are taken over (C/groups) channels x P rows
@@ -71,6 +93,9 @@ struct GroupNormArgs {
 };
 int  groupnorm_chunks(int P);
 void groupnorm(const GroupNormArgs& a, hipStream_t s);
+// statistics only: leaves per-(slab, channel) (scale, shift) pairs in a.ws_scale for a consumer that applies the affine
+// (+ SiLU) itself while it reads the tensor anyway (the Winograd input transform)
+void groupnorm_stats(const GroupNormArgs& a, hipStream_t s);
 void layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* out, int ldo,
                int rows, int C, float eps, hipStream_t s);
 

@@ -170,7 +170,8 @@ struct Packer {
         const WTensor& w = t(n + ".weight");
         return LinW{w.d, bias ? t(n + ".bias").d : nullptr, (int)w.shape[1], (int)w.shape[0], half(w.d, w.numel)};
     }
-    ConvW conv3(const std::string& n) {                      // [O][I][3][3] -> [O][chunk][tap][32] (+ a bf16 copy in chunks of 64)
+    // [O][I][3][3] -> [O][chunk][tap][32] (+ a bf16 copy in chunks of 64) (+ Winograd-domain weights for stride-1 convs)
+    ConvW conv3(const std::string& n, bool stride1 = true) {
         const WTensor& w = t(n + ".weight");
         const int co = (int)w.shape[0], ci = (int)w.shape[1];
         const int cp = (ci + 3) / 4 * 4;
@@ -184,7 +185,13 @@ struct Packer {
         to_bf16(tmp, d16, (size_t)co * ld64, s);
         E2V_HIP(hipStreamSynchronize(s));
         (void)hipFree(tmp);
-        return ConvW{d, t(n + ".bias").d, ci, cp, co, d16, ld32, ld64};
+        const float* wino = nullptr;
+        if (stride1 && ci % 4 == 0 && co % 4 == 0 && c->conv_algo != 1 && (c->conv_algo == 2 || std::min(ci, co) >= c->wino_min_c)) {
+            float* u = c->dev_alloc((size_t)16 * co * ci);
+            wino_pack_weights(w.d, u, co, ci, s);
+            wino = u;
+        }
+        return ConvW{d, t(n + ".bias").d, ci, cp, co, d16, ld32, ld64, wino};
     }
     LinW fuse_rows(const std::vector<std::string>& names, bool bias) {   // stack Linear weights along `out`
         int in = 0, out = 0;
@@ -265,7 +272,7 @@ void e2v_ctx::finalize(int which) {
                 b.res.push_back(P.resnet(idx("down_blocks", i, "resnets", j), true));
                 if (i < 3) b.attn.push_back(P.transformer(idx("down_blocks", i, "attentions", j)));
             }
-            if (i != 3) { b.resample = true; b.rs = P.conv3("down_blocks." + std::to_string(i) + ".downsamplers.0.conv"); }
+            if (i != 3) { b.resample = true; b.rs = P.conv3("down_blocks." + std::to_string(i) + ".downsamplers.0.conv", false); }
             u.down.push_back(std::move(b));
         }
         u.mid_r0 = P.resnet("mid_block.resnets.0", true);
@@ -305,7 +312,7 @@ void e2v_ctx::finalize(int which) {
         for (int i = 0; i < 4; ++i) {
             VAEW::Block b;
             for (int j = 0; j < VL; ++j) b.res.push_back(P.resnet(idx("vae.encoder.down_blocks", i, "resnets", j), false));
-            if (i != 3) { b.resample = true; b.rs = P.conv3("vae.encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv"); }
+            if (i != 3) { b.resample = true; b.rs = P.conv3("vae.encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", false); }
             v.enc_down.push_back(std::move(b));
         }
         v.enc_mid0 = P.resnet("vae.encoder.mid_block.resnets.0", false);
@@ -401,6 +408,24 @@ struct Runner {
         return out;
     }
 
+    // statistics only: (scale, shift) per (slab, channel) left in c->gn_scale for the conv's input transform
+    void gn_stats(const NormW& w, const float* x0, int c0, const float* x1, int c1, int samples, int P, int groups, float eps) {
+        const int C = c0 + c1;
+        E2V_REQUIRE(C == w.c && C % groups == 0 && c0 % 4 == 0 && c1 % 4 == 0, E2V_ESHAPE, "GroupNorm channel mismatch");
+        gn_ws(samples, P, C);
+        GroupNormArgs a;
+        a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1; a.ld0 = c0; a.ld1 = c1;
+        a.gamma = w.g; a.beta = w.b; a.samples = samples; a.P = P; a.groups = groups; a.eps = eps;
+        a.ws_part = c->gn_part; a.ws_scale = c->gn_scale;
+        groupnorm_stats(a, s);
+    }
+
+    // does this conv run in Winograd form?  (fp32 arithmetic only: in bf16 the transforms would dominate and the
+    // rounding of transformed inputs costs accuracy)
+    bool winograd(const ConvW& w, int stride, int pad, int Hi, int Wi, int Ho, int Wo) const {
+        return w.wino && c->conv_algo != 1 && !c->bf16_compute && stride == 1 && pad == 1 && Hi == Ho && Wi == Wo;
+    }
+
     Act ln(const NormW& w, const Act& x) {
         E2V_REQUIRE(x.C == w.c && x.C % 4 == 0 && x.C <= 1280, E2V_ESHAPE, "LayerNorm width unsupported");
         Act out(pool(), x.rows, x.C);
@@ -424,10 +449,32 @@ struct Runner {
     }
 
     // 3x3 conv over `geo.nimg` images; (Hi, Wi) = logical input size (after nearest resize), (Ho, Wo) output size
+    // gn_P > 0: the input is the RAW tensor and GroupNorm's affine + SiLU (statistics already in c->gn_scale, slabs of
+    // gn_P rows) is applied on the way in -- only valid when winograd() says so
     Act conv3(const ConvW& w, const float* x0, int c0, const float* x1, int c1, Geo geo, int Hi, int Wi, int Ho, int Wo,
-              int stride, int pad, const float* rowbias = nullptr, int rows_per_sample = 1, const float* resid = nullptr) {
+              int stride, int pad, const float* rowbias = nullptr, int rows_per_sample = 1, const float* resid = nullptr,
+              int gn_P = 0) {
         E2V_REQUIRE(c0 + c1 == w.cin_pad, E2V_ESHAPE, "conv: input channels do not match the weight");
         Act out(pool(), (int64_t)geo.nimg * Ho * Wo, w.cout);
+        if (winograd(w, stride, pad, Hi, Wi, Ho, Wo)) {
+            WinoArgs a;
+            a.x0 = x0; a.c0 = c0; a.ld0 = c0; a.x1 = x1; a.c1 = c1; a.ld1 = c1;
+            a.nimg = geo.nimg; a.Hs = geo.H; a.Ws = geo.W; a.Ho = Ho; a.Wo = Wo;
+            if (Hi != geo.H || Wi != geo.W) {
+                a.upsample = 1;
+                a.ups_h = (float)geo.H / (float)Hi;        // torch: scale = (float)input_size / output_size
+                a.ups_w = (float)geo.W / (float)Wi;
+            }
+            if (gn_P > 0) { a.gn_scsh = c->gn_scale; a.gn_P = gn_P; a.gn_silu = 1; }
+            a.U = w.wino; a.N = w.cout; a.out = out.p; a.ldc = w.cout; a.bias = w.b;
+            a.rowbias = rowbias; a.rb_ld = w.cout; a.rows_per_sample = rows_per_sample; a.resid = resid; a.ldr = w.cout;
+            const int chunk = wino_chunk_images(a, c->wino_ws_floats);
+            const size_t need = wino_workspace_floats(a, chunk);
+            Act ws(pool(), (int64_t)((need + 1023) / 1024), 1024);
+            wino_conv3x3(a, ws.p, chunk, s);
+            return out;
+        }
+        E2V_REQUIRE(gn_P == 0, E2V_EINVAL, "conv: fused GroupNorm needs the Winograd path");
         IgemmArgs g;
         g.a0 = x0; g.c0 = c0; g.lda0 = c0; g.a1 = x1; g.c1 = c1; g.lda1 = c1;
         E2V_REQUIRE(c1 == 0 || c0 % 32 == 0, E2V_ESHAPE, "conv: the concat seam must be a multiple of 32 channels");
@@ -457,13 +504,14 @@ struct Runner {
             tp = linear(w.temb, temb_silu, temb_dim, samples);                                        // :183
         }
         Act h1;
-        {
+        if (winograd(w.c1, 1, 1, geo.H, geo.W, geo.H, geo.W)) {        // GroupNorm + SiLU applied inside the conv's input transform
+            gn_stats(w.n1, x0, c0, x1, c1, samples, P, groups, eps);                                  // :177-178
+            h1 = conv3(w.c1, x0, c0, x1, c1, geo, geo.H, geo.W, geo.H, geo.W, 1, 1, tp.p, P, nullptr, P);   // :180,186
+        } else {
             Act hn = gn(w.n1, x0, c0, x1, c1, samples, P, groups, eps, true);                        // :177-178
             h1 = conv3(w.c1, hn.p, w.cin, nullptr, 0, geo, geo.H, geo.W, geo.H, geo.W, 1, 1,          // :180,186
                        tp.p, P);
         }
-        Act h2 = gn(w.n2, h1.p, w.cout, nullptr, 0, samples, P, groups, eps, true);                  // :188,194
-        h1.reset();
         Act sc;
         const float* resid = x0;
         if (w.sc.w) {                                                                                 // :199-200
@@ -472,6 +520,12 @@ struct Runner {
         } else {
             E2V_REQUIRE(c1 == 0, E2V_ESHAPE, "identity shortcut with a concatenated input");
         }
+        if (winograd(w.c2, 1, 1, geo.H, geo.W, geo.H, geo.W)) {
+            gn_stats(w.n2, h1.p, w.cout, nullptr, 0, samples, P, groups, eps);                        // :188,194
+            return conv3(w.c2, h1.p, w.cout, nullptr, 0, geo, geo.H, geo.W, geo.H, geo.W, 1, 1, nullptr, 1, resid, P);   // :197,202
+        }
+        Act h2 = gn(w.n2, h1.p, w.cout, nullptr, 0, samples, P, groups, eps, true);                  // :188,194
+        h1.reset();
         return conv3(w.c2, h2.p, w.cout, nullptr, 0, geo, geo.H, geo.W, geo.H, geo.W, 1, 1, nullptr, 1, resid);   // :197,202
     }
 

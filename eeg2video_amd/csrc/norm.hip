@@ -160,11 +160,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
 }
 
-void groupnorm(const GroupNormArgs& a, hipStream_t s) {
+static void groupnorm_stats_launch(const GroupNormArgs& a, hipStream_t s) {
     const int Ctot = a.c0 + a.c1;
     const int chunks = groupnorm_chunks(a.P);
-    const double elems = (double)a.samples * a.P * Ctot;
-    ProfScope ps(a.silu ? "groupnorm_silu" : "groupnorm", 8.0 * elems, 2.0 * 4.0 * elems, s);   // algorithmic: read + write
     {
         const int qt = quad_tile(a.c0 / 4);
         hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, a.samples), dim3(256), 0, s, a.x0, a.ld0, a.c0, a.P, chunks,
@@ -177,6 +175,19 @@ void groupnorm(const GroupNormArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.samples), dim3(64), 0, s, a.ws_part, chunks, Ctot, a.groups,
                        a.P, a.eps, a.gamma, a.beta, a.ws_scale);
+}
+
+void groupnorm_stats(const GroupNormArgs& a, hipStream_t s) {
+    const double elems = (double)a.samples * a.P * (a.c0 + a.c1);
+    ProfScope ps("groupnorm_stats", 3.0 * elems, 4.0 * elems, s);                               // algorithmic: one read
+    groupnorm_stats_launch(a, s);
+}
+
+void groupnorm(const GroupNormArgs& a, hipStream_t s) {
+    const int Ctot = a.c0 + a.c1;
+    const double elems = (double)a.samples * a.P * Ctot;
+    ProfScope ps(a.silu ? "groupnorm_silu" : "groupnorm", 8.0 * elems, 2.0 * 4.0 * elems, s);   // algorithmic: read + write
+    groupnorm_stats_launch(a, s);
     const size_t rows = (size_t)a.samples * a.P;
     const size_t total = rows * (Ctot / 4);
     const int blocks = (int)((total + 511) / 512 < 16384 ? (total + 511) / 512 : 16384);

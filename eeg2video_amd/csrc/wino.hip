@@ -1,0 +1,215 @@
+// Winograd F(2x2, 3x3) form of the stride-1 3x3 convolutions of ResnetBlock3D / Upsample3D (resnet.py:58-66,
+// 180, 197) and of the VAE's resnets: 16 multiplies per 2x2 output tile instead of 36, i.e. 2.25x fewer
+// matrix-core flops than the direct implicit GEMM, paid for with two HBM-bound transform passes.
+//
+//   V[k][t][c] = (B^T d B)[k]        d = 4x4 input patch of tile t, channel c            (wino_in_kernel)
+//   M[k][t][o] = sum_c V[k][t][c] U[k][o][c]      16 independent GEMMs = igemm(), batch 16
+//   y[2x2]     = A^T M A (+ bias, time-embedding row, residual)                          (wino_out_kernel)
+//   U[k][o][c] = (G g G^T)[k]        once, at e2v_finalize_weights                       (wino_weight_kernel)
+//
+// The input transform also absorbs what precedes the conv in the graph: the channel concat of the up blocks
+// (two sources), the nearest 2x resize of Upsample3D (torch's fp32-scale index formula) and, for the resnets,
+// the GroupNorm affine + SiLU (per-(slab, channel) scale / shift from groupnorm_stats) -- the normalised
+// activation is then never written to HBM.  Zero padding is applied after the activation, as F.conv2d does.
+//
+// fp32 throughout; F(2x2, 3x3) has transform constants 0, +-1, +-1/2 only, its rounding error stays within a small
+// multiple of the direct sum's (tests/test_hip_ops.py::test_conv3x3_winograd pins 2e-5 relative to the output scale).
+#include "kernels.h"
+#include "prof.h"
+
+namespace e2v {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wino_silu(float v) { return v / (1.0f + expf(-v)); }
+
+// one thread = one tile x four channels; consecutive threads = consecutive channel quads (16-byte lanes, coalesced)
+__global__ __launch_bounds__(256) void wino_in_kernel(const WinoArgs p, int img_lo, int nimg, float* __restrict__ V) {
+    const int Ctot = p.c0 + p.c1;
+    const int CQ = Ctot / 4;
+    const int th = (p.Ho + 1) / 2, tw = (p.Wo + 1) / 2;
+    const size_t T = (size_t)nimg * th * tw;
+    const size_t total = T * CQ;
+    const size_t plane = T * Ctot;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / CQ;
+        const int c = (int)(i - t * CQ) * 4;
+        const int img = (int)(t / (th * tw));
+        const int rem = (int)(t - (size_t)img * th * tw);
+        const int ty = rem / tw, tx = rem - ty * tw;
+        const bool second = c >= p.c0;
+        const float* __restrict__ src = second ? p.x1 + (c - p.c0) : p.x0 + c;
+        const int ld = second ? p.ld1 : p.ld0;
+        const size_t img_row = (size_t)(img_lo + img) * p.Hs * p.Ws;
+        f32x4 ga = {1.f, 0.f, 1.f, 0.f}, gb = {1.f, 0.f, 1.f, 0.f};
+        if (p.gn_scsh) {                                   // (scale, shift) pairs of the 4 channels
+            const size_t slab = img_row / (size_t)p.gn_P;
+            const float* sc = p.gn_scsh + (slab * Ctot + c) * 2;
+            ga = *reinterpret_cast<const f32x4*>(sc);
+            gb = *reinterpret_cast<const f32x4*>(sc + 4);
+        }
+        f32x4 d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int iy = 2 * ty - 1 + r;
+            const bool yok = (unsigned)iy < (unsigned)p.Ho;
+            int sy = yok ? iy : 0;
+            if (p.upsample) sy = min((int)floorf((float)sy * p.ups_h), p.Hs - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ix = 2 * tx - 1 + q;
+                const bool ok = yok && (unsigned)ix < (unsigned)p.Wo;
+                int sx = ok ? ix : 0;
+                if (p.upsample) sx = min((int)floorf((float)sx * p.ups_w), p.Ws - 1);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) {
+                    v = *reinterpret_cast<const f32x4*>(src + (img_row + (size_t)sy * p.Ws + sx) * ld);
+                    if (p.gn_scsh) {
+                        v[0] = v[0] * ga[0] + ga[1];
+                        v[1] = v[1] * ga[2] + ga[3];
+                        v[2] = v[2] * gb[0] + gb[1];
+                        v[3] = v[3] * gb[2] + gb[3];
+                        if (p.gn_silu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = wino_silu(v[e]);
+                        }
+                    }
+                }
+                d[r][q] = v;
+            }
+        }
+        // B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+        f32x4 u[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u[0][q] = d[0][q] - d[2][q];
+            u[1][q] = d[1][q] + d[2][q];
+            u[2][q] = d[2][q] - d[1][q];
+            u[3][q] = d[1][q] - d[3][q];
+        }
+        float* __restrict__ o = V + t * Ctot + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            *reinterpret_cast<f32x4*>(o + (size_t)(4 * r + 0) * plane) = u[r][0] - u[r][2];
+            *reinterpret_cast<f32x4*>(o + (size_t)(4 * r + 1) * plane) = u[r][1] + u[r][2];
+            *reinterpret_cast<f32x4*>(o + (size_t)(4 * r + 2) * plane) = u[r][2] - u[r][1];
+            *reinterpret_cast<f32x4*>(o + (size_t)(4 * r + 3) * plane) = u[r][1] - u[r][3];
+        }
+    }
+}
+
+// one thread = one tile x four output channels: y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]
+__global__ __launch_bounds__(256) void wino_out_kernel(const WinoArgs p, int img_lo, int nimg, const float* __restrict__ Mb) {
+    const int NQ = p.N / 4;
+    const int th = (p.Ho + 1) / 2, tw = (p.Wo + 1) / 2;
+    const size_t T = (size_t)nimg * th * tw;
+    const size_t total = T * NQ;
+    const size_t plane = T * p.N;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / NQ;
+        const int n = (int)(i - t * NQ) * 4;
+        const int img = (int)(t / (th * tw));
+        const int rem = (int)(t - (size_t)img * th * tw);
+        const int ty = rem / tw, tx = rem - ty * tw;
+        const float* __restrict__ m = Mb + t * p.N + n;
+        f32x4 w[2][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(m + (size_t)(0 + q) * plane);
+            const f32x4 m1 = *reinterpret_cast<const f32x4*>(m + (size_t)(4 + q) * plane);
+            const f32x4 m2 = *reinterpret_cast<const f32x4*>(m + (size_t)(8 + q) * plane);
+            const f32x4 m3 = *reinterpret_cast<const f32x4*>(m + (size_t)(12 + q) * plane);
+            w[0][q] = m0 + m1 + m2;
+            w[1][q] = m1 - m2 - m3;
+        }
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int oy = 2 * ty + a;
+            if (oy >= p.Ho) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ox = 2 * tx + b;
+                if (ox >= p.Wo) continue;
+                f32x4 y = b == 0 ? w[a][0] + w[a][1] + w[a][2] : w[a][1] - w[a][2] - w[a][3];
+                const size_t row = ((size_t)(img_lo + img) * p.Ho + oy) * p.Wo + ox;
+                y += bias;
+                if (p.rowbias) y += *reinterpret_cast<const f32x4*>(p.rowbias + (row / p.rows_per_sample) * p.rb_ld + n);
+                if (p.resid) y += *reinterpret_cast<const f32x4*>(p.resid + row * p.ldr + n);
+                *reinterpret_cast<f32x4*>(p.out + row * p.ldc + n) = y;
+            }
+        }
+    }
+}
+
+// [O][I][3][3] -> U[16][O][I] = G g G^T,  G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
+__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int cout, int cin) {
+    const size_t total = (size_t)cout * cin;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float* g = w + i * 9;
+        float t[4][3];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            t[0][x] = g[x];
+            t[1][x] = 0.5f * (g[x] + g[3 + x] + g[6 + x]);
+            t[2][x] = 0.5f * (g[x] - g[3 + x] + g[6 + x]);
+            t[3][x] = g[6 + x];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            U[(size_t)(4 * r + 0) * total + i] = t[r][0];
+            U[(size_t)(4 * r + 1) * total + i] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
+            U[(size_t)(4 * r + 2) * total + i] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
+            U[(size_t)(4 * r + 3) * total + i] = t[r][2];
+        }
+    }
+}
+
+void wino_pack_weights(const float* w_oihw, float* U, int cout, int cin, hipStream_t s) {
+    const size_t total = (size_t)cout * cin;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wino_weight_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, U, cout, cin);
+}
+
+size_t wino_workspace_floats(const WinoArgs& a, int nimg) {
+    const size_t T = (size_t)nimg * ((a.Ho + 1) / 2) * ((a.Wo + 1) / 2);
+    return 16 * T * (size_t)(a.c0 + a.c1 + a.N);
+}
+
+int wino_chunk_images(const WinoArgs& a, size_t max_floats) {
+    const size_t per_img = wino_workspace_floats(a, 1);
+    size_t n = max_floats / (per_img ? per_img : 1);
+    if (n < 1) n = 1;
+    return (int)(n < (size_t)a.nimg ? n : (size_t)a.nimg);
+}
+
+void wino_conv3x3(const WinoArgs& a, float* ws, int chunk_images, hipStream_t s) {
+    const int Ctot = a.c0 + a.c1;
+    const int th = (a.Ho + 1) / 2, tw = (a.Wo + 1) / 2;
+    for (int lo = 0; lo < a.nimg; lo += chunk_images) {
+        const int n = a.nimg - lo < chunk_images ? a.nimg - lo : chunk_images;
+        const size_t T = (size_t)n * th * tw;
+        float* V = ws;
+        float* Mb = ws + 16 * T * Ctot;
+        {
+            const size_t total = T * (Ctot / 4);
+            ProfScope ps(a.gn_scsh ? "wino_in_gn_silu" : "wino_in", 32.0 * T * Ctot, 4.0 * (4.0 * T * Ctot + 16.0 * T * Ctot), s);
+            const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+            hipLaunchKernelGGL(wino_in_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, V);
+        }
+        IgemmArgs g;
+        g.a0 = V; g.c0 = Ctot; g.lda0 = Ctot; g.w = a.U; g.ldw = Ctot; g.ldw16 = Ctot;
+        g.out = Mb; g.ldc = a.N; g.M = (int)T; g.N = a.N; g.taps = 1;
+        g.batch = 16; g.sa0 = (long long)T * Ctot; g.sw = (long long)a.N * Ctot; g.sout = (long long)T * a.N;
+        igemm(g, s);
+        {
+            const size_t total = T * (a.N / 4);
+            ProfScope ps("wino_out", 24.0 * T * a.N, 4.0 * (16.0 * T * a.N + 4.0 * T * a.N * (a.resid ? 2 : 1)), s);
+            const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+            hipLaunchKernelGGL(wino_out_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, Mb);
+        }
+    }
+}
+
+}  // namespace e2v

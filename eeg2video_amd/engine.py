@@ -114,6 +114,12 @@ class Engine:
         code = {"fp32": _lib.E2V_F32, "f32": _lib.E2V_F32, "bf16": _lib.E2V_BF16}[dtype]
         self._check(self.lib.e2v_set_compute_dtype(self.ctx, code))
 
+    def set_conv_algo(self, algo: str) -> None:
+        """'auto' (default: Winograd F(2x2,3x3) for the wide stride-1 3x3 convs, direct implicit GEMM elsewhere),
+        'direct' or 'winograd'.  For the graph entry points call it before the weights are finalized."""
+        code = {"auto": 0, "direct": 1, "winograd": 2}[algo]
+        self._check(self.lib.e2v_set_conv_algo(self.ctx, code))
+
     def device_bytes(self) -> int:
         return int(self.lib.e2v_device_bytes(self.ctx))
 

@@ -241,3 +241,26 @@ def test_bf16_compute_mode_unet_and_generate(tiny):
     finally:
         eng.set_compute_dtype("fp32")
     assert torch.equal(pipe.unet(x.cuda(), 301, cond.cuda()).sample, y32)     # back to the parity configuration
+
+
+@pytest.mark.parametrize("algo", ["1", "2"])
+def test_conv_algorithms_forced_unet_and_vae_vs_oracle(algo, monkeypatch):
+    """E2V_CONV_ALGO=1: every 3x3 conv through the direct implicit GEMM; =2: every stride-1 3x3 conv in Winograd
+    F(2x2,3x3) form with the resnets' GroupNorm + SiLU fused into its input transform.  (The default, auto, mixes the
+    two by channel count and is what every other test of this file runs.)  Same oracle, same tolerance."""
+    from eeg2video_amd.pipeline import build_pipeline
+    from oracle import unet3d_forward, vae_decode
+    monkeypatch.setenv("E2V_CONV_ALGO", algo)
+    usd = synth_state_dict(unet_param_spec(TINY_UNET), seed=42, mode="perturbed")
+    vsd = synth_state_dict(vae_param_spec(TINY_VAE), seed=43, mode="perturbed")
+    pipe = build_pipeline(TINY_UNET, TINY_VAE, device=0, unet_sd=usd, vae_sd=vsd)
+    shape = (2, 4, 3, 9, 12)
+    x = _t(counter_normal(5, "x", shape))
+    cond = _t(counter_normal(6, "c", (shape[0], 11, TINY_UNET.cross_attention_dim)))
+    ref = unet3d_forward({k: _t(v) for k, v in usd.items()}, TINY_UNET, x, 301, cond)
+    y = pipe.unet(x.cuda(), 301, cond.cuda(), return_dict=False)[0]
+    assert rel_err(y, ref) < 1e-4
+    z = _t(counter_normal(11, "z", (2, 4, 4, 6)))
+    refv = vae_decode({k: _t(v) for k, v in vsd.items()}, TINY_VAE, z)
+    yv = pipe.vae.decode(z.cuda()).sample
+    assert rel_err(yv, refv) < 1e-4

@@ -86,6 +86,55 @@ def test_conv3x3_concat_rowbias_residual(eng):
     close(from_cl(y, n, h, w), ref)
 
 
+@pytest.fixture
+def wino(eng):
+    """Force the Winograd F(2x2,3x3) form for every stride-1 3x3 conv of the test, then restore the default."""
+    eng.set_conv_algo("winograd")
+    yield eng
+    eng.set_conv_algo("auto")
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", [(32, 64, 2, 5, 8), (4, 64, 3, 9, 12), (64, 4, 2, 7, 5), (256, 256, 2, 18, 32),
+                                            (1280, 640, 1, 9, 16), (64, 32, 2, 1, 1), (32, 32, 1, 2, 3)])
+def test_conv3x3_winograd(wino, cin, cout, n, h, w):
+    """Winograd F(2x2,3x3) (wino.hip): same fp32 result as F.conv2d to the tolerance of the direct kernel; odd maps
+    exercise the ragged last tile row / column."""
+    x, wt, b = rnd(n, cin, h, w, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.1), rnd(cout, seed=3)
+    ref = F.conv2d(x, wt, b, padding=1)
+    y = wino.op_conv3x3(to_cl(x).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=h, Ws=w)
+    close(from_cl(y, n, h, w), ref)
+
+
+@pytest.mark.parametrize("hs,ws,hi,wi", [(5, 8, 9, 16), (5, 8, 10, 16), (3, 3, 5, 6), (2, 2, 3, 3), (5, 6, 12, 7)])
+def test_conv3x3_winograd_fused_nearest_resize(wino, hs, ws, hi, wi):
+    n, c = 3, 32
+    x, wt, b = rnd(n, c, hs, ws, seed=8), rnd(64, c, 3, 3, seed=9, scale=0.1), rnd(64, seed=10)
+    ref = F.conv2d(F.interpolate(x, size=(hi, wi), mode="nearest"), wt, b, padding=1)
+    y = wino.op_conv3x3(to_cl(x).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=hs, Ws=ws, Hi=hi, Wi=wi)
+    close(from_cl(y, n, hi, wi), ref)
+
+
+def test_conv3x3_winograd_concat_rowbias_residual_and_chunking(wino, monkeypatch):
+    n_s, f, c0, c1, cout, h, w = 2, 3, 64, 32, 64, 5, 6
+    n = n_s * f
+    a, s = rnd(n, c0, h, w, seed=11), rnd(n, c1, h, w, seed=12)
+    wt, b = rnd(cout, c0 + c1, 3, 3, seed=13, scale=0.1), rnd(cout, seed=14)
+    temb, res = rnd(n_s, cout, seed=15), rnd(n, cout, h, w, seed=16)
+    ref = F.conv2d(torch.cat([a, s], 1), wt, b, padding=1) + temb.repeat_interleave(f, 0)[:, :, None, None] + res
+    y = wino.op_conv3x3(to_cl(a).cuda(), wt.cuda(), b.cuda(), x1=to_cl(s).cuda(), n_img=n, Hs=h, Ws=w,
+                        rowbias=temb.cuda().contiguous(), rows_per_sample=f * h * w, resid=to_cl(res).cuda())
+    close(from_cl(y, n, h, w), ref)
+
+
+def test_conv3x3_stride2_ignores_winograd(wino):
+    """stride 2 has no F(2x2,3x3) form: the forced setting falls back to the direct kernel."""
+    n, c, h, w = 2, 32, 9, 12
+    x, wt, b = rnd(n, c, h, w, seed=4), rnd(64, c, 3, 3, seed=5, scale=0.1), rnd(64, seed=6)
+    ref = F.conv2d(x, wt, b, stride=2, padding=1)
+    y = wino.op_conv3x3(to_cl(x).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=h, Ws=w, stride=2)
+    close(from_cl(y, n, ref.shape[2], ref.shape[3]), ref)
+
+
 @pytest.mark.parametrize("m,k,n", [(240, 1280, 1280), (77, 64, 128), (1000, 320, 960), (130, 40, 72), (5, 320, 1280)])
 def test_linear(eng, m, k, n):
     x, w, b, r = rnd(m, k, seed=20), rnd(n, k, seed=21, scale=0.05), rnd(n, seed=22), rnd(m, n, seed=23)
