@@ -226,8 +226,8 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[set][mi]),
-                                                                          __builtin_bit_cast(bf16x8, bf[set][ni]),
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[set][ni]),
+                                                                          __builtin_bit_cast(bf16x8, af[set][mi]),
                                                                           acc[mi][ni], 0, 0, 0);
         } else {
 #pragma unroll
@@ -236,7 +236,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi][s], bf[set][ni][s], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[set][ni][s], af[set][mi][s], acc[mi][ni], 0, 0, 0);
         }
     };
     static_assert(BK == 32 && NBUF == 2, "the k-step below is written for two LDS buffers and four fragment groups of 32 bytes per row");
@@ -268,47 +268,72 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
     }
     if (ks < nk) kstep(std::integral_constant<int, 0>{});
 
-    // epilogue: C/D layout of the 32x32 MFMA -- column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    const int col = lane & 31;
-    const int rquad = (lane >> 5) * 4;
+    // epilogue.  The MFMAs ran with the WEIGHT fragment as their A operand, so in each 32x32 result a lane holds pixel
+    // m = lane & 31 and output channels n = 8 g + 4 (lane >> 5) + e in register r = 4 g + e: four consecutive channels
+    // per register quad, i.e. 16-byte bias / time-embedding / residual loads and 16-byte stores (a short-K layer --
+    // every Winograd-domain GEMM, every attention projection -- spends a tenth of its time here).
+    const int mrow = lane & 31;
+    const int nq = (lane >> 5) * 4;
     if (p.geglu) {
         if constexpr (TN == 2) {
-            const int nv = n0 + wn * WN + col;
-            if (nv + 32 < p.N) {
-                const float bv = p.bias ? p.bias[nv] : 0.f;
-                const float bg = p.bias ? p.bias[nv + 32] : 0.f;
-                const int no = (n0 + wn * WN) / 2 + col;
+            const int nb = n0 + wn * WN;                           // value columns nb .. nb+31, gate columns nb+32 .. nb+63
+            if (nb + 64 <= p.N) {
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int m = bm * BM + wm * WM + mi * 32 + mrow;
+                    if (m >= p.M) continue;
+                    float* orow = out + (size_t)m * p.ldc + nb / 2 + nq;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = bm * BM + wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + rquad;
-                        if (m < p.M) {
-                            const float v = acc[mi][0][r] * p.alpha + bv;
-                            const float g = acc[mi][1][r] * p.alpha + bg;
-                            out[(size_t)m * p.ldc + no] = v * gelu_erf(g);
-                        }
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * g + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        const f32x4 bg = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + 32 + 8 * g + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        f32x4 y;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_erf(acc[mi][1][4 * g + e] * p.alpha + bg[e]);
+                        *reinterpret_cast<f32x4*>(orow + 8 * g) = y;
                     }
+                }
             }
         }
         return;
     }
+    const bool vec = ((p.N | p.ldc | p.ldr | p.rb_ld) & 3) == 0;   // strides of absent operands are 0
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-        const int n = n0 + wn * WN + ni * 32 + col;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = bm * BM + wm * WM + mi * 32 + mrow;
+        if (m >= p.M) continue;
+        const float* rbp = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.rb_ld : nullptr;
+        const float* rsp = p.resid ? p.resid + (size_t)m * p.ldr : nullptr;
+        float* orow = out + (size_t)m * p.ldc;
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+        for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = bm * BM + wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + rquad;
-                if (m < p.M) {
-                    float v = acc[mi][ni][r] * p.alpha + bv;
-                    if (p.rowbias) v += p.rowbias[(size_t)(m / p.rows_per_sample) * p.rb_ld + n];
-                    if (p.resid) v += p.resid[(size_t)m * p.ldr + n];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    out[(size_t)m * p.ldc + n] = v;
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * WN + ni * 32 + 8 * g + nq;
+                if (n >= p.N) continue;
+                if (vec) {
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = acc[mi][ni][4 * g + e] * p.alpha;
+                    if (p.bias) y += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (rbp) y += *reinterpret_cast<const f32x4*>(rbp + n);
+                    if (rsp) y += *reinterpret_cast<const f32x4*>(rsp + n);
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(orow + n) = y;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= p.N) break;
+                        float v = acc[mi][ni][4 * g + e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
+                        if (rbp) v += rbp[n + e];
+                        if (rsp) v += rsp[n + e];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        orow[n + e] = v;
+                    }
                 }
             }
     }
