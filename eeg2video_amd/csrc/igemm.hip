@@ -32,7 +32,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //             144 bytes in both modes and a lane's fragment is the same 16 bytes (4 fp32 / 8 bf16), so the fragment
 //             reads, the schedule and the epilogue are shared.
 template <int BM, int BN, int WGM, int WGN, int ABL, int NBUF, bool BF = false>
-__device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, const int n0, float* smem) {
+__device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int rbg, const int n0, float* smem) {
+    // rbg counts row blocks over all batch entries (batch-major): entry z, row block bm within it
+    const int z = p.batch > 1 ? rbg / p.nbm_per : 0;
+    const int bm = rbg - z * p.nbm_per;
     constexpr int BKE = BF ? 64 : 32;               // k elements per stage
     constexpr int KH = BF ? 2 : 1;                  // 32-float pieces of an A row per stage
     constexpr int ESZ = BF ? 2 : 4;                 // bytes per weight element
@@ -49,11 +52,11 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int bm, con
     const int wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
-    const float* __restrict__ a0 = p.a0 + (size_t)blockIdx.z * p.sa0;
+    const float* __restrict__ a0 = p.a0 + (size_t)z * p.sa0;
     const float* __restrict__ a1 = p.a1;
-    const char* __restrict__ w = BF ? reinterpret_cast<const char*>(p.w16) + (size_t)blockIdx.z * p.sw * 2
-                                    : reinterpret_cast<const char*>(p.w + (size_t)blockIdx.z * p.sw);
-    float* __restrict__ out = p.out + (size_t)blockIdx.z * p.sout;
+    const char* __restrict__ w = BF ? reinterpret_cast<const char*>(p.w16) + (size_t)z * p.sw * 2
+                                    : reinterpret_cast<const char*>(p.w + (size_t)z * p.sw);
+    float* __restrict__ out = p.out + (size_t)z * p.sout;
 
     // K order: source (the two halves of a channel concat) > 32/64-channel chunk > tap.  The 9 taps of one channel chunk
     // run back to back, so the (shifted) re-reads of the same input rows hit L1 / L2 instead of going back out to the
@@ -371,17 +374,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
 }
 
-// dedicated single-shape kernels (E2V_IGEMM_SCHED=2: A/B reference for the mixed kernel)
-template <int BN>
-__global__ __launch_bounds__(256) void igemm_kernel_single(const IgemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int nbn = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    igemm_tile<128, BN, 2, 2, 0, 2>(p, tile / nbn, (tile % nbn) * BN, smem);
-}
-
 template <int ABL, bool BF = false>
 static void launch_igemm(const IgemmArgs& a, int ntiles, const char* cls, hipStream_t s) {
     static bool configured = false;
@@ -391,7 +383,7 @@ static void launch_igemm(const IgemmArgs& a, int ntiles, const char* cls, hipStr
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         configured = true;
     }
-    dim3 grid(ntiles, 1, a.batch);
+    dim3 grid(ntiles, 1, 1);
     const double K = (double)a.taps * (a.c0 + a.c1);
     const double rows_in = a.taps == 1 ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
     std::string pname = cls;
@@ -428,8 +420,9 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
     }
     // ---- tile schedule ----------------------------------------------------------------------------------
     static const int abl = [] { const char* e = std::getenv("E2V_IGEMM_ABLATE"); return e ? std::atoi(e) : 0; }();
-    static const int sched = [] { const char* e = std::getenv("E2V_IGEMM_SCHED"); return e ? std::atoi(e) : 1; }();
-    const int nbm = (a.M + 127) / 128;
+    static const int sched = [] { const char* e = std::getenv("E2V_IGEMM_SCHED"); return e ? std::atoi(e) : 1; }();   // 0: no half-size tails
+    a.nbm_per = (a.M + 127) / 128;
+    const int nbm = a.nbm_per * a.batch;                     // batch entries are just more row blocks (dealt to the XCDs together)
     const int slots = 512;                                   // 2 workgroups per CU x 256 CUs
     a.s2 = (a.N + 63) / 64;
     a.w1 = a.N / 128;                                        // full 128-wide column tiles
@@ -450,11 +443,11 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
         // chunk is at most half a round, run it as half-size tiles (it then takes about half a round's time).
         const double per_rb = a.w1 + 0.5 * a.s1;             // cost of one row block in 128x128 units
         const int nrb = (nbm + 7) / 8;                       // row blocks of the largest chunk
-        const double units = per_rb * nrb * a.batch;
+        const double units = per_rb * nrb;
         const int xslots = slots / 8;
         if (units * 8 < slots) {
             a.rb1 = 0;                                       // less than one round: half-size tiles spread over more CUs
-        } else if (a.batch == 1) {
+        } else {
             const int full = (int)std::floor(units / xslots);
             const int wide_rb = (int)std::floor(full * xslots / per_rb);
             const int tail = nrb - wide_rb;
@@ -472,21 +465,6 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
         ntiles = t > ntiles ? t : ntiles;
     }
     ntiles *= 8;
-    if (sched == 2 && !a.geglu && abl == 0 && !use_bf16) {               // A/B reference: one tile shape per launch
-        const long n128 = (a.N + 127) / 128 * 128;
-        const bool narrow = (double)(n128 - a.N) > 0.12 * (double)n128;
-        static bool cfgd = false;
-        if (!cfgd) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel_single<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 78336);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel_single<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 78336);
-            cfgd = true;
-        }
-        const int nb = nbm * (narrow ? (a.N + 63) / 64 : (a.N + 127) / 128);
-        ProfScope ps(narrow ? "igemm_f32_128x64" : "igemm_f32_128x128", 2.0 * a.M * a.N * (double)a.taps * (a.c0 + a.c1) * a.batch, 0.0, s);
-        if (narrow) hipLaunchKernelGGL((igemm_kernel_single<64>), dim3(nb, 1, a.batch), dim3(256), 78336, s, a);
-        else hipLaunchKernelGGL((igemm_kernel_single<128>), dim3(nb, 1, a.batch), dim3(256), 78336, s, a);
-        return;
-    }
     if (use_bf16 && abl == 0) { launch_igemm<0, true>(a, ntiles, cls, s); return; }
     if (abl == 1) launch_igemm<1>(a, ntiles, cls, s);
     else if (abl == 2) launch_igemm<2>(a, ntiles, cls, s);
