@@ -112,6 +112,9 @@ e2v_status e2v_create(const e2v_config* cfg, int device, e2v_ctx** out) {
         make_alphas(c);
         if (const char* e = std::getenv("E2V_CONV_ALGO")) c->conv_algo = std::atoi(e);
         if (const char* e = std::getenv("E2V_WINO_MIN_C")) c->wino_min_c = std::atoi(e);
+        if (const char* e = std::getenv("E2V_WINO_F4")) c->wino_f4 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("E2V_WINO_F4_PAD")) c->wino_f4_pad = std::atof(e);
+        if (const char* e = std::getenv("E2V_WINO_F4_MIN_C")) c->wino4_min_c = std::atoi(e);
         if (const char* e = std::getenv("E2V_WINO_WS_MB")) c->wino_ws_floats = (size_t)std::atol(e) * (1u << 18);
     });
     if (st != E2V_OK) { delete c; return st; }
@@ -287,7 +290,7 @@ e2v_status e2v_set_compute_dtype(e2v_ctx* c, int dtype) {
 }
 
 e2v_status e2v_set_conv_algo(e2v_ctx* c, int algo) {
-    if (!c || algo < E2V_CONV_AUTO || algo > E2V_CONV_WINOGRAD) return E2V_EINVAL;
+    if (!c || algo < E2V_CONV_AUTO || algo > E2V_CONV_WINOGRAD4) return E2V_EINVAL;
     c->conv_algo = algo;
     return E2V_OK;
 }
@@ -449,11 +452,20 @@ e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, 
         const int cin = c0 + c1;
         E2V_REQUIRE(c1 == 0 || c0 % 32 == 0, E2V_ESHAPE, "conv: the concat seam must be a multiple of 32 channels");
         const bool wino_shape = stride == 1 && pad_lo == 1 && Hi == Ho && Wi == Wo && cout % 4 == 0 && !c->bf16_compute;
-        if (wino_shape && (c->conv_algo == E2V_CONV_WINOGRAD ||
-                           (c->conv_algo == E2V_CONV_AUTO && std::min(cin, cout) >= c->wino_min_c))) {
-            Act u(c->pool, (int64_t)16 * cout, cin);
-            wino_pack_weights(w_oihw, u.p, cout, cin, s);
+        int wm = 0;                                            // same policy as the graph runner (model.cpp: Runner::winograd)
+        if (wino_shape && c->conv_algo == E2V_CONV_WINOGRAD) wm = 2;
+        if (wino_shape && c->conv_algo == E2V_CONV_WINOGRAD4) wm = 4;
+        if (wino_shape && c->conv_algo == E2V_CONV_AUTO) {
+            const int cmin = std::min(cin, cout);
+            const double padded = (double)((Ho + 3) / 4 * 4) * ((Wo + 3) / 4 * 4);
+            if (c->wino_f4 && cmin >= c->wino4_min_c && padded <= c->wino_f4_pad * Ho * Wo) wm = 4;
+            else if (cmin >= c->wino_min_c) wm = 2;
+        }
+        if (wm) {
+            Act u(c->pool, (int64_t)(wm + 2) * (wm + 2) * cout, cin);
+            wino_pack_weights(w_oihw, u.p, cout, cin, wm, s);
             WinoArgs a;
+            a.m = wm;
             a.x0 = x0; a.c0 = c0; a.ld0 = c0; a.x1 = x1; a.c1 = c1; a.ld1 = c1;
             a.nimg = n_img; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo;
             if (Hi != Hs || Wi != Ws) { a.upsample = 1; a.ups_h = (float)Hs / (float)Hi; a.ups_w = (float)Ws / (float)Wi; }

@@ -63,14 +63,15 @@ struct WinoArgs {
     int Ho = 1, Wo = 1;                                        // output map (= source map, or 2x with upsample)
     int upsample = 0; float ups_h = 1.f, ups_w = 1.f;
     const float* gn_scsh = nullptr; int gn_P = 1; int gn_silu = 0;   // fused GroupNorm affine (+ SiLU) on the way in
-    const float* U = nullptr;                                  // [16][N][c0+c1] (wino_pack_weights)
+    int m = 2;                                                 // output tile: 2 = F(2x2,3x3), 4 = F(4x4,3x3)
+    const float* U = nullptr;                                  // [(m+2)^2][N][c0+c1] (wino_pack_weights)
     int N = 0;
     float* out = nullptr; int ldc = 0;
     const float* bias = nullptr;
     const float* rowbias = nullptr; int rb_ld = 0; int rows_per_sample = 1;
     const float* resid = nullptr; int ldr = 0;
 };
-void wino_pack_weights(const float* w_oihw, float* U, int cout, int cin, hipStream_t s);
+void wino_pack_weights(const float* w_oihw, float* U, int cout, int cin, int m, hipStream_t s);
 size_t wino_workspace_floats(const WinoArgs& a, int nimg);       // V + M for `nimg` images
 int wino_chunk_images(const WinoArgs& a, size_t max_floats);     // images per pass so that the workspace fits
 void wino_conv3x3(const WinoArgs& a, float* workspace, int chunk_images, hipStream_t s);

@@ -186,12 +186,21 @@ struct Packer {
         E2V_HIP(hipStreamSynchronize(s));
         (void)hipFree(tmp);
         const float* wino = nullptr;
-        if (stride1 && ci % 4 == 0 && co % 4 == 0 && c->conv_algo != 1 && (c->conv_algo == 2 || std::min(ci, co) >= c->wino_min_c)) {
-            float* u = c->dev_alloc((size_t)16 * co * ci);
-            wino_pack_weights(w.d, u, co, ci, s);
-            wino = u;
+        const float* wino4 = nullptr;
+        if (stride1 && ci % 4 == 0 && co % 4 == 0 && c->conv_algo != 1) {
+            const int cmin = std::min(ci, co);
+            if (c->conv_algo == 2 || (c->conv_algo == 0 && cmin >= c->wino_min_c)) {
+                float* u = c->dev_alloc((size_t)16 * co * ci);
+                wino_pack_weights(w.d, u, co, ci, 2, s);
+                wino = u;
+            }
+            if (c->conv_algo == 3 || (c->conv_algo == 0 && c->wino_f4 && cmin >= c->wino4_min_c)) {
+                float* u4 = c->dev_alloc((size_t)36 * co * ci);
+                wino_pack_weights(w.d, u4, co, ci, 4, s);
+                wino4 = u4;
+            }
         }
-        return ConvW{d, t(n + ".bias").d, ci, cp, co, d16, ld32, ld64, wino};
+        return ConvW{d, t(n + ".bias").d, ci, cp, co, d16, ld32, ld64, wino, wino4};
     }
     LinW fuse_rows(const std::vector<std::string>& names, bool bias) {   // stack Linear weights along `out`
         int in = 0, out = 0;
@@ -422,8 +431,15 @@ struct Runner {
 
     // does this conv run in Winograd form?  (fp32 arithmetic only: in bf16 the transforms would dominate and the
     // rounding of transformed inputs costs accuracy)
-    bool winograd(const ConvW& w, int stride, int pad, int Hi, int Wi, int Ho, int Wo) const {
-        return w.wino && c->conv_algo != 1 && !c->bf16_compute && stride == 1 && pad == 1 && Hi == Ho && Wi == Wo;
+    // returns the output tile size: 0 = direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3).  fp32 arithmetic only: in bf16 the
+    // transforms would dominate and rounding the transformed inputs costs accuracy.
+    int winograd(const ConvW& w, int stride, int pad, int Hi, int Wi, int Ho, int Wo) const {
+        if (c->conv_algo == 1 || c->bf16_compute || stride != 1 || pad != 1 || Hi != Ho || Wi != Wo) return 0;
+        if (c->conv_algo == 2) return w.wino ? 2 : 0;
+        if (c->conv_algo == 3) return w.wino4 ? 4 : 0;
+        const double padded = (double)((Ho + 3) / 4 * 4) * ((Wo + 3) / 4 * 4);
+        if (w.wino4 && padded <= c->wino_f4_pad * Ho * Wo) return 4;
+        return w.wino ? 2 : 0;
     }
 
     Act ln(const NormW& w, const Act& x) {
@@ -456,8 +472,9 @@ struct Runner {
               int gn_P = 0) {
         E2V_REQUIRE(c0 + c1 == w.cin_pad, E2V_ESHAPE, "conv: input channels do not match the weight");
         Act out(pool(), (int64_t)geo.nimg * Ho * Wo, w.cout);
-        if (winograd(w, stride, pad, Hi, Wi, Ho, Wo)) {
+        if (const int wm = winograd(w, stride, pad, Hi, Wi, Ho, Wo)) {
             WinoArgs a;
+            a.m = wm;
             a.x0 = x0; a.c0 = c0; a.ld0 = c0; a.x1 = x1; a.c1 = c1; a.ld1 = c1;
             a.nimg = geo.nimg; a.Hs = geo.H; a.Ws = geo.W; a.Ho = Ho; a.Wo = Wo;
             if (Hi != geo.H || Wi != geo.W) {
@@ -466,7 +483,7 @@ struct Runner {
                 a.ups_w = (float)geo.W / (float)Wi;
             }
             if (gn_P > 0) { a.gn_scsh = c->gn_scale; a.gn_P = gn_P; a.gn_silu = 1; }
-            a.U = w.wino; a.N = w.cout; a.out = out.p; a.ldc = w.cout; a.bias = w.b;
+            a.U = wm == 4 ? w.wino4 : w.wino; a.N = w.cout; a.out = out.p; a.ldc = w.cout; a.bias = w.b;
             a.rowbias = rowbias; a.rb_ld = w.cout; a.rows_per_sample = rows_per_sample; a.resid = resid; a.ldr = w.cout;
             const int chunk = wino_chunk_images(a, c->wino_ws_floats);
             const size_t need = wino_workspace_floats(a, chunk);

@@ -15,7 +15,8 @@ namespace e2v {
 struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
 struct LinW { const float* w = nullptr; const float* b = nullptr; int in = 0, out = 0; const void* w16 = nullptr; };
 struct ConvW { const float* w = nullptr; const float* b = nullptr; int cin = 0, cin_pad = 0, cout = 0; const void* w16 = nullptr; int ldw = 0, ldw16 = 0;
-               const float* wino = nullptr; };   // [16][cout][cin] Winograd-domain weights (stride-1 convs wide enough to profit)
+               const float* wino = nullptr;      // [16][cout][cin] Winograd F(2x2,3x3)-domain weights (stride-1 convs wide enough to profit)
+               const float* wino4 = nullptr; };  // [36][cout][cin] F(4x4,3x3)-domain weights (only when that form is enabled)
 
 struct ResW {
     NormW n1, n2;
@@ -83,8 +84,11 @@ struct e2v_ctx {
     e2v::UNetW unet;
     e2v::VAEW vae;
     bool unet_ready = false, vae_ready = false, sem_ready = false;
-    int conv_algo = 0;                                           // e2v_set_conv_algo: 0 auto, 1 direct, 2 Winograd wherever it applies
-    int wino_min_c = 256;                                        // auto: Winograd when min(Cin, Cout) >= this (E2V_WINO_MIN_C)
+    int conv_algo = 0;                                           // e2v_set_conv_algo: 0 auto, 1 direct, 2 / 3 Winograd F(2x2) / F(4x4) wherever it applies
+    bool wino_f4 = true;                                         // auto: F(4x4,3x3) where min(Cin, Cout) >= wino4_min_c and the map, padded to
+    int wino4_min_c = 128;                                       //   multiples of 4, grows by <= wino_f4_pad (E2V_WINO_F4 / _F4_MIN_C / _F4_PAD)
+    double wino_f4_pad = 1.7;
+    int wino_min_c = 256;                                        // auto: F(2x2,3x3) when min(Cin, Cout) >= this (E2V_WINO_MIN_C)
     size_t wino_ws_floats = (size_t)1 << 30;                     // workspace cap per pass (E2V_WINO_WS_MB)
     bool bf16_compute = false;                                   // e2v_set_compute_dtype: bf16 MFMA for convs / linears
     std::vector<e2v::LinW> sem;                                  // semantic predictor layers (first one K-padded to 4)

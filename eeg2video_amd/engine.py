@@ -117,7 +117,7 @@ class Engine:
     def set_conv_algo(self, algo: str) -> None:
         """'auto' (default: Winograd F(2x2,3x3) for the wide stride-1 3x3 convs, direct implicit GEMM elsewhere),
         'direct' or 'winograd'.  For the graph entry points call it before the weights are finalized."""
-        code = {"auto": 0, "direct": 1, "winograd": 2}[algo]
+        code = {"auto": 0, "direct": 1, "winograd": 2, "winograd4": 3}[algo]
         self._check(self.lib.e2v_set_conv_algo(self.ctx, code))
 
     def device_bytes(self) -> int:

@@ -176,12 +176,15 @@ int64_t e2v_profile_end(e2v_ctx* ctx, char* json, int64_t cap);
  * activations in HBM, fp32 GroupNorm / LayerNorm / softmax).  Takes effect for the following calls. */
 e2v_status e2v_set_compute_dtype(e2v_ctx* ctx, int dtype);
 
-/* Algorithm of the stride-1 3x3 convolutions in fp32 arithmetic: E2V_CONV_AUTO (default) runs Winograd F(2x2,3x3) --
- * 2.25x fewer matrix-core flops, same fp32 result to ~1e-6 relative -- where min(Cin, Cout) >= 256 and the direct
- * implicit GEMM elsewhere; E2V_CONV_DIRECT / E2V_CONV_WINOGRAD force one form wherever it applies.  The Winograd-domain
- * weights are made by e2v_finalize_weights, so for the graph entry points call this BEFORE finalizing; the kernel-level
- * e2v_op_conv3x3 follows it immediately.  (The reference leaves this choice to cuDNN: F.conv2d, resnet.py:24-31.) */
-enum { E2V_CONV_AUTO = 0, E2V_CONV_DIRECT = 1, E2V_CONV_WINOGRAD = 2 };
+/* Algorithm of the stride-1 3x3 convolutions in fp32 arithmetic.  E2V_CONV_AUTO (default): Winograd F(4x4,3x3) -- 4x
+ * fewer matrix-core flops than the direct implicit GEMM -- where min(Cin, Cout) >= 128 and the map padded to multiples of
+ * 4 grows by at most 1.7x, else F(2x2,3x3) (2.25x fewer) where min(Cin, Cout) >= 256, else direct.  Measured deviation
+ * of a full 50-step B = 8 generate from the all-direct result: frames 1.4e-5 (F(2x2) only: 5.8e-6), against the 1e-3
+ * parity tolerance.  E2V_CONV_DIRECT / E2V_CONV_WINOGRAD / E2V_CONV_WINOGRAD4 force one form wherever it applies.
+ * The Winograd-domain weights are made by e2v_finalize_weights, so for the graph entry points call this BEFORE finalizing;
+ * the kernel-level e2v_op_conv3x3 follows it immediately.  (The reference leaves this choice to cuDNN: F.conv2d,
+ * resnet.py:24-31.) */
+enum { E2V_CONV_AUTO = 0, E2V_CONV_DIRECT = 1, E2V_CONV_WINOGRAD = 2, E2V_CONV_WINOGRAD4 = 3 };
 e2v_status e2v_set_conv_algo(e2v_ctx* ctx, int algo);
 
 /* bytes of device memory currently held by the ctx (weights + cached workspace) */

@@ -243,11 +243,12 @@ def test_bf16_compute_mode_unet_and_generate(tiny):
     assert torch.equal(pipe.unet(x.cuda(), 301, cond.cuda()).sample, y32)     # back to the parity configuration
 
 
-@pytest.mark.parametrize("algo", ["1", "2"])
+@pytest.mark.parametrize("algo", ["1", "2", "3"])
 def test_conv_algorithms_forced_unet_and_vae_vs_oracle(algo, monkeypatch):
     """E2V_CONV_ALGO=1: every 3x3 conv through the direct implicit GEMM; =2: every stride-1 3x3 conv in Winograd
-    F(2x2,3x3) form with the resnets' GroupNorm + SiLU fused into its input transform.  (The default, auto, mixes the
-    two by channel count and is what every other test of this file runs.)  Same oracle, same tolerance."""
+    F(2x2,3x3) form with the resnets' GroupNorm + SiLU fused into its input transform; =3: the same in F(4x4,3x3) form.
+    (The default, auto, picks per layer by channel count and map size and is what every other test of this file runs.)
+    Same oracle, same tolerance."""
     from eeg2video_amd.pipeline import build_pipeline
     from oracle import unet3d_forward, vae_decode
     monkeypatch.setenv("E2V_CONV_ALGO", algo)

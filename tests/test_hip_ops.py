@@ -126,6 +126,22 @@ def test_conv3x3_winograd_concat_rowbias_residual_and_chunking(wino, monkeypatch
     close(from_cl(y, n, h, w), ref)
 
 
+@pytest.mark.parametrize("cin,cout,n,h,w", [(32, 64, 2, 5, 8), (64, 4, 2, 7, 5), (256, 256, 2, 18, 32), (640, 320, 1, 36, 64),
+                                            (64, 32, 2, 1, 1), (32, 32, 1, 4, 4)])
+def test_conv3x3_winograd_f4(eng, cin, cout, n, h, w):
+    """Opt-in F(4x4,3x3): transform constants up to 8 cost ~17x the direct sum's rounding error -- 1e-4 of the output
+    scale here (measured 5e-6 on a 640-channel conv), which is why it is not the default."""
+    eng.set_conv_algo("winograd4")
+    try:
+        x, wt, b = rnd(n, cin, h, w, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.1), rnd(cout, seed=3)
+        res = rnd(n, cout, h, w, seed=4)
+        ref = F.conv2d(x, wt, b, padding=1) + res
+        y = eng.op_conv3x3(to_cl(x).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=h, Ws=w, resid=to_cl(res).cuda())
+        close(from_cl(y, n, h, w), ref, rtol=1e-4, atol=1e-4)
+    finally:
+        eng.set_conv_algo("auto")
+
+
 def test_conv3x3_stride2_ignores_winograd(wino):
     """stride 2 has no F(2x2,3x3) form: the forced setting falls back to the direct kernel."""
     n, c, h, w = 2, 32, 9, 12
