@@ -17,11 +17,18 @@
 #include "kernels.h"
 #include "prof.h"
 
+#include <string>
+
 namespace e2v {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float wino_silu(float v) { return v / (1.0f + expf(-v)); }
+// x * sigmoid(x) on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each).  The input transforms evaluate it
+// up to 2.25x per element (once per tile that touches the pixel), so the IEEE expf + division of norm.hip's
+// gn_apply_kernel would make these HBM-bound kernels ALU-bound; the two forms differ by ~1e-7 relative.
+__device__ __forceinline__ float wino_silu(float v) {
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+}
 
 // one thread = one tile x four channels; consecutive threads = consecutive channel quads (16-byte lanes, coalesced)
 __global__ __launch_bounds__(256) void wino_in_kernel(const WinoArgs p, int img_lo, int nimg, float* __restrict__ V) {
@@ -360,7 +367,10 @@ void wino_conv3x3(const WinoArgs& a, float* ws, int chunk_images, hipStream_t s)
         {
             const size_t total = T * (Ctot / 4);
             const double px = (double)a.m * a.m;                  // output pixels per tile
-            ProfScope ps(a.gn_scsh ? "wino_in_gn_silu" : "wino_in", 2.0 * P * T * Ctot, 4.0 * ((px + P) * T * Ctot), s);
+            std::string nm = a.gn_scsh ? "wino_in_gn_silu" : "wino_in";
+            if (profiler().on && profiler().detail)
+                nm += " T" + std::to_string(T) + " C" + std::to_string(Ctot) + " m" + std::to_string(a.m) + (a.c1 ? " cat" : "") + (a.upsample ? " up" : "");
+            ProfScope ps(nm.c_str(), 2.0 * P * T * Ctot, 4.0 * ((px + P) * T * Ctot), s);
             const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
             if (a.m == 4) hipLaunchKernelGGL(wino4_in_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, V);
             else hipLaunchKernelGGL(wino_in_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, V);
@@ -373,7 +383,10 @@ void wino_conv3x3(const WinoArgs& a, float* ws, int chunk_images, hipStream_t s)
         {
             const size_t total = T * (a.N / 4);
             const double px = (double)a.m * a.m;
-            ProfScope ps("wino_out", 1.5 * P * T * a.N, 4.0 * (P * T * a.N + px * T * a.N * (a.resid ? 2 : 1)), s);
+            std::string nm = "wino_out";
+            if (profiler().on && profiler().detail)
+                nm += " T" + std::to_string(T) + " N" + std::to_string(a.N) + " m" + std::to_string(a.m) + (a.resid ? " res" : "") + (a.rowbias ? " temb" : "");
+            ProfScope ps(nm.c_str(), 1.5 * P * T * a.N, 4.0 * (P * T * a.N + px * T * a.N * (a.resid ? 2 : 1)), s);
             const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
             if (a.m == 4) hipLaunchKernelGGL(wino4_out_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, Mb);
             else hipLaunchKernelGGL(wino_out_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, Mb);
