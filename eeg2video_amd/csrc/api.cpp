@@ -439,6 +439,62 @@ e2v_status e2v_generate(e2v_ctx* c, const float* latents, const float* cond, con
     });
 }
 
+// ---- DDIM inversion (EEG2Video_New/Generation/tuneavideo/util.py:56-101) --------------------------
+// next_step: "timestep" = t - T/n (alpha of the step being left; < 0 -> final_alpha_cumprod), "next_timestep" = t.
+static void ddim_next_coeffs(const e2v_ctx* c, int64_t t, int steps, float co[4]) {
+    const int64_t T = c->cfg.num_train_timesteps;
+    E2V_REQUIRE(steps > 0 && steps <= T, E2V_EINVAL, "num_inference_steps out of range");
+    E2V_REQUIRE(t >= 0 && t < (int64_t)c->alphas.size(), E2V_EINVAL, "timestep out of range");
+    const int64_t cur = std::min<int64_t>(t - T / steps, 999);                     // util.py:58-59
+    const float a_t = cur >= 0 ? c->alphas[(size_t)cur] : c->alphas[0];           // :60 (set_alpha_to_one = False)
+    const float a_n = c->alphas[(size_t)t];                                        // :61
+    co[0] = std::sqrt(a_t);
+    co[1] = std::sqrt(1.0f - a_t);
+    co[2] = std::sqrt(a_n);
+    co[3] = std::sqrt(1.0f - a_n);
+}
+
+e2v_status e2v_ddim_next_step(e2v_ctx* c, const float* eps, const float* x, float* xo, int64_t count, int64_t t,
+                              int num_inference_steps, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(eps && x && xo && count >= 0, E2V_EINVAL, "null argument");
+        float co[4];
+        ddim_next_coeffs(c, t, num_inference_steps, co);
+        ddim_cfg_step(eps, nullptr, x, xo, count, 1.0f, co[0], co[1], co[2], co[3], S(stream));   // :63-65, same form as step()
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+e2v_status e2v_ddim_invert(e2v_ctx* c, const float* latents, const float* cond, int B, int F, int h, int w, int T,
+                           int num_inv_steps, float* all_latents, float* final_latent, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(latents && cond && (all_latents || final_latent), E2V_EINVAL, "null argument");
+        E2V_REQUIRE(B > 0 && F > 0 && h > 0 && w > 0 && T > 0, E2V_ESHAPE, "non-positive dimension");
+        E2V_REQUIRE(num_inv_steps > 0 && num_inv_steps <= c->cfg.num_train_timesteps, E2V_EINVAL, "num_inv_steps out of range");
+        hipStream_t s = S(stream);
+        const int Cl = c->cfg.in_channels;
+        const int P = F * h * w;
+        const size_t per = (size_t)B * P * Cl;
+        Act x(c->pool, (int64_t)B * P, Cl);
+        ncfhw_to_cl(latents, x.p, B, Cl, Cl, P, 1.0f, s);
+        if (all_latents) E2V_HIP(hipMemcpyAsync(all_latents, latents, per * sizeof(float), hipMemcpyDeviceToDevice, s));   // all_latent = [latent] (:86)
+        std::vector<int64_t> ts(num_inv_steps);
+        e2v_ddim_timesteps(c, num_inv_steps, ts.data());
+        for (int i = 0; i < num_inv_steps; ++i) {                                 // :88
+            const int64_t t = ts[num_inv_steps - 1 - i];                          // timesteps[len - i - 1] (:89): ascending
+            Act eps = c->unet_forward_cl(x.p, &t, 1, cond, B, F, h, w, T, s);     // get_noise_pred_single (:68-70), no guidance
+            float co[4];
+            ddim_next_coeffs(c, t, num_inv_steps, co);
+            ddim_cfg_step(eps.p, nullptr, x.p, x.p, (long long)per, 1.0f, co[0], co[1], co[2], co[3], s);   // next_step (:91)
+            if (all_latents) cl_to_ncfhw(x.p, Cl, all_latents + (size_t)(i + 1) * per, B, Cl, P, 1.f, 0.f, 0, 0.f, 0.f, s);
+        }
+        if (final_latent) cl_to_ncfhw(x.p, Cl, final_latent, B, Cl, P, 1.f, 0.f, 0, 0.f, 0.f, s);
+        E2V_HIP(hipGetLastError());
+    });
+}
+
 // ---------------------------------------------------------------------------------------------------
 // kernel-level entry points (eeg2video_hip_ops.h)
 // ---------------------------------------------------------------------------------------------------

@@ -173,6 +173,27 @@ class Engine:
                                                int(t_prev), _stream()))
         return out
 
+    def ddim_next_step(self, eps: torch.Tensor, t: int, x: torch.Tensor, num_inference_steps: int) -> torch.Tensor:
+        e, x = self._dev(eps, "eps"), self._dev(x, "sample")
+        out = torch.empty_like(x)
+        self._check(self.lib.e2v_ddim_next_step(self.ctx, e.data_ptr(), x.data_ptr(), out.data_ptr(), x.numel(), int(t),
+                                                int(num_inference_steps), _stream()))
+        return out
+
+    def ddim_invert(self, latents: torch.Tensor, cond: torch.Tensor, num_inv_steps: int, return_all: bool = True):
+        """DDIM inversion loop on the device (reference: tuneavideo/util.py ddim_loop); returns the list of n+1 latents
+        (return_all) or only the last one."""
+        x, cond = self._dev(latents, "latents"), self._dev(cond, "cond")
+        b, c, f, h, w = x.shape
+        if cond.shape[0] != b:
+            raise ValueError(f"cond batch {cond.shape[0]} != latent batch {b}")
+        allb = torch.empty((num_inv_steps + 1,) + tuple(x.shape), device=self.device, dtype=torch.float32) if return_all else None
+        last = torch.empty_like(x) if not return_all else None
+        self._check(self.lib.e2v_ddim_invert(self.ctx, x.data_ptr(), cond.data_ptr(), b, f, h, w, cond.shape[1],
+                                             int(num_inv_steps), allb.data_ptr() if return_all else None,
+                                             last.data_ptr() if last is not None else None, _stream()))
+        return list(allb.unbind(0)) if return_all else last
+
     def vae_decode(self, latents: torch.Tensor, postprocess: bool = True) -> torch.Tensor:
         z = self._dev(latents, "latents")
         if z.dim() == 4:

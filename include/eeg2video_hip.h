@@ -122,6 +122,20 @@ e2v_status e2v_ddim_cfg_step(e2v_ctx* ctx, const float* eps_uncond, const float*
                              float* x_out, int64_t count, float guidance_scale, int64_t t, int64_t t_prev,
                              e2v_stream stream);
 
+/* replaces: next_step (EEG2Video_New/Generation/tuneavideo/util.py:56-66), the deterministic DDIM update run towards
+ * noise: alpha_t = abar[min(t - T/n, 999)] (final alpha when negative), alpha_next = abar[t];
+ * x_next = sqrt(alpha_next) (x - sqrt(1-alpha_t) eps) / sqrt(alpha_t) + sqrt(1-alpha_next) eps. */
+e2v_status e2v_ddim_next_step(e2v_ctx* ctx, const float* eps, const float* x, float* x_out, int64_t count, int64_t t,
+                              int num_inference_steps, e2v_stream stream);
+
+/* replaces: ddim_loop / ddim_inversion (util.py:74-101; caller train_finetune_videodiffusion.py:326-328): num_inv_steps
+ * times { eps = unet(latent, t_i, cond); latent = next_step(eps, t_i, latent) } over the ascending DDIM timesteps, no
+ * guidance.  latents [B,4,F,h,w], cond [B,T,cross_attention_dim]; all_latents (may be NULL) receives the reference's
+ * list [latent_0 .. latent_n] as [n+1][B,4,F,h,w]; final_latent (may be NULL) = all_latents[-1], what the caller feeds
+ * back as `latents=`. */
+e2v_status e2v_ddim_invert(e2v_ctx* ctx, const float* latents, const float* cond, int B, int F, int h, int w, int T,
+                           int num_inv_steps, float* all_latents, float* final_latent, e2v_stream stream);
+
 /* postprocess = 1 replaces TuneAVideoPipeline.decode_latents (pipeline_tuneeeg2video.py:175-184) without the
  * D2H copy: latents [B,4,F,h,w] -> (vae.decode(latents / 0.18215).sample / 2 + 0.5).clamp(0,1) as videos
  * [B,3,F,8h,8w].  postprocess = 0 replaces AutoencoderKL.decode (call site :179): z [B,4,F,h,w] is decoded as

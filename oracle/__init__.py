@@ -22,7 +22,7 @@ Pinning status (details in DESIGN.md "Oracle"):
   PARITY UNPINNED by the reference (it has no tests or fixtures), anchored only on closed
   forms (timestep lists, alpha-bar table, ``negative.npy`` shape/dtype) and invariants.
 """
-from .ddim import DDIMOracle  # noqa: F401
+from .ddim import DDIMOracle, ddim_loop, next_step  # noqa: F401
 from .unet3d import unet3d_forward  # noqa: F401
 from .vae import vae_decode, vae_encode  # noqa: F401
 from .pipeline import generate  # noqa: F401

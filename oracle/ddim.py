@@ -49,3 +49,30 @@ class DDIMOracle:
         std = eta * var ** 0.5
         direction = (1 - a_p - std ** 2) ** 0.5 * eps
         return a_p ** 0.5 * x0 + direction
+
+
+# ---- DDIM inversion: EEG2Video_New/Generation/tuneavideo/util.py:56-101 (reference-owned; PINNED by
+# tests/golden/reference_t1_inversion.npz, generated from the reference's own next_step) -----------------
+def next_step(model_output: torch.Tensor, timestep: int, sample: torch.Tensor, sched: DDIMOracle) -> torch.Tensor:
+    """util.py:56-66, line for line."""
+    timestep, next_timestep = min(int(timestep) - sched.num_train_timesteps // sched.num_inference_steps, 999), int(timestep)
+    alpha_prod_t = sched.alphas_cumprod[timestep] if timestep >= 0 else sched.final_alpha_cumprod
+    alpha_prod_t_next = sched.alphas_cumprod[next_timestep]
+    beta_prod_t = 1 - alpha_prod_t
+    next_original_sample = (sample - beta_prod_t ** 0.5 * model_output) / alpha_prod_t ** 0.5
+    next_sample_direction = (1 - alpha_prod_t_next) ** 0.5 * model_output
+    return alpha_prod_t_next ** 0.5 * next_original_sample + next_sample_direction
+
+
+def ddim_loop(unet_fn, sched: DDIMOracle, latent: torch.Tensor, num_inv_steps: int, cond: torch.Tensor):
+    """util.py:74-93 with the cond embeddings passed in (the reference reads them from ``cond_embeddings.pt``, :80-82).
+    ``unet_fn(latent, t, cond) -> eps``."""
+    cond = cond.repeat(latent.shape[0], 1, 1) if cond.shape[0] == 1 and latent.shape[0] > 1 else cond
+    all_latent = [latent]
+    latent = latent.clone()
+    for i in range(num_inv_steps):
+        t = sched.timesteps[len(sched.timesteps) - i - 1]
+        noise_pred = unet_fn(latent, int(t), cond)
+        latent = next_step(noise_pred, int(t), latent, sched)
+        all_latent.append(latent)
+    return all_latent

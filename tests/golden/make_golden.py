@@ -333,8 +333,72 @@ def tier1_extras(out: dict) -> None:
     out["x.dana.t"], out["x.dana.out_beta0.3"] = t.numpy(), y.numpy()
 
 
+def tier1_inversion(out: dict) -> None:
+    """DDIM inversion, `EEG2Video_New/Generation/tuneavideo/util.py:56-101`.  The file imports
+    `imageio` and `torchvision` (absent here) for its GIF writer only; empty stand-in modules let it import, and
+    `next_step` / `ddim_loop` then run unmodified.  `ddim_loop` reads `cond_embeddings.pt` and moves it to 'cuda' in
+    fp16 (:80-82): `torch.load` is pinned to our tensor and the move is redirected to the CPU (dtype kept)."""
+    import types
+    for name in ("imageio", "torchvision"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.path.insert(0, os.path.join(REF, "EEG2Video_New", "Generation", "tuneavideo"))
+    import util as ref_util
+
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2      # SD-v1-4 scheduler config
+    abar = torch.cumprod(1.0 - betas, dim=0)
+    out["inv.alphas_cumprod"] = abar.numpy()
+
+    def sched(n):
+        ts = (np.arange(0, n) * (1000 // n)).round()[::-1].copy().astype(np.int64) + 1
+        return types.SimpleNamespace(config=types.SimpleNamespace(num_train_timesteps=1000), num_inference_steps=n,
+                                     alphas_cumprod=abar, final_alpha_cumprod=abar[0], timesteps=torch.from_numpy(ts))
+
+    eps = _t(counter_normal(21, "inv.eps", (2, 4, 3, 5, 6)))
+    x = _t(counter_normal(22, "inv.x", (2, 4, 3, 5, 6)))
+    out["inv.eps"], out["inv.x"] = eps.numpy(), x.numpy()
+    cases = []
+    for n in (50, 4, 333, 20):
+        s = sched(n)
+        for t in sorted({int(s.timesteps[-1]), int(s.timesteps[len(s.timesteps) // 2]), int(s.timesteps[0])}):
+            cases.append((n, t))
+            out[f"inv.next_step.n{n}.t{t}"] = ref_util.next_step(eps, t, x, s).numpy()
+    out["inv.next_step.cases"] = np.array(cases, dtype=np.int64)
+
+    # the loop, with a closed-form stand-in for the UNet (the real one is pinned by tier 2)
+    cond = _t(counter_normal(23, "inv.cond", (1, 7, 16)))
+
+    def unet(latents, t, encoder_hidden_states):
+        c = encoder_hidden_states.float().mean(dim=(1, 2)).view(-1, 1, 1, 1, 1)
+        return {"sample": 0.3 * latents + 0.05 * torch.sin(latents * 3.0) + c + float(t) * 1e-4}
+
+    n = 5
+    s = sched(n)
+    saved = (torch.load, torch.Tensor.to)
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if (isinstance(v, str) and v.startswith("cuda")) else v for v in a)
+        return saved[1](self, *a, **k)
+
+    try:
+        torch.load = lambda *a, **k: cond.clone()
+        torch.Tensor.to = to_cpu
+        lat = ref_util.ddim_inversion(unet, s, x, n, prompt="")
+    finally:
+        torch.load, torch.Tensor.to = saved
+    out["inv.loop.cond"], out["inv.loop.n"] = cond.numpy(), np.array([n], dtype=np.int64)
+    out["inv.loop.latents"] = np.stack([l.numpy() for l in lat])
+
+
 def main() -> None:
+    if "--only-inversion" in sys.argv:                      # add one fixture without re-running the 0.9 G-parameter CLIP
+        ti = {}
+        tier1_inversion(ti)
+        np.savez_compressed(os.path.join(HERE, "reference_t1_inversion.npz"), **ti)
+        print("reference_t1_inversion.npz", os.path.getsize(os.path.join(HERE, "reference_t1_inversion.npz")) // 1024, "KiB")
+        return
     t1, t2, tx = {}, {}, {}
+    tier1_inversion(t1i := {})
+    np.savez_compressed(os.path.join(HERE, "reference_t1_inversion.npz"), **t1i)
     tier1(t1)
     tier2(t2)
     tier1_extras(tx)

@@ -265,3 +265,47 @@ def test_conv_algorithms_forced_unet_and_vae_vs_oracle(algo, monkeypatch):
     refv = vae_decode({k: _t(v) for k, v in vsd.items()}, TINY_VAE, z)
     yv = pipe.vae.decode(z.cuda()).sample
     assert rel_err(yv, refv) < 1e-4
+
+
+def test_ddim_next_step_vs_reference_golden(tiny, golden_dir):
+    """e2v_ddim_next_step against the reference's own next_step outputs (tuneavideo/util.py:56-66)."""
+    eng = tiny[0].unet.engine
+    g = np.load(os.path.join(golden_dir, "reference_t1_inversion.npz"))
+    eng.set_alphas_cumprod(g["inv.alphas_cumprod"])
+    eps, x = _t(g["inv.eps"]).cuda(), _t(g["inv.x"]).cuda()
+    for n, t in g["inv.next_step.cases"]:
+        y = eng.ddim_next_step(eps, int(t), x, int(n))
+        assert rel_err(y, _t(g[f"inv.next_step.n{n}.t{t}"])) < 2e-6, (n, t)
+
+
+def test_ddim_inversion_vs_oracle_and_mirror(tiny):
+    """The fused device loop (e2v_ddim_invert) and the tuneavideo/util.py mirror against the oracle's ddim_loop driving the
+    oracle UNet; the inverted latent then round-trips through the generate loop's first steps without blowing up."""
+    from eeg2video_amd.scheduler import DDIMScheduler
+    from eeg2video_amd.util import ddim_inversion, next_step
+    from oracle import DDIMOracle, ddim_loop, unet3d_forward
+    pipe, usd, _ = tiny
+    eng = pipe.unet.engine
+    n = 3
+    x = _t(counter_normal(31, "x", (2, 4, 3, 9, 12)))
+    cond = _t(counter_normal(32, "c", (1, 11, TINY_UNET.cross_attention_dim)))
+    so = DDIMOracle()
+    so.set_timesteps(n)
+    ref = ddim_loop(lambda l, t, c: unet3d_forward(usd, TINY_UNET, l, t, c), so, x, n, cond)
+    sch = DDIMScheduler(engine=eng)
+    sch.set_timesteps(n)
+    got = ddim_inversion(pipe.unet, sch, x.cuda(), n, prompt=cond)
+    assert len(got) == n + 1 and torch.equal(got[0].cpu(), x)
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) < 1e-4
+    last = eng.ddim_invert(x.cuda(), cond.repeat(2, 1, 1).cuda(), n, return_all=False)
+    assert torch.equal(last, got[-1])
+    # the stepwise mirror gives the same numbers as the fused loop
+    lat = x.cuda()
+    for i in range(n):
+        t = int(sch.timesteps[len(sch.timesteps) - i - 1])
+        eps = pipe.unet(lat, t, encoder_hidden_states=cond.repeat(2, 1, 1).cuda())["sample"]
+        lat = next_step(eps, t, lat, sch)
+    assert torch.equal(lat, got[-1])
+    with pytest.raises(ValueError):
+        ddim_inversion(pipe.unet, sch, x.cuda(), n + 1, prompt=cond)

@@ -164,3 +164,41 @@ def test_t1_semantic_predictor_full_size(tx):
         y = semantic_predictor(sd, _t(tx["x.clip.eeg"])).numpy()
     np.testing.assert_allclose(y[:, tx["x.clip.idx"]], tx["x.clip.out_sampled"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(np.sqrt((y.astype(np.float64) ** 2).sum(1)), tx["x.clip.out_l2"], rtol=1e-6)
+
+
+# ---- DDIM inversion: the reference's own next_step / ddim_loop outputs ----------------------------
+@pytest.fixture(scope="module")
+def tinv(golden_dir):
+    return np.load(os.path.join(golden_dir, "reference_t1_inversion.npz"))
+
+
+def test_t1_inversion_next_step_bit_exact(tinv):
+    """`next_step` (tuneavideo/util.py:56-66) run by the reference itself for n in {50, 4, 333, 20}: first / middle / last
+    timestep (the first one exercises final_alpha_cumprod)."""
+    from oracle import next_step
+    s = DDIMOracle()
+    assert np.array_equal(s.alphas_cumprod.numpy(), tinv["inv.alphas_cumprod"])
+    eps, x = torch.from_numpy(tinv["inv.eps"]), torch.from_numpy(tinv["inv.x"])
+    for n, t in tinv["inv.next_step.cases"]:
+        s.set_timesteps(int(n))
+        assert torch.equal(next_step(eps, int(t), x, s), torch.from_numpy(tinv[f"inv.next_step.n{n}.t{t}"])), (n, t)
+
+
+def test_t1_inversion_loop(tinv):
+    """`ddim_inversion` (util.py:74-101) run unmodified with a closed-form UNet stand-in: pins the ascending timestep order,
+    the fp16 cast of the cond embeddings and the list it returns."""
+    from oracle import ddim_loop
+    s = DDIMOracle()
+    n = int(tinv["inv.loop.n"][0])
+    s.set_timesteps(n)
+    cond16 = torch.from_numpy(tinv["inv.loop.cond"]).to(torch.float16)           # util.py:81
+
+    def unet_fn(latents, t, cond):
+        c = cond.float().mean(dim=(1, 2)).view(-1, 1, 1, 1, 1)
+        return 0.3 * latents + 0.05 * torch.sin(latents * 3.0) + c + float(t) * 1e-4
+
+    lat = ddim_loop(unet_fn, s, torch.from_numpy(tinv["inv.x"]), n, cond16)
+    ref = tinv["inv.loop.latents"]
+    assert len(lat) == n + 1 == ref.shape[0]
+    for a, b in zip(lat, ref):
+        assert torch.equal(a, torch.from_numpy(b))
