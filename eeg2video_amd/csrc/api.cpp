@@ -427,6 +427,10 @@ e2v_status e2v_generate(e2v_ctx* c, const float* latents, const float* cond, con
             ddim_coeffs(c, ts[i], ts[i] - ratio, co);
             ddim_cfg_step(eps.p, cfg_on ? eps.p + per * B : nullptr, x.p, x.p, (long long)(per * B), guidance, co[0], co[1],
                           co[2], co[3], s);                                      // :320-325
+            // profiling aid: rocprofv3 --pmc (ROCm 7.2) segfaults in its dispatch hook once ~8k launches are queued
+            // behind each other; E2V_SYNC_EACH_STEP=1 drains the stream after every DDIM step (never set in a timed run)
+            static const bool sync_each = [] { const char* e = std::getenv("E2V_SYNC_EACH_STEP"); return e && std::atoi(e) != 0; }();
+            if (sync_each) E2V_HIP(hipStreamSynchronize(s));
         }
         if (latents_out) cl_to_ncfhw(x.p, Cl, latents_out, B, Cl, P, 1.f, 0.f, 0, 0.f, 0.f, s);
         if (videos) {                                                            // decode_latents (:175-184)
