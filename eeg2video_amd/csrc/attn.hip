@@ -73,25 +73,41 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs p) {
         }
     }
 
+    // K/V staging: the (row, column) a thread fetches never changes, only the tile's first key does.  Loads go through
+    // buffer descriptors rebuilt per tile from the (wave-uniform) address of that first key, so a lane's offset is a
+    // loop-invariant 32-bit number and keys past the end of a ragged last tile are fetched with an offset outside the
+    // descriptor window -- the buffer unit returns zeros, no per-element select (VALU time is not hidden behind the fp32
+    // MFMA on gfx950: this took the staging from ~60 to ~10 vector instructions per tile).
+    constexpr unsigned OOB = 0x80000000u;
+    auto rsrc_of = [](const void* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, 0x7FFFFFF0,
+                                                 0x00020000);
+    };
+    int ld_row[LPT];
+    unsigned ld_off[LPT];
+#pragma unroll
+    for (int e = 0; e < LPT; ++e) {
+        const int idx = tid + 256 * e;
+        const int row = idx / DQ, c4 = idx - row * DQ;
+        ld_row[e] = row;
+        ld_off[e] = idx < NF4 ? (unsigned)(row * p.ldkv + c4 * 4) * 4u : OOB;
+    }
     f32x4 kreg[LPT], vreg[LPT];
     auto load_tile = [&](int tt) {
         const int seg = tt / tps;
         const int key0 = (tt - seg * tps) * KT;
+        const size_t first = (kvbase[seg] + key0) * p.ldkv + head * D;
+        const __amdgpu_buffer_rsrc_t rk = rsrc_of(p.k + first), rv = rsrc_of(p.v + first);
+        const int left = p.Nk - key0;                           // keys this tile really has (uniform)
 #pragma unroll
         for (int e = 0; e < LPT; ++e) {
-            const int idx = tid + 256 * e;
-            f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (idx < NF4) {
-                const int row = idx / DQ, c4 = idx - row * DQ;
-                const int key = key0 + row;
-                if (key < p.Nk) {
-                    const size_t off = (kvbase[seg] + key) * p.ldkv + head * D + c4 * 4;
-                    kk = *reinterpret_cast<const f32x4*>(p.k + off);
-                    vv = *reinterpret_cast<const f32x4*>(p.v + off);
-                }
-            }
-            kreg[e] = kk;
-            vreg[e] = vv;
+            unsigned off = ld_off[e];
+            if (left < KT) off = ld_row[e] < left ? off : OOB;  // ragged last tile of a segment only
+            kreg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
+            vreg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
         }
     };
     auto store_tile = [&](int buf) {
