@@ -15,6 +15,7 @@
 #include "kernels.h"
 #include "prof.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace e2v {
@@ -667,12 +668,14 @@ void temporal_attention(const float* qkv, int ld, float* out, int ldo, int n, in
     if (!total) return;
     ProfScope ps("temporal_attn", 4.0 * total * F * D, 4.0 * 4.0 * (double)n * F * HW * heads * D, s);
     const int C = heads * D;
-    // slab of whole heads and pixel count such that the staged q/k/v fit 48 KB (3 blocks per CU)
+    // slab of whole heads and pixel count such that the staged q/k/v fit 16 KB: with 48 KB (3 blocks of 2 waves per CU) the
+    // load phase had too little in flight -- 0.60 -> 0.33 ms at level 0 (1.9 -> 3.4 TB/s algorithmic)
+    static const size_t budget = [] { const char* e = std::getenv("E2V_TATTN_LDS_KB"); return (size_t)(e ? std::atoi(e) : 16) * 1024; }();
     int hs = heads;
-    while (hs > 1 && (size_t)F * 3 * hs * D * 4 > 48 * 1024) hs = (hs + 1) / 2;
+    while (hs > 1 && (size_t)F * 3 * hs * D * 4 > budget) hs = (hs + 1) / 2;
     while (heads % hs) --hs;
     const int CS = hs * D;
-    int PB = (int)((48 * 1024) / ((size_t)F * 3 * CS * 4));
+    int PB = (int)(budget / ((size_t)F * 3 * CS * 4));
     PB = PB < 1 ? 1 : (PB > 8 ? 8 : PB);
     const size_t smem = (size_t)F * PB * 3 * CS * 4;
     if (smem > 64 * 1024) {           // does not fit the default LDS window: per-thread global version
