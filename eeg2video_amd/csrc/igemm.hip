@@ -1,12 +1,15 @@
 // fp32 implicit-GEMM convolution / linear on the gfx950 matrix cores.
 //
 // One kernel serves InflatedConv3d 3x3 (resnet.py:10-18, stride 1/2, with the nearest resize of
-// Upsample3D folded into the gather), every 1x1 conv / nn.Linear of the path, and the batched
-// QK^T / PV products of the VAE attention block.  Arithmetic is v_mfma_f32_32x32x2_f32: exact
-// fp32 products, fp32 accumulate (bitwise an fmaf chain) -- the parity configuration of BASELINE.json.
+// Upsample3D folded into the gather), every 1x1 conv / nn.Linear of the path, the 16 / 36 batched
+// GEMMs of the Winograd convs (wino.hip) and the batched QK^T / PV products of the VAE attention block.
+// Arithmetic is v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (bitwise an fmaf chain) --
+// the parity configuration of BASELINE.json.
 //
-// Tiling: 256 threads = 4 waves as 2x2; block tile BM x BN x 32, LDS double-buffered, global loads
-// of step k+1 issued before the MFMAs of step k (register staging, one barrier per step).
+// Tiling: 256 threads = 4 waves as 2x2; block tile BM x BN x 32, LDS double-buffered; global loads
+// (buffer loads driven by an LDS gather table, hardware zero-fill for masked elements) run TWO k-steps
+// ahead through two register sets; one LDS-only-relevant barrier per step; 16-byte epilogue accesses
+// because the weight fragment is the MFMA's A operand.  DESIGN.md 3.1 has the measurements behind each choice.
 // LDS rows are padded to 36 floats: a wave's ds_read_b128 of 16 distinct rows then covers all 64 banks
 // exactly once.  Each lane feeds 4 consecutive k (one b128) to 4 MFMAs: the two lane halves own
 // k = 8g + {0..3} and 8g + {4..7}; A and B use the same assignment so the sum is over all 32 k.
@@ -397,22 +400,9 @@ static void launch_igemm(const IgemmArgs& a, int ntiles, const char* cls, hipStr
     hipLaunchKernelGGL((igemm_kernel<ABL, BF>), grid, dim3(256), smem, s, a);
 }
 
-// 256 zero bytes per device: the source of every masked 16-byte load
-static const float* zero_page() {
-    static float* z[64] = {nullptr};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!z[dev]) {
-        (void)hipMalloc((void**)&z[dev], 256);
-        (void)hipMemset(z[dev], 0, 256);
-    }
-    return z[dev];
-}
-
 void igemm(const IgemmArgs& a_in, hipStream_t s) {
     if (a_in.M <= 0 || a_in.N <= 0) return;
     IgemmArgs a = a_in;
-    a.zeros = zero_page();
     if (a.taps == 1) {      // linear / 1x1: a 1 x M map without padding -- the same gather as the 3x3 case
         a.Ho = a.Hi = a.Hs = 1;
         a.Wo = a.Wi = a.Ws = a.M;

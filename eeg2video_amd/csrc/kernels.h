@@ -41,7 +41,6 @@ struct IgemmArgs {
     long long sa0 = 0, sw = 0, sout = 0;
     int bf16 = 0;                  // 1: multiply in bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate); needs w16
     const void* w16 = nullptr;     // the same packed weights rounded to bf16
-    const float* zeros = nullptr;  // filled by the launcher: 16+ zero bytes, the source of masked loads
     int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, nbm_per = 0, tail_rb = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
 };
 void igemm(const IgemmArgs& a, hipStream_t s);
