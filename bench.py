@@ -92,7 +92,7 @@ def main() -> int:
                     help="DDIM steps of the event-instrumented pass (0 = --ddim-steps: the instrumented pass is the timed workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel-class table (JSON) here")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "f32x3"],
                     help="fp32 = BASELINE configs[1] (default, the metric's configuration); bf16 = configs[2]: bf16 MFMA "
                          "(fp32 accumulate) for convs / linears, fp32 activations, GroupNorm, LayerNorm, softmax")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
@@ -122,12 +122,15 @@ def main() -> int:
                                        vae_param_spec)
 
     t_setup = time.perf_counter()
+    if args.dtype == "f32x3":                      # opt-in, experimental: the weights are split at finalize, so select it first
+        os.environ["E2V_F32X3"] = "1"
     ucfg, vcfg = UNetConfig(), VAEConfig()
     usd = synth_state_dict(unet_param_spec(ucfg), seed=42, mode="reference_init")
     vsd = synth_state_dict(vae_param_spec(vcfg), seed=43, mode="reference_init")
     pipe = build_pipeline(ucfg, vcfg, device=local, unet_sd=usd, vae_sd=vsd)
     eng = pipe.unet.engine
-    eng.set_compute_dtype(args.dtype)
+    if args.dtype != "f32x3":
+        eng.set_compute_dtype(args.dtype)
     dev = eng.device
     B = args.batch
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
@@ -190,7 +193,8 @@ def main() -> int:
         if dom in HBM_BOUND:
             roof = {"bound": "hbm", "achieved": d["gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": d["gbps"] / PEAK_HBM_GBPS}
         else:
-            peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom else PEAK_F32_MFMA_TFLOPS
+            # f32x3 executes 6 bf16 MFMA flops per fp32 flop counted: its fp32-equivalent ceiling is the bf16 peak / 6
+            peak = PEAK_BF16_MFMA_TFLOPS / 6 if "f32x3" in dom else PEAK_BF16_MFMA_TFLOPS if "bf16" in dom else PEAK_F32_MFMA_TFLOPS
             roof = {"bound": "mfma", "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": d["tflops"] / peak}
         roof.update({"traffic": traffic, "kernel": dom, "launches": d["launches"], "avg_launch_us": d["avg_us"],
                      "share_of_gpu_time": d["share"],
@@ -209,15 +213,17 @@ def main() -> int:
             y_gpu = pipe.unet(x1.to(dev), 501, c1.to(dev)).sample
             torch.cuda.synchronize()
             cpu, err = cpu_baseline(usd, vsd, y_gpu, x1, c1)
-            parity = {"unet_sample_max_abs_over_max_ref": err, "tolerance": 1e-3 if args.dtype == "fp32" else 5e-2}
+            parity = {"unet_sample_max_abs_over_max_ref": err, "tolerance": 5e-2 if args.dtype == "bf16" else 1e-3}
         result = {
             "metric": "6-frame 288x512 clips/sec (50-step DDIM)", "value": value, "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "fp32" else "bf16 multiply / f32 accumulate, f32 activations", "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16": "bf16 multiply / f32 accumulate, f32 activations",
+                      "f32x3": "f32 products from 3-way split bf16 operands (6 bf16 MFMAs), f32 accumulate"}[args.dtype], "data": "synthetic",
             "config": {"workload": (f"{world}xMI355X: batch={B}/GPU synthetic latents [B,4,6,36,64] + [B,77,768] cond, "
                                     f"{args.ddim_steps}-step DDIM, CFG {args.guidance}, 288x512x6 VAE decode, "
-                                    + ("fp32 (BASELINE configs[1])" if args.dtype == "fp32" else "bf16 MFMA with fp32 norms (BASELINE configs[2])")),
+                                    + {"fp32": "fp32 (BASELINE configs[1])", "bf16": "bf16 MFMA with fp32 norms (BASELINE configs[2])",
+                                       "f32x3": "fp32-equivalent via split bf16 (experimental, opt-in)"}[args.dtype]),
                        "clips_per_gpu": B, "ddim_steps": args.ddim_steps, "guidance_scale": args.guidance,
                        "unet_samples_per_ddim_step": 2 * B, "weights": "random-init SD-v1-4 architecture, counter RNG seed 42/43",
                        "collective": "RCCL all-gather of decoded frames" if world > 1 else "none"},

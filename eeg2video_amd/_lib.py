@@ -33,7 +33,7 @@ class E2VConfig(C.Structure):
 
 
 E2V_OK, E2V_EINVAL, E2V_ESHAPE, E2V_ENOWEIGHT, E2V_EHIP, E2V_ESTATE = 0, -1, -2, -3, -4, -5
-E2V_F32, E2V_F16, E2V_BF16 = 0, 1, 2
+E2V_F32, E2V_F16, E2V_BF16, E2V_F32X3 = 0, 1, 2, 3
 
 _ctx = C.c_void_p
 _stream = C.c_void_p

@@ -111,6 +111,7 @@ e2v_status e2v_create(const e2v_config* cfg, int device, e2v_ctx** out) {
         c->expected_keys();
         make_alphas(c);
         if (const char* e = std::getenv("E2V_CONV_ALGO")) c->conv_algo = std::atoi(e);
+        if (const char* e = std::getenv("E2V_F32X3")) c->x3_compute = std::atoi(e) != 0;
         if (const char* e = std::getenv("E2V_WINO_MIN_C")) c->wino_min_c = std::atoi(e);
         if (const char* e = std::getenv("E2V_WINO_F4")) c->wino_f4 = std::atoi(e) != 0;
         if (const char* e = std::getenv("E2V_WINO_F4_PAD")) c->wino_f4_pad = std::atof(e);
@@ -284,8 +285,13 @@ int64_t e2v_profile_end(e2v_ctx* c, char* json, int64_t cap) {
 }
 
 e2v_status e2v_set_compute_dtype(e2v_ctx* c, int dtype) {
-    if (!c || (dtype != E2V_F32 && dtype != E2V_BF16)) return E2V_EINVAL;
+    if (!c || (dtype != E2V_F32 && dtype != E2V_BF16 && dtype != E2V_F32X3)) return E2V_EINVAL;
+    if (dtype == E2V_F32X3 && (c->unet_ready || c->vae_ready || c->sem_ready)) {
+        c->err = "E2V_F32X3 needs the split weights: select it before e2v_finalize_weights";
+        return E2V_ESTATE;
+    }
     c->bf16_compute = dtype == E2V_BF16;
+    c->x3_compute = dtype == E2V_F32X3;
     return E2V_OK;
 }
 
@@ -530,6 +536,13 @@ e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, 
             a.nimg = n_img; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo;
             if (Hi != Hs || Wi != Ws) { a.upsample = 1; a.ups_h = (float)Hs / (float)Hi; a.ups_w = (float)Ws / (float)Wi; }
             a.U = u.p; a.N = cout; a.out = out; a.ldc = cout; a.bias = bias;
+            Act u3;
+            if (c->x3_compute) {
+                const size_t n = (size_t)(wm + 2) * (wm + 2) * cout * cin;
+                u3 = Act(c->pool, (int64_t)((3 * n + 1) / 2 + 1023) / 1024, 1024);
+                split_bf16x3(u.p, u3.p, n, n, s);
+                a.U3 = u3.p;
+            }
             a.rowbias = rowbias; a.rb_ld = cout; a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
             a.resid = resid; a.ldr = cout;
             const int chunk = wino_chunk_images(a, c->wino_ws_floats);
@@ -590,6 +603,13 @@ e2v_status e2v_op_linear(e2v_ctx* c, const float* x, int ldx, int64_t M, int K, 
             w16 = Act(c->pool, g.N, (K + 1) / 2);
             to_bf16(g.w, w16.p, (size_t)g.N * K, s);
             g.bf16 = 1; g.w16 = w16.p; g.ldw16 = K;
+        }
+        Act w3;
+        if (c->x3_compute) {
+            const size_t n = (size_t)g.N * K;
+            w3 = Act(c->pool, (int64_t)((3 * n + 1) / 2 + 1023) / 1024, 1024);
+            split_bf16x3(g.w, w3.p, n, n, s);
+            g.x3 = 1; g.w3 = w3.p; g.w3_plane = (long long)n;
         }
         igemm(g, s);
         E2V_HIP(hipGetLastError());

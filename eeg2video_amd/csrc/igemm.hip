@@ -29,6 +29,80 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Epilogue shared by the fp32, bf16 and split-bf16 tiles (all use 32x32 MFMA results with the WEIGHT fragment as the A
+// operand): in each 32x32 result a lane holds pixel m = lane & 31 and output channels n = 8 g + 4 (lane >> 5) + e in register
+// r = 4 g + e -- four consecutive channels per register quad, i.e. 16-byte bias / time-embedding / residual loads and 16-byte
+// stores (a short-K layer -- every Winograd-domain GEMM, every attention projection -- spends a tenth of its time here).
+template <int BM, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)[TM][TN], float* __restrict__ out, const int bm,
+                                               const int n0, const int wm, const int wn, const int lane) {
+    const int mrow = lane & 31;
+    const int nq = (lane >> 5) * 4;
+    if (p.geglu) {
+        if constexpr (TN == 2) {
+            const int nb = n0 + wn * WN;                           // value columns nb .. nb+31, gate columns nb+32 .. nb+63
+            if (nb + 64 <= p.N) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int m = bm * BM + wm * WM + mi * 32 + mrow;
+                    if (m >= p.M) continue;
+                    float* orow = out + (size_t)m * p.ldc + nb / 2 + nq;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * g + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        const f32x4 bg = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + 32 + 8 * g + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        f32x4 y;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_erf(acc[mi][1][4 * g + e] * p.alpha + bg[e]);
+                        *reinterpret_cast<f32x4*>(orow + 8 * g) = y;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    const bool vec = ((p.N | p.ldc | p.ldr | p.rb_ld) & 3) == 0;   // strides of absent operands are 0
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = bm * BM + wm * WM + mi * 32 + mrow;
+        if (m >= p.M) continue;
+        const float* rbp = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.rb_ld : nullptr;
+        const float* rsp = p.resid ? p.resid + (size_t)m * p.ldr : nullptr;
+        float* orow = out + (size_t)m * p.ldc;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * WN + ni * 32 + 8 * g + nq;
+                if (n >= p.N) continue;
+                if (vec) {
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = acc[mi][ni][4 * g + e] * p.alpha;
+                    if (p.bias) y += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (rbp) y += *reinterpret_cast<const f32x4*>(rbp + n);
+                    if (rsp) y += *reinterpret_cast<const f32x4*>(rsp + n);
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(orow + n) = y;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= p.N) break;
+                        float v = acc[mi][ni][4 * g + e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
+                        if (rbp) v += rbp[n + e];
+                        if (rsp) v += rsp[n + e];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        orow[n + e] = v;
+                    }
+                }
+            }
+    }
+}
+
 // BF = false: fp32 operands, v_mfma_f32_32x32x2_f32, 32 k per stage (the parity configuration).
 // BF = true : bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation over fp32 activations in HBM: the A tile is
 //             rounded to bf16 on its way into LDS, weights are pre-converted (p.w16), 64 k per stage.  LDS rows are
@@ -274,75 +348,238 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int rbg, co
     }
     if (ks < nk) kstep(std::integral_constant<int, 0>{});
 
-    // epilogue.  The MFMAs ran with the WEIGHT fragment as their A operand, so in each 32x32 result a lane holds pixel
-    // m = lane & 31 and output channels n = 8 g + 4 (lane >> 5) + e in register r = 4 g + e: four consecutive channels
-    // per register quad, i.e. 16-byte bias / time-embedding / residual loads and 16-byte stores (a short-K layer --
-    // every Winograd-domain GEMM, every attention projection -- spends a tenth of its time here).
-    const int mrow = lane & 31;
-    const int nq = (lane >> 5) * 4;
-    if (p.geglu) {
-        if constexpr (TN == 2) {
-            const int nb = n0 + wn * WN;                           // value columns nb .. nb+31, gate columns nb+32 .. nb+63
-            if (nb + 64 <= p.N) {
+    igemm_epilogue<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane);
+}
+
+// =====================================================================================================
+// "f32x3": fp32 GEMM on the bf16 matrix pipe.  Every fp32 operand is split EXACTLY into three bf16 pieces by truncation
+// (x = x1 + x2 + x3: 8 + 8 + 8 = 24 mantissa bits), and a product is the sum of the six piece products of weight at
+// least 2^-16: x1 y1 + x1 y2 + x2 y1 + x1 y3 + x3 y1 + x2 y2 (the three dropped ones are below 2^-24 of the product, the
+// rounding of an fp32 multiply).  Piece products are exact in fp32 and accumulate in the MFMA's fp32 accumulator, so the
+// result carries fp32-level error (measured 2.5e-7 of the output scale at K = 1280, the fp32 FMA chain 6e-7) while the
+// arithmetic runs on v_mfma_f32_32x32x16_bf16: 6 x 32 = 192 cycles per 32x32x16 block instead of 512 on the fp32 MFMA, on
+// a pipe that -- unlike the fp32 MFMA -- does not share its ALUs with the VALU.
+// Weights are split once (e2v_finalize_weights: three bf16 planes); activations are split on their way into LDS.
+// Opt-in (E2V_F32X3): it changes "computes in f32" into "computes f32-equivalent products on the bf16 pipe".
+// taps == 1 only (linears, Winograd-domain GEMMs = 95 % of the igemm time in fp32 mode).
+// =====================================================================================================
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void igemm_tile_x3(const IgemmArgs& p, const int rbg, const int n0, char* smem) {
+    const int z = p.batch > 1 ? rbg / p.nbm_per : 0;
+    const int bm = rbg - z * p.nbm_per;
+    constexpr int BKE = 32;
+    constexpr int PLD = 80;                         // bytes per LDS row of one plane: 32 bf16 + 16 pad (conflict-free b128 reads)
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int RPP = NT / 8;
+    constexpr int AR = BM / RPP;
+    constexpr int BRX = BN * 4 / NT;                // 16-byte weight loads per thread and plane (4 lanes per 64-byte row)
+    char* Ap = smem;                                // [3][BM][PLD]
+    char* Bp = smem + 3 * BM * PLD;                 // [3][BN][PLD]
+    unsigned* tab = reinterpret_cast<unsigned*>(smem + 3 * (BM + BN) * PLD);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const float* __restrict__ a0 = p.a0 + (size_t)z * p.sa0;
+    const float* __restrict__ a1 = p.a1;
+    const char* __restrict__ w = reinterpret_cast<const char*>(p.w3) + ((size_t)z * p.sw + (size_t)n0 * p.ldw) * 2;
+    float* __restrict__ out = p.out + (size_t)z * p.sout;
+
+    const int steps0 = (p.c0 + BKE - 1) / BKE, steps1 = (p.c1 + BKE - 1) / BKE;
+    const int nk = steps0 + steps1;
+    const int c4 = tid & 7;
+    const int r0 = tid >> 3;
+
+    // taps == 1: the gather table is the identity over the block's rows (kept so that masked rows read through the same
+    // out-of-window offset as in the fp32 tile)
+    const size_t row_base = (size_t)bm * BM;
+    for (int e = tid; e < BM; e += NT) tab[e] = (bm * BM + e < p.M) ? (unsigned)e : ~0u;
+    constexpr unsigned OOB = 0x80000000u;
+    const float* const a0b = a0 + row_base * p.lda0;
+    const float* const a1b = p.c1 > 0 ? a1 + row_base * p.lda1 : a0b;
+    auto rsrc_of = [](const void* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, 0x7FFFFFF0,
+                                                 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rw0 = rsrc_of(w), rw1 = rsrc_of(w + (size_t)p.w3_plane * 2), rw2 = rsrc_of(w + (size_t)p.w3_plane * 4);
+    unsigned b_off[BRX];
+    int b_q[BRX];
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi) {
-                    const int m = bm * BM + wm * WM + mi * 32 + mrow;
-                    if (m >= p.M) continue;
-                    float* orow = out + (size_t)m * p.ldc + nb / 2 + nq;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * g + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
-                        const f32x4 bg = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + 32 + 8 * g + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
-                        f32x4 y;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_erf(acc[mi][1][4 * g + e] * p.alpha + bg[e]);
-                        *reinterpret_cast<f32x4*>(orow + 8 * g) = y;
-                    }
-                }
-            }
-        }
-        return;
+    for (int j = 0; j < BRX; ++j) {
+        const int idx = tid + NT * j;
+        const int row = idx >> 2, q = idx & 3;
+        b_q[j] = q;
+        b_off[j] = (n0 + row < p.N) ? (unsigned)(row * p.ldw * 2 + q * 16) : OOB;
     }
-    const bool vec = ((p.N | p.ldc | p.ldr | p.rb_ld) & 3) == 0;   // strides of absent operands are 0
+    __syncthreads();
+
+    int k_src = 0, k_cb = 0, cseg = p.c0, ldb = p.lda0 * 4;
+    bool done = false;
+    unsigned pixn[AR];
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        const int m = bm * BM + wm * WM + mi * 32 + mrow;
-        if (m >= p.M) continue;
-        const float* rbp = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.rb_ld : nullptr;
-        const float* rsp = p.resid ? p.resid + (size_t)m * p.ldr : nullptr;
-        float* orow = out + (size_t)m * p.ldc;
+    for (int i = 0; i < AR; ++i) pixn[i] = tab[r0 + RPP * i];
+    f32x4 rga[2][AR], rgb[2][3 * BRX];
+    auto issue_loads = [&](f32x4 (&ra)[AR], f32x4 (&rb)[3 * BRX]) {
+        const unsigned colb = (unsigned)(k_cb + c4 * 4) * 4u;
+        const __amdgpu_buffer_rsrc_t rsa = rsrc_of(k_src ? a1b : a0b);
+        const bool cok0 = (!done) & (k_cb + c4 * 4 < cseg);
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const unsigned rowb = __umul24(pixn[i], (unsigned)ldb) + colb;
+            const bool ok = (pixn[i] != ~0u) & cok0;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, ok ? rowb : OOB, 0, 0));
+        }
+        const int koffb = ((k_src ? p.c0 : 0) + k_cb) * 2;                          // wave-uniform: rides in soffset
+#pragma unroll
+        for (int j = 0; j < BRX; ++j) {
+            const bool ok = (!done) & (k_cb + b_q[j] * 8 < cseg);
+            const unsigned off = ok ? b_off[j] : OOB;
+            rb[3 * j + 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw0, off, koffb, 0));
+            rb[3 * j + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw1, off, koffb, 0));
+            rb[3 * j + 2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw2, off, koffb, 0));
+        }
+        const int cb2 = k_cb + BKE;
+        const bool wrap = cb2 >= cseg;
+        k_cb = wrap ? 0 : cb2;
+        const bool more = k_src == 0 && p.c1 > 0;
+        done = done || (wrap && !more);
+        k_src = (wrap && more) ? 1 : k_src;
+        cseg = k_src ? p.c1 : p.c0;
+        ldb = (k_src ? p.lda1 : p.lda0) * 4;
+    };
+    // activations: exact three-way truncation split of four fp32 -> three packed bf16x4 (8 bytes per plane)
+    auto store_tile = [&](const f32x4 (&ra)[AR], const f32x4 (&rb)[3 * BRX]) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            unsigned h1[4], h2[4], h3[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = ra[i][e];
+                const unsigned b1 = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+                const float r1 = x - __builtin_bit_cast(float, b1);
+                const unsigned b2 = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+                const float r2 = r1 - __builtin_bit_cast(float, b2);
+                h1[e] = b1; h2[e] = b2; h3[e] = __builtin_bit_cast(unsigned, r2);
+            }
+            char* dst = Ap + (r0 + RPP * i) * PLD + c4 * 8;
+            const u32x2 v1 = {(h1[0] >> 16) | (h1[1] & 0xFFFF0000u), (h1[2] >> 16) | (h1[3] & 0xFFFF0000u)};
+            const u32x2 v2 = {(h2[0] >> 16) | (h2[1] & 0xFFFF0000u), (h2[2] >> 16) | (h2[3] & 0xFFFF0000u)};
+            const u32x2 v3 = {(h3[0] >> 16) | (h3[1] & 0xFFFF0000u), (h3[2] >> 16) | (h3[3] & 0xFFFF0000u)};
+            *reinterpret_cast<u32x2*>(dst) = v1;
+            *reinterpret_cast<u32x2*>(dst + BM * PLD) = v2;
+            *reinterpret_cast<u32x2*>(dst + 2 * BM * PLD) = v3;
+        }
+#pragma unroll
+        for (int j = 0; j < BRX; ++j) {
+            const int idx = tid + NT * j;
+            char* dst = Bp + (idx >> 2) * PLD + (idx & 3) * 16;
+            *reinterpret_cast<f32x4*>(dst) = rb[3 * j + 0];
+            *reinterpret_cast<f32x4*>(dst + BN * PLD) = rb[3 * j + 1];
+            *reinterpret_cast<f32x4*>(dst + 2 * BN * PLD) = rb[3 * j + 2];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * WN + ni * 32 + 8 * g + nq;
-                if (n >= p.N) continue;
-                if (vec) {
-                    f32x4 y;
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    issue_loads(rga[0], rgb[0]);
+    issue_loads(rga[1], rgb[1]);
+    store_tile(rga[0], rgb[0]);
+    __syncthreads();
+
+    const char* Afr = Ap + (wm * WM + (lane & 31)) * PLD + (lane >> 5) * 16;
+    const char* Bfr = Bp + (wn * WN + (lane & 31)) * PLD + (lane >> 5) * 16;
+    auto kstep = [&](auto Pc) {
+        constexpr int P = decltype(Pc)::value;
+        if (!(p.dbg & 1)) issue_loads(rga[P], rgb[P]);  // tile ks+2
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = acc[mi][ni][4 * g + e] * p.alpha;
-                    if (p.bias) y += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    if (rbp) y += *reinterpret_cast<const f32x4*>(rbp + n);
-                    if (rsp) y += *reinterpret_cast<const f32x4*>(rsp + n);
-                    if (p.relu) {
+        for (int g = 0; g < 2; ++g) {                   // two 16-deep chunks of the 32-k stage
+            bf16x8 af[3][TM], bf[3][TN];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
-                    }
-                    *reinterpret_cast<f32x4*>(orow + n) = y;
-                } else {
+            for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (n + e >= p.N) break;
-                        float v = acc[mi][ni][4 * g + e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
-                        if (rbp) v += rbp[n + e];
-                        if (rsp) v += rsp[n + e];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        orow[n + e] = v;
-                    }
-                }
+                for (int mi = 0; mi < TM; ++mi)
+                    af[pl][mi] = *reinterpret_cast<const bf16x8*>(Afr + pl * BM * PLD + mi * 32 * PLD + g * 32);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    bf[pl][ni] = *reinterpret_cast<const bf16x8*>(Bfr + pl * BN * PLD + ni * 32 * PLD + g * 32);
             }
+            // smallest terms first; (weight piece, activation piece)
+            constexpr int TW[6] = {1, 2, 0, 1, 0, 0}, TA[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[TW[t]][ni], af[TA[t]][mi], acc[mi][ni], 0, 0, 0);
+        }
+        if (!(p.dbg & 2)) {
+            __syncthreads();                            // everyone has read tile ks
+            store_tile(rga[P ^ 1], rgb[P ^ 1]);         // tile ks+1
+            __syncthreads();
+        }
+    };
+    int ks = 0;
+    for (; ks + 1 < nk; ks += 2) {
+        kstep(std::integral_constant<int, 0>{});
+        kstep(std::integral_constant<int, 1>{});
     }
+    if (ks < nk) kstep(std::integral_constant<int, 0>{});
+    igemm_epilogue<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane);
+}
+
+__global__ __launch_bounds__(256) void igemm_x3_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_x3[];
+    const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
+    const int nrb = rb_hi - rb_lo;
+    const int tail = min(nrb, p.tail_rb);
+    const int per1 = p.w1 + p.s1;
+    const int n1 = (nrb - tail) * per1;
+    if (loc < n1) {
+        const int r = loc / per1, j = loc - r * per1;
+        if (j < p.w1)
+            igemm_tile_x3<128, 128, 2, 2>(p, rb_lo + r, j * 128, smem_x3);
+        else
+            igemm_tile_x3<128, 64, 2, 2>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_x3);
+    } else {
+        const int t = loc - n1;
+        if (t >= tail * p.s2) return;
+        const int r = t / p.s2;
+        igemm_tile_x3<128, 64, 2, 2>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_x3);
+    }
+}
+
+static void launch_igemm_x3(const IgemmArgs& a, int ntiles, hipStream_t s) {
+    static bool configured = false;
+    constexpr size_t smem = (size_t)3 * (128 + 128) * 80 + 128 * sizeof(unsigned);
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        configured = true;
+    }
+    const double K = (double)(a.c0 + a.c1);
+    std::string pname = "igemm_f32x3";
+    if (profiler().on && profiler().detail)
+        pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) +
+                 (a.geglu ? " geglu" : "") + (a.batch > 1 ? " b" + std::to_string(a.batch) : "");
+    ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
+                 4.0 * a.batch * ((double)a.M * K + 1.5 * a.N * K + (double)a.M * (a.geglu ? a.N / 2 : a.N)), s);
+    hipLaunchKernelGGL(igemm_x3_kernel, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
 }
 
 // One launch runs a MIX of tile shapes (IgemmArgs::rb1/w1/s1/s2): row blocks [0, rb1) are cut into w1 tiles of
@@ -422,6 +659,9 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
     a.rb1 = nbm;
     const bool use_bf16 = a.bf16 && a.w16 && a.c0 % 8 == 0 && a.c1 % 8 == 0 && a.ldw16 % 8 == 0 &&
                           (a.c1 == 0 || a.c0 % 64 == 0 || a.taps == 1);
+    // split-bf16 fp32 (see igemm_tile_x3): linears / Winograd GEMMs whose K is a multiple of 8 and whose weights were split
+    const bool use_x3 = !use_bf16 && a.x3 && a.w3 && a.taps == 1 && !a.relu && a.c0 % 8 == 0 && a.c1 % 8 == 0 && a.ldw % 8 == 0 &&
+                        abl == 0;
     if (use_bf16) a.ldw = a.ldw16;
     const char* cls = use_bf16 ? "igemm_bf16" : "igemm_f32";
     if (a.geglu) {                                           // the GEGLU epilogue pairs the two 32-column halves of a wave
@@ -455,6 +695,12 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
         ntiles = t > ntiles ? t : ntiles;
     }
     ntiles *= 8;
+    if (use_x3) {
+        static const int dbg = [] { const char* e = std::getenv("E2V_X3_DBG"); return e ? std::atoi(e) : 0; }();
+        a.dbg = dbg;
+        launch_igemm_x3(a, ntiles, s);
+        return;
+    }
     if (use_bf16 && abl == 0) { launch_igemm<0, true>(a, ntiles, cls, s); return; }
     if (abl == 1) launch_igemm<1>(a, ntiles, cls, s);
     else if (abl == 2) launch_igemm<2>(a, ntiles, cls, s);
@@ -483,6 +729,25 @@ void pack_conv3x3(const float* w, float* o, int cout, int cin, int bke, hipStrea
     const size_t total = (size_t)cout * conv3x3_packed_ld(cin, bke);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(256), 0, s, w, o, cout, cin, bke);
+}
+
+// fp32 -> three bf16 planes by truncation: x = p0 + p1 + p2 exactly (planes `plane` elements apart)
+__global__ void split_bf16x3_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, size_t n, size_t plane) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = in[i];
+        const unsigned b1 = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+        const float r1 = x - __builtin_bit_cast(float, b1);
+        const unsigned b2 = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, b2);
+        out[i] = (unsigned short)(b1 >> 16);
+        out[plane + i] = (unsigned short)(b2 >> 16);
+        out[2 * plane + i] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    }
+}
+void split_bf16x3(const float* in, void* out, size_t n, size_t plane, hipStream_t s) {
+    if (!n) return;
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(blocks), dim3(256), 0, s, in, static_cast<unsigned short*>(out), n, plane);
 }
 
 __global__ void to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n) {

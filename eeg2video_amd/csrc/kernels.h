@@ -41,7 +41,10 @@ struct IgemmArgs {
     long long sa0 = 0, sw = 0, sout = 0;
     int bf16 = 0;                  // 1: multiply in bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate); needs w16
     const void* w16 = nullptr;     // the same packed weights rounded to bf16
-    int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, nbm_per = 0, tail_rb = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
+    int x3 = 0;                    // 1: fp32 products from three bf16 pieces per operand on the bf16 MFMA (igemm_tile_x3); needs w3
+    const void* w3 = nullptr;      // three bf16 planes of w ([N][K] each, w3_plane elements apart; batch entries sw apart)
+    long long w3_plane = 0;
+    int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, nbm_per = 0, tail_rb = 0, dbg = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
 };
 void igemm(const IgemmArgs& a, hipStream_t s);
 
@@ -51,6 +54,7 @@ int conv3x3_packed_ld(int cin, int bke);
 void pack_conv3x3(const float* w_oihw, float* w_packed, int cout, int cin, int bke, hipStream_t s);
 void copy_rows(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t s);
 void to_bf16(const float* in, void* out_bf16, size_t n, hipStream_t s);
+void split_bf16x3(const float* in, void* out_planes, size_t n, size_t plane_stride, hipStream_t s);   // exact 3-way truncation split
 
 // ---------------------------------------------------------------------------------------
 // Winograd F(2x2, 3x3) for the stride-1, pad-1 3x3 convolutions (wino.hip); output map = logical input map
@@ -64,6 +68,7 @@ struct WinoArgs {
     const float* gn_scsh = nullptr; int gn_P = 1; int gn_silu = 0;   // fused GroupNorm affine (+ SiLU) on the way in
     int m = 2;                                                 // output tile: 2 = F(2x2,3x3), 4 = F(4x4,3x3)
     const float* U = nullptr;                                  // [(m+2)^2][N][c0+c1] (wino_pack_weights)
+    const void* U3 = nullptr;                                  // its three-plane bf16 split (f32x3 mode), planes (m+2)^2*N*C apart
     int N = 0;
     float* out = nullptr; int ldc = 0;
     const float* bias = nullptr;

@@ -165,10 +165,16 @@ struct Packer {
         to_bf16(w, d, n, s);
         return d;
     }
+    const void* split3(const float* w, size_t n) {           // three bf16 planes (f32x3 mode only)
+        if (!c->x3_compute) return nullptr;
+        float* d = c->dev_alloc((3 * n + 1) / 2);
+        split_bf16x3(w, d, n, n, s);
+        return d;
+    }
     NormW norm(const std::string& n) { return NormW{t(n + ".weight").d, t(n + ".bias").d, (int)t(n + ".weight").shape[0]}; }
     LinW lin(const std::string& n, bool bias = true) {       // Linear or 1x1 conv: [out][in] as it is
         const WTensor& w = t(n + ".weight");
-        return LinW{w.d, bias ? t(n + ".bias").d : nullptr, (int)w.shape[1], (int)w.shape[0], half(w.d, w.numel)};
+        return LinW{w.d, bias ? t(n + ".bias").d : nullptr, (int)w.shape[1], (int)w.shape[0], half(w.d, w.numel), split3(w.d, w.numel)};
     }
     // [O][I][3][3] -> [O][chunk][tap][32] (+ a bf16 copy in chunks of 64) (+ Winograd-domain weights for stride-1 convs)
     ConvW conv3(const std::string& n, bool stride1 = true) {
@@ -187,20 +193,23 @@ struct Packer {
         (void)hipFree(tmp);
         const float* wino = nullptr;
         const float* wino4 = nullptr;
+        const void* wino_x3 = nullptr; const void* wino4_x3 = nullptr;
         if (stride1 && ci % 4 == 0 && co % 4 == 0 && c->conv_algo != 1) {
             const int cmin = std::min(ci, co);
             if (c->conv_algo == 2 || (c->conv_algo == 0 && cmin >= c->wino_min_c)) {
                 float* u = c->dev_alloc((size_t)16 * co * ci);
                 wino_pack_weights(w.d, u, co, ci, 2, s);
                 wino = u;
+                wino_x3 = split3(u, (size_t)16 * co * ci);
             }
             if (c->conv_algo == 3 || (c->conv_algo == 0 && c->wino_f4 && cmin >= c->wino4_min_c)) {
                 float* u4 = c->dev_alloc((size_t)36 * co * ci);
                 wino_pack_weights(w.d, u4, co, ci, 4, s);
                 wino4 = u4;
+                wino4_x3 = split3(u4, (size_t)36 * co * ci);
             }
         }
-        return ConvW{d, t(n + ".bias").d, ci, cp, co, d16, ld32, ld64, wino, wino4};
+        return ConvW{d, t(n + ".bias").d, ci, cp, co, d16, ld32, ld64, wino, wino4, wino_x3, wino4_x3};
     }
     LinW fuse_rows(const std::vector<std::string>& names, bool bias) {   // stack Linear weights along `out`
         int in = 0, out = 0;
@@ -214,7 +223,7 @@ struct Packer {
             if (bias) copy_rows(t(n + ".bias").d, (int)w.shape[0], b + r, (int)w.shape[0], 1, (int)w.shape[0], s);
             r += (int)w.shape[0];
         }
-        return LinW{d, b, in, out, half(d, (size_t)out * in)};
+        return LinW{d, b, in, out, half(d, (size_t)out * in), split3(d, (size_t)out * in)};
     }
     LinW geglu(const std::string& n) {        // rows [value 0..4C) | gate 0..4C)] -> per 64: [32 value | 32 gate]
         const WTensor& w = t(n + ".weight");
@@ -229,7 +238,7 @@ struct Packer {
             copy_rows(bsrc.d + q * 32, 32, b + q * 64, 32, 1, 32, s);
             copy_rows(bsrc.d + half + q * 32, 32, b + q * 64 + 32, 32, 1, 32, s);
         }
-        return LinW{d, b, in, out, this->half(d, (size_t)out * in)};
+        return LinW{d, b, in, out, this->half(d, (size_t)out * in), split3(d, (size_t)out * in)};
     }
     ResW resnet(const std::string& p, bool temb) {
         ResW r;
@@ -460,6 +469,7 @@ struct Runner {
         g.w = w.w; g.ldw = w.in; g.ldw16 = w.in; g.out = out.p; g.ldc = out.C; g.bias = w.b;
         g.resid = resid; g.ldr = ldr; g.M = (int)M; g.N = w.out; g.taps = 1; g.geglu = geglu ? 1 : 0;
         g.bf16 = c->bf16_compute ? 1 : 0; g.w16 = w.w16;
+        if (c->x3_compute && w.w3) { g.x3 = 1; g.w3 = w.w3; g.w3_plane = (long long)w.out * w.in; }
         igemm(g, s);
         return out;
     }
@@ -484,6 +494,7 @@ struct Runner {
             }
             if (gn_P > 0) { a.gn_scsh = c->gn_scale; a.gn_P = gn_P; a.gn_silu = 1; }
             a.U = wm == 4 ? w.wino4 : w.wino; a.N = w.cout; a.out = out.p; a.ldc = w.cout; a.bias = w.b;
+            if (c->x3_compute) a.U3 = wm == 4 ? w.wino4_x3 : w.wino_x3;
             a.rowbias = rowbias; a.rb_ld = w.cout; a.rows_per_sample = rows_per_sample; a.resid = resid; a.ldr = w.cout;
             const int chunk = wino_chunk_images(a, c->wino_ws_floats);
             const size_t need = wino_workspace_floats(a, chunk);

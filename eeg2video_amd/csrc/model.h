@@ -13,10 +13,12 @@
 namespace e2v {
 
 struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
-struct LinW { const float* w = nullptr; const float* b = nullptr; int in = 0, out = 0; const void* w16 = nullptr; };
+struct LinW { const float* w = nullptr; const float* b = nullptr; int in = 0, out = 0; const void* w16 = nullptr;
+              const void* w3 = nullptr; };      // three bf16 planes of w (out*in elements apart) for the f32x3 mode
 struct ConvW { const float* w = nullptr; const float* b = nullptr; int cin = 0, cin_pad = 0, cout = 0; const void* w16 = nullptr; int ldw = 0, ldw16 = 0;
                const float* wino = nullptr;      // [16][cout][cin] Winograd F(2x2,3x3)-domain weights (stride-1 convs wide enough to profit)
-               const float* wino4 = nullptr; };  // [36][cout][cin] F(4x4,3x3)-domain weights (only when that form is enabled)
+               const float* wino4 = nullptr;     // [36][cout][cin] F(4x4,3x3)-domain weights (only when that form is enabled)
+               const void* wino_x3 = nullptr; const void* wino4_x3 = nullptr; };   // their three-plane bf16 splits (f32x3 mode)
 
 struct ResW {
     NormW n1, n2;
@@ -90,6 +92,7 @@ struct e2v_ctx {
     double wino_f4_pad = 1.7;
     int wino_min_c = 256;                                        // auto: F(2x2,3x3) when min(Cin, Cout) >= this (E2V_WINO_MIN_C)
     size_t wino_ws_floats = (size_t)1 << 30;                     // workspace cap per pass (E2V_WINO_WS_MB)
+    bool x3_compute = false;                                     // E2V_F32X3: fp32 products from split bf16 pieces on the bf16 MFMA
     bool bf16_compute = false;                                   // e2v_set_compute_dtype: bf16 MFMA for convs / linears
     std::vector<e2v::LinW> sem;                                  // semantic predictor layers (first one K-padded to 4)
     int sem_in_pad = 0;

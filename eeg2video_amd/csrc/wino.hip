@@ -379,6 +379,7 @@ void wino_conv3x3(const WinoArgs& a, float* ws, int chunk_images, hipStream_t s)
         g.a0 = V; g.c0 = Ctot; g.lda0 = Ctot; g.w = a.U; g.ldw = Ctot; g.ldw16 = Ctot;
         g.out = Mb; g.ldc = a.N; g.M = (int)T; g.N = a.N; g.taps = 1;
         g.batch = P; g.sa0 = (long long)T * Ctot; g.sw = (long long)a.N * Ctot; g.sout = (long long)T * a.N;
+        if (a.U3) { g.x3 = 1; g.w3 = a.U3; g.w3_plane = (long long)P * a.N * Ctot; }
         igemm(g, s);
         {
             const size_t total = T * (a.N / 4);

@@ -111,7 +111,7 @@ class Engine:
 
     def set_compute_dtype(self, dtype: str) -> None:
         """'fp32' (default, parity configuration) or 'bf16' (bf16 MFMA with fp32 accumulate for convs / linears)."""
-        code = {"fp32": _lib.E2V_F32, "f32": _lib.E2V_F32, "bf16": _lib.E2V_BF16}[dtype]
+        code = {"fp32": _lib.E2V_F32, "f32": _lib.E2V_F32, "bf16": _lib.E2V_BF16, "f32x3": _lib.E2V_F32X3}[dtype]
         self._check(self.lib.e2v_set_compute_dtype(self.ctx, code))
 
     def set_conv_algo(self, algo: str) -> None:

@@ -38,7 +38,7 @@ typedef enum {
     E2V_ESTATE = -5      /* call order (weights not finalized, ...) */
 } e2v_status;
 
-typedef enum { E2V_F32 = 0, E2V_F16 = 1, E2V_BF16 = 2 } e2v_dtype;
+typedef enum { E2V_F32 = 0, E2V_F16 = 1, E2V_BF16 = 2, E2V_F32X3 = 3 } e2v_dtype;
 
 /* Mirror of the UNet3DConditionModel ctor kwargs the path uses (EEG2Video/models/unet.py:41-78) and of
  * the AutoencoderKL config (diffusers 0.11.1 vae/config.json).  e2v_default_config()
@@ -187,7 +187,11 @@ int64_t e2v_profile_end(e2v_ctx* ctx, char* json, int64_t cap);
 
 /* Arithmetic of the convolutions / linears (everything else stays fp32): E2V_F32 (default; fp32 MFMA, the parity
  * configuration of BASELINE configs[1]) or E2V_BF16 (BASELINE configs[2]: bf16 MFMA with fp32 accumulation, fp32
- * activations in HBM, fp32 GroupNorm / LayerNorm / softmax).  Takes effect for the following calls. */
+ * activations in HBM, fp32 GroupNorm / LayerNorm / softmax).  Takes effect for the following calls.
+ * E2V_F32X3 (opt-in, experimental): fp32 results from the bf16 matrix pipe -- every operand of a linear / Winograd-domain
+ * GEMM is split exactly into three bf16 pieces and the six significant piece products are accumulated in fp32 (error at
+ * the level of the fp32 FMA chain); must be selected BEFORE e2v_finalize_weights (the weights are split there), else
+ * E2V_ESTATE.  Also selectable with E2V_F32X3=1 in the environment at e2v_create. */
 e2v_status e2v_set_compute_dtype(e2v_ctx* ctx, int dtype);
 
 /* Algorithm of the stride-1 3x3 convolutions in fp32 arithmetic.  E2V_CONV_AUTO (default): Winograd F(4x4,3x3) -- 4x

@@ -6,7 +6,8 @@ from eeg2video_amd.engine import Engine
 from eeg2video_amd.weights import TINY_UNET, TINY_VAE
 
 eng = Engine(TINY_UNET, TINY_VAE, 0)
-eng.set_compute_dtype(os.environ.get("DTYPE", "fp32"))
+if "DTYPE" in os.environ:
+    eng.set_compute_dtype(os.environ["DTYPE"])
 eng.set_conv_algo(os.environ.get("ALGO", "direct"))
 reps = int(os.environ.get("REPS", "5"))
 only = os.environ.get("ONLY", "")
