@@ -362,6 +362,10 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int rbg, co
 // Weights are split once (e2v_finalize_weights: three bf16 planes); activations are split on their way into LDS.
 // Opt-in (E2V_F32X3): it changes "computes in f32" into "computes f32-equivalent products on the bf16 pipe".
 // taps == 1 only (linears, Winograd-domain GEMMs = 95 % of the igemm time in fp32 mode).
+// First version: one 32-k LDS stage (61 KB, 2 workgroups per CU), two barriers per stage, 150-170 TFLOP/s fp32-equivalent
+// (36-40 % of the bf16 pipe / 6).  A variant with 16-k stages, double-buffered LDS, one barrier per stage and the split
+// interleaved with the MFMAs (sched_group_barrier) measured no better (136-160): the six piece products read one 16-byte
+// LDS fragment per MFMA, 4x the fp32 tile's LDS traffic per matrix-pipe cycle -- the next step is a 128x64 per-wave tile.
 // =====================================================================================================
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
