@@ -508,7 +508,7 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmArgs& p, const int rbg,
     const char* Bfr = Bp + (wn * WN + (lane & 31)) * PLD + (lane >> 5) * 16;
     auto kstep = [&](auto Pc) {
         constexpr int P = decltype(Pc)::value;
-        if (!(p.dbg & 1)) issue_loads(rga[P], rgb[P]);  // tile ks+2
+        issue_loads(rga[P], rgb[P]);                    // tile ks+2
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {                   // two 16-deep chunks of the 32-k stage
@@ -532,11 +532,9 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmArgs& p, const int rbg,
                     for (int ni = 0; ni < TN; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[TW[t]][ni], af[TA[t]][mi], acc[mi][ni], 0, 0, 0);
         }
-        if (!(p.dbg & 2)) {
-            __syncthreads();                            // everyone has read tile ks
-            store_tile(rga[P ^ 1], rgb[P ^ 1]);         // tile ks+1
-            __syncthreads();
-        }
+        __syncthreads();                                // everyone has read tile ks
+        store_tile(rga[P ^ 1], rgb[P ^ 1]);             // tile ks+1
+        __syncthreads();
     };
     int ks = 0;
     for (; ks + 1 < nk; ks += 2) {
@@ -699,12 +697,7 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
         ntiles = t > ntiles ? t : ntiles;
     }
     ntiles *= 8;
-    if (use_x3) {
-        static const int dbg = [] { const char* e = std::getenv("E2V_X3_DBG"); return e ? std::atoi(e) : 0; }();
-        a.dbg = dbg;
-        launch_igemm_x3(a, ntiles, s);
-        return;
-    }
+    if (use_x3) { launch_igemm_x3(a, ntiles, s); return; }
     if (use_bf16 && abl == 0) { launch_igemm<0, true>(a, ntiles, cls, s); return; }
     if (abl == 1) launch_igemm<1>(a, ntiles, cls, s);
     else if (abl == 2) launch_igemm<2>(a, ntiles, cls, s);

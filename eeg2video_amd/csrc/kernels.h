@@ -44,7 +44,7 @@ struct IgemmArgs {
     int x3 = 0;                    // 1: fp32 products from three bf16 pieces per operand on the bf16 MFMA (igemm_tile_x3); needs w3
     const void* w3 = nullptr;      // three bf16 planes of w ([N][K] each, w3_plane elements apart; batch entries sw apart)
     long long w3_plane = 0;
-    int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, nbm_per = 0, tail_rb = 0, dbg = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
+    int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, nbm_per = 0, tail_rb = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
 };
 void igemm(const IgemmArgs& a, hipStream_t s);
 

@@ -309,3 +309,36 @@ def test_ddim_inversion_vs_oracle_and_mirror(tiny):
     assert torch.equal(lat, got[-1])
     with pytest.raises(ValueError):
         ddim_inversion(pipe.unet, sch, x.cuda(), n + 1, prompt=cond)
+
+
+def test_f32x3_mode_unet_vae_and_ops_vs_oracle(monkeypatch):
+    """Opt-in E2V_F32X3: every linear / Winograd-domain GEMM runs as six bf16-piece MFMAs over exactly split operands
+    (igemm_tile_x3).  It must meet the SAME tolerances as the fp32-MFMA path: per-op 2e-5 of the output scale, tiny UNet /
+    VAE 1e-4 against the oracle."""
+    from eeg2video_amd.pipeline import build_pipeline
+    from oracle import unet3d_forward, vae_decode
+    monkeypatch.setenv("E2V_F32X3", "1")
+    usd = synth_state_dict(unet_param_spec(TINY_UNET), seed=42, mode="perturbed")
+    vsd = synth_state_dict(vae_param_spec(TINY_VAE), seed=43, mode="perturbed")
+    pipe = build_pipeline(TINY_UNET, TINY_VAE, device=0, unet_sd=usd, vae_sd=vsd)
+    eng = pipe.unet.engine
+    g = torch.Generator().manual_seed(3)
+    for m, k, n in [(240, 1280, 1280), (1000, 320, 960), (77, 64, 128), (130, 40, 72)]:
+        x, w, b, r = (torch.randn(*s, generator=g) for s in ((m, k), (n, k), (n,), (m, n)))
+        w = w * 0.05
+        eng.profile_begin()
+        y = eng.op_linear(x.cuda(), w.cuda(), b.cuda(), r.cuda())
+        assert "igemm_f32x3" in eng.profile_end(), "the split-bf16 kernel did not run"
+        ref = torch.nn.functional.linear(x.double(), w.double(), b.double()) + r.double()
+        assert (y.cpu().double() - ref).abs().max().item() <= 4e-5 * ref.abs().max().item()
+    shape = (2, 4, 3, 9, 12)
+    x = _t(counter_normal(5, "x", shape))
+    cond = _t(counter_normal(6, "c", (shape[0], 11, TINY_UNET.cross_attention_dim)))
+    ref = unet3d_forward({k: _t(v) for k, v in usd.items()}, TINY_UNET, x, 301, cond)
+    y = pipe.unet(x.cuda(), 301, cond.cuda(), return_dict=False)[0]
+    assert rel_err(y, ref) < 1e-4
+    z = _t(counter_normal(11, "z", (2, 4, 4, 6)))
+    refv = vae_decode({k: _t(v) for k, v in vsd.items()}, TINY_VAE, z)
+    assert rel_err(pipe.vae.decode(z.cuda()).sample, refv) < 1e-4
+    with pytest.raises(RuntimeError):                   # selecting it after the weights are finalized is a call-order error
+        eng.set_compute_dtype("f32x3")
