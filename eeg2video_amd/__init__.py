@@ -14,7 +14,7 @@ The compute path has no CPU fallback: without the built library or without a GPU
 from .weights import TINY_SEMANTIC, TINY_UNET, TINY_VAE, SemanticConfig, UNetConfig, VAEConfig  # noqa: F401
 
 __all__ = ["UNetConfig", "VAEConfig", "TINY_UNET", "TINY_VAE", "Engine", "UNet3DConditionModel", "AutoencoderKL",
-           "DDIMScheduler", "TuneAVideoPipeline", "build_pipeline"]
+           "DDIMScheduler", "PNDMScheduler", "TuneAVideoPipeline", "build_pipeline"]
 
 
 def __getattr__(name):          # lazy: importing the package must not need torch.cuda or the .so
@@ -30,6 +30,9 @@ def __getattr__(name):          # lazy: importing the package must not need torc
     if name == "DDIMScheduler":
         from .scheduler import DDIMScheduler
         return DDIMScheduler
+    if name == "PNDMScheduler":
+        from .scheduler import PNDMScheduler
+        return PNDMScheduler
     if name in ("TuneAVideoPipeline", "build_pipeline"):
         from . import pipeline
         return getattr(pipeline, name)

@@ -61,6 +61,8 @@ SIGNATURES = {
     "e2v_semantic_predict": (_i, [_ctx, _p, _i, _p, _stream]),
     "e2v_dana_noise": (_i, [_ctx, _p, _p, _p, c_int64_p, _i, _f, _i, _i, _i, _i, _i, _p, _stream]),
     "e2v_frames_to_uint8": (_i, [_ctx, _p, _p, _i64, _stream]),
+    "e2v_cfg_combine": (_i, [_ctx, _p, _p, _f, _p, _i64, _stream]),
+    "e2v_lincomb": (_i, [_ctx, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_float), _p, _i64, _stream]),
     "e2v_ddim_next_step": (_i, [_ctx, _p, _p, _p, _i64, _i64, _i, _stream]),
     "e2v_ddim_invert": (_i, [_ctx, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _stream]),
     "e2v_set_compute_dtype": (_i, [_ctx, _i]),

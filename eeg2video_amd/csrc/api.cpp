@@ -449,6 +449,26 @@ e2v_status e2v_generate(e2v_ctx* c, const float* latents, const float* cond, con
     });
 }
 
+// ---- building blocks of the schedulers other than DDIM (pipeline_tuneeeg2video.py:48-55) -----------
+e2v_status e2v_cfg_combine(e2v_ctx* c, const float* eu, const float* ec, float g, float* out, int64_t count, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(eu && ec && out && count >= 0, E2V_EINVAL, "null argument");
+        cfg_combine(eu, ec, g, out, count, S(stream));
+        E2V_HIP(hipGetLastError());
+    });
+}
+
+e2v_status e2v_lincomb(e2v_ctx* c, int n, const float* const* xs, const float* coefs, float* out, int64_t count, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(n >= 1 && n <= 5 && xs && coefs && out && count >= 0, E2V_EINVAL, "lincomb takes 1..5 terms");
+        for (int k = 0; k < n; ++k) E2V_REQUIRE(xs[k] != nullptr, E2V_EINVAL, "null term");
+        lincomb(n, xs, coefs, out, count, S(stream));
+        E2V_HIP(hipGetLastError());
+    });
+}
+
 // ---- DDIM inversion (EEG2Video_New/Generation/tuneavideo/util.py:56-101) --------------------------
 // next_step: "timestep" = t - T/n (alpha of the step being left; < 0 -> final_alpha_cumprod), "next_timestep" = t.
 static void ddim_next_coeffs(const e2v_ctx* c, int64_t t, int steps, float co[4]) {

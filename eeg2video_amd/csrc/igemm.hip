@@ -369,7 +369,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int rbg, co
 // =====================================================================================================
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int ABLX = 0>
 __device__ __forceinline__ void igemm_tile_x3(const IgemmArgs& p, const int rbg, const int n0, char* smem) {
     const int z = p.batch > 1 ? rbg / p.nbm_per : 0;
     const int bm = rbg - z * p.nbm_per;
@@ -508,7 +508,7 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmArgs& p, const int rbg,
     const char* Bfr = Bp + (wn * WN + (lane & 31)) * PLD + (lane >> 5) * 16;
     auto kstep = [&](auto Pc) {
         constexpr int P = decltype(Pc)::value;
-        issue_loads(rga[P], rgb[P]);                    // tile ks+2
+        if (ABLX < 1) issue_loads(rga[P], rgb[P]);      // tile ks+2
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {                   // two 16-deep chunks of the 32-k stage
@@ -532,9 +532,11 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmArgs& p, const int rbg,
                     for (int ni = 0; ni < TN; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[TW[t]][ni], af[TA[t]][mi], acc[mi][ni], 0, 0, 0);
         }
-        __syncthreads();                                // everyone has read tile ks
-        store_tile(rga[P ^ 1], rgb[P ^ 1]);             // tile ks+1
-        __syncthreads();
+        if (ABLX < 2) {
+            __syncthreads();                            // everyone has read tile ks
+            store_tile(rga[P ^ 1], rgb[P ^ 1]);         // tile ks+1
+            __syncthreads();
+        }
     };
     int ks = 0;
     for (; ks + 1 < nk; ks += 2) {
@@ -545,6 +547,7 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmArgs& p, const int rbg,
     igemm_epilogue<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane);
 }
 
+template <int ABLX>
 __global__ __launch_bounds__(256) void igemm_x3_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_x3[];
     const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
@@ -556,22 +559,25 @@ __global__ __launch_bounds__(256) void igemm_x3_kernel(const IgemmArgs p) {
     if (loc < n1) {
         const int r = loc / per1, j = loc - r * per1;
         if (j < p.w1)
-            igemm_tile_x3<128, 128, 2, 2>(p, rb_lo + r, j * 128, smem_x3);
+            igemm_tile_x3<128, 128, 2, 2, ABLX>(p, rb_lo + r, j * 128, smem_x3);
         else
-            igemm_tile_x3<128, 64, 2, 2>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_x3);
+            igemm_tile_x3<128, 64, 2, 2, ABLX>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_x3);
     } else {
         const int t = loc - n1;
         if (t >= tail * p.s2) return;
         const int r = t / p.s2;
-        igemm_tile_x3<128, 64, 2, 2>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_x3);
+        igemm_tile_x3<128, 64, 2, 2, ABLX>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_x3);
     }
 }
 
 static void launch_igemm_x3(const IgemmArgs& a, int ntiles, hipStream_t s) {
-    static bool configured = false;
+    static const int ablx = [] { const char* e = std::getenv("E2V_X3_ABLATE"); return e ? std::atoi(e) : 0; }();   // timing experiments only
     constexpr size_t smem = (size_t)3 * (128 + 128) * 80 + 128 * sizeof(unsigned);
+    static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         configured = true;
     }
     const double K = (double)(a.c0 + a.c1);
@@ -581,7 +587,9 @@ static void launch_igemm_x3(const IgemmArgs& a, int ntiles, hipStream_t s) {
                  (a.geglu ? " geglu" : "") + (a.batch > 1 ? " b" + std::to_string(a.batch) : "");
     ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
                  4.0 * a.batch * ((double)a.M * K + 1.5 * a.N * K + (double)a.M * (a.geglu ? a.N / 2 : a.N)), s);
-    hipLaunchKernelGGL(igemm_x3_kernel, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
+    if (ablx == 1) hipLaunchKernelGGL(igemm_x3_kernel<1>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
+    else if (ablx == 2) hipLaunchKernelGGL(igemm_x3_kernel<2>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
+    else hipLaunchKernelGGL(igemm_x3_kernel<0>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
 }
 
 // One launch runs a MIX of tile shapes (IgemmArgs::rb1/w1/s1/s2): row blocks [0, rb1) are cut into w1 tiles of

@@ -142,6 +142,10 @@ void ddim_cfg_step(const float* eps_u, const float* eps_c, const float* x, float
                    float guidance, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_p, float sqrt_1m_a_p,
                    hipStream_t s);
 
+// out = sum_{i<n} coefs[i] xs[i] (n <= 5) / out = eu + g (ec - eu): schedulers other than DDIM (PNDM) and the guidance line
+void lincomb(int n, const float* const* xs, const float* coefs, float* out, long long count, hipStream_t s);
+void cfg_combine(const float* eu, const float* ec, float g, float* out, long long count, hipStream_t s);
+
 // (f) rows -------------------------------------------------------------------------------------------
 // DANA noise (EEG2Video/models/DANA_module.py:52-72) fused with the caller's layout fix 'a b c d e -> a c b d e'
 // (inference_eeg2video.py:77,82): x0, eps_div [B,F,C,HW], eps_same [B,1,C,HW] -> out [B,C,F,HW];

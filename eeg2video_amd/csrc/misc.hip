@@ -150,6 +150,39 @@ void ddim_cfg_step(const float* eps_u, const float* eps_c, const float* x, float
                        (size_t)count, guidance, sqrt_a_t, sqrt_1m_a_t, sqrt_a_p, sqrt_1m_a_p);
 }
 
+// out = sum_i c_i x_i over up to five tensors (the linear multistep combinations of PNDM/PLMS and its sample update);
+// cfg (ec != nullptr): out = eu + g (ec - eu), the guidance line of the pipeline (pipeline_tuneeeg2video.py:320-322)
+struct LinComb { const float* x[5]; float c[5]; int n; };
+__global__ void lincomb_kernel(const LinComb a, float* __restrict__ out, size_t count) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        float v = a.c[0] * a.x[0][i];
+#pragma unroll
+        for (int k = 1; k < 5; ++k)
+            if (k < a.n) v += a.c[k] * a.x[k][i];
+        out[i] = v;
+    }
+}
+void lincomb(int n, const float* const* xs, const float* coefs, float* out, long long count, hipStream_t s) {
+    if (count <= 0) return;
+    LinComb a{};
+    a.n = n;
+    for (int k = 0; k < n; ++k) { a.x[k] = xs[k]; a.c[k] = coefs[k]; }
+    ProfScope ps("lincomb", 2.0 * n * count, 4.0 * count * (n + 1), s);
+    hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, s, a, out, (size_t)count);
+}
+__global__ void cfg_combine_kernel(const float* __restrict__ eu, const float* __restrict__ ec, float g, float* __restrict__ out,
+                                   size_t count) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const float e = eu[i];
+        out[i] = e + g * (ec[i] - e);
+    }
+}
+void cfg_combine(const float* eu, const float* ec, float g, float* out, long long count, hipStream_t s) {
+    if (count <= 0) return;
+    ProfScope ps("cfg_combine", 3.0 * count, 12.0 * count, s);
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, s, eu, ec, g, out, (size_t)count);
+}
+
 // ---- SURVEY 8(f) rows ---------------------------------------------------------------------------------------
 __global__ void dana_kernel(const float* __restrict__ x0, const float* __restrict__ ed, const float* __restrict__ es,
                             const float* __restrict__ coef, float s1b, float sb, float* __restrict__ out, int B, int F, int C,

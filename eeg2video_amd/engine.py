@@ -173,6 +173,25 @@ class Engine:
                                                int(t_prev), _stream()))
         return out
 
+    def cfg_combine(self, eps_uncond: torch.Tensor, eps_cond: torch.Tensor, guidance_scale: float) -> torch.Tensor:
+        eu, ec = self._dev(eps_uncond, "eps_uncond"), self._dev(eps_cond, "eps_cond")
+        out = torch.empty_like(eu)
+        self._check(self.lib.e2v_cfg_combine(self.ctx, eu.data_ptr(), ec.data_ptr(), float(guidance_scale), out.data_ptr(),
+                                             eu.numel(), _stream()))
+        return out
+
+    def lincomb(self, terms) -> torch.Tensor:
+        """sum of coef * tensor over 1..5 (coef, tensor) pairs of equal shape."""
+        xs = [self._dev(t, "term") for _, t in terms]
+        n = len(xs)
+        if not 1 <= n <= 5 or any(x.shape != xs[0].shape for x in xs):
+            raise ValueError("lincomb takes 1..5 tensors of one shape")
+        out = torch.empty_like(xs[0])
+        ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        coefs = (C.c_float * n)(*[float(c) for c, _ in terms])
+        self._check(self.lib.e2v_lincomb(self.ctx, n, ptrs, coefs, out.data_ptr(), out.numel(), _stream()))
+        return out
+
     def ddim_next_step(self, eps: torch.Tensor, t: int, x: torch.Tensor, num_inference_steps: int) -> torch.Tensor:
         e, x = self._dev(eps, "eps"), self._dev(x, "sample")
         out = torch.empty_like(x)

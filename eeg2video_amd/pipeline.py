@@ -21,7 +21,7 @@ from typing import Callable, List, Optional, Union
 import numpy as np
 import torch
 
-from .scheduler import DDIMScheduler
+from .scheduler import DDIMScheduler, PNDMScheduler  # noqa: F401
 from .unet import UNet3DConditionModel
 from .vae import AutoencoderKL
 
@@ -210,10 +210,14 @@ class TuneAVideoPipeline:
                     x_in = torch.cat([latents] * 2) if do_cfg else latents                        # :313
                     x_in = self.scheduler.scale_model_input(x_in, t)                              # :314
                     eps = self.unet(x_in, t, encoder_hidden_states=emb).sample                    # :317
-                    if do_cfg:                                                                    # :320-325, one kernel
+                    if do_cfg and isinstance(self.scheduler, DDIMScheduler):                      # :320-325, one kernel
                         eu, ec = eps.chunk(2)
                         latents = eng.ddim_cfg_step(eu, ec, latents, guidance_scale, int(t),
                                                     self.scheduler.prev_timestep(int(t)))
+                    elif do_cfg:                                                                  # :320-322 then :325
+                        eu, ec = eps.chunk(2)
+                        eps = eng.cfg_combine(eu, ec, guidance_scale)
+                        latents = self.scheduler.step(eps, t, latents, **extra).prev_sample
                     else:
                         latents = self.scheduler.step(eps, t, latents, **extra).prev_sample
                     bar.update()                                                                  # :328-331

@@ -122,6 +122,17 @@ e2v_status e2v_ddim_cfg_step(e2v_ctx* ctx, const float* eps_uncond, const float*
                              float* x_out, int64_t count, float guidance_scale, int64_t t, int64_t t_prev,
                              e2v_stream stream);
 
+/* replaces: the guidance line noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond)
+ * (pipeline_tuneeeg2video.py:320-322) for schedulers whose update is not fused with it (everything but DDIM). */
+e2v_status e2v_cfg_combine(e2v_ctx* ctx, const float* eps_uncond, const float* eps_cond, float guidance_scale, float* out,
+                           int64_t count, e2v_stream stream);
+
+/* out = sum_{i<n} coefs[i] * xs[i], 1 <= n <= 5 (host arrays of n device pointers / n coefficients): the arithmetic of the
+ * linear multistep schedulers the pipeline's constructor accepts (pipeline_tuneeeg2video.py:48-55) -- PNDM/PLMS's
+ * (55 e1 - 59 e2 + 37 e3 - 9 e4) / 24 and its sample update; host side in eeg2video_amd/scheduler.py: PNDMScheduler. */
+e2v_status e2v_lincomb(e2v_ctx* ctx, int n, const float* const* xs, const float* coefs, float* out, int64_t count,
+                       e2v_stream stream);
+
 /* replaces: next_step (EEG2Video_New/Generation/tuneavideo/util.py:56-66), the deterministic DDIM update run towards
  * noise: alpha_t = abar[min(t - T/n, 999)] (final alpha when negative), alpha_next = abar[t];
  * x_next = sqrt(alpha_next) (x - sqrt(1-alpha_t) eps) / sqrt(alpha_t) + sqrt(1-alpha_next) eps. */

@@ -29,12 +29,12 @@ def decode_latents(vae_sd, vae_cfg, latents: torch.Tensor) -> torch.Tensor:
 def generate(unet_sd, unet_cfg, vae_sd, vae_cfg, latents: torch.Tensor, cond: torch.Tensor,
              uncond: torch.Tensor, num_inference_steps: int = 50, guidance_scale: float = 7.5,
              eta: float = 0.0, trace: Optional[Dict[str, List[torch.Tensor]]] = None,
-             decode: bool = True) -> torch.Tensor:
+             decode: bool = True, scheduler=None) -> torch.Tensor:
     """latents ``[B,4,F,h,w]``, cond ``[B,77,D]``, uncond ``[1 or B,77,D]`` -> videos ``[B,3,F,8h,8w]``.
 
     ``trace`` (optional) collects per-step ``eps`` (after guidance) and ``latents`` for the
     teacher-forced per-step parity tests."""
-    sched = DDIMOracle()
+    sched = scheduler if scheduler is not None else DDIMOracle()      # any oracle scheduler (DDIMOracle, PNDMOracle)
     b = latents.shape[0]
     do_cfg = guidance_scale > 1.0                                                    # :281
     if do_cfg:                                                                       # :162-172 (uncond first)

@@ -342,3 +342,39 @@ def test_f32x3_mode_unet_vae_and_ops_vs_oracle(monkeypatch):
     assert rel_err(pipe.vae.decode(z.cuda()).sample, refv) < 1e-4
     with pytest.raises(RuntimeError):                   # selecting it after the weights are finalized is a call-order error
         eng.set_compute_dtype("f32x3")
+
+
+def test_pndm_scheduler_vs_oracle_and_pipeline(tiny):
+    """PNDMScheduler mirror (host schedule + e2v_lincomb on the device) against oracle/pndm.py on a random trajectory, and
+    the pipeline's stepped loop with it (guidance through e2v_cfg_combine) against the oracle loop."""
+    from eeg2video_amd.scheduler import PNDMScheduler
+    from oracle import PNDMOracle, generate
+    pipe, usd, vsd = tiny
+    eng = pipe.unet.engine
+    so, sm = PNDMOracle(), PNDMScheduler(engine=eng)
+    so.set_timesteps(7)
+    sm.set_timesteps(7)
+    assert sm.timesteps.tolist() == so.timesteps.tolist()
+    xo = _t(counter_normal(41, "x", (2, 4, 3, 5, 6)))
+    xm = xo.cuda()
+    for i, t in enumerate(so.timesteps):
+        eps = _t(counter_normal(42 + i, "e", (2, 4, 3, 5, 6)))
+        xo = so.step(eps, int(t), xo)
+        xm = sm.step(eps.cuda(), int(t), xm).prev_sample
+        assert rel_err(xm, xo) < 2e-6, i
+    eu, ec = _t(counter_normal(60, "u", (3, 7))), _t(counter_normal(61, "c", (3, 7)))
+    assert rel_err(eng.cfg_combine(eu.cuda(), ec.cuda(), 12.5), eu + 12.5 * (ec - eu)) < 1e-6      # fused vs unfused multiply-add
+    # whole pipeline, 3 inference steps (4 UNet evaluations), guidance on
+    b, f, tok, d = 1, 3, 77, TINY_UNET.cross_attention_dim
+    lat = _t(counter_normal(70, "lat", (b, 4, f, 4, 6)))
+    eeg = _t(counter_normal(71, "eeg", (b, tok * d)))
+    neg = _t(counter_normal(72, "neg", (1, tok, d)))
+    ref = generate(usd, TINY_UNET, vsd, TINY_VAE, lat, eeg.reshape(b, tok, d), neg, 3, 7.5, scheduler=PNDMOracle())
+    old = pipe.scheduler
+    try:
+        pipe.scheduler = PNDMScheduler(engine=eng)
+        out = pipe(None, eeg, video_length=f, height=32, width=48, num_inference_steps=3, guidance_scale=7.5,
+                   negative_prompt=neg, latents=lat.cuda()).videos
+    finally:
+        pipe.scheduler = old
+    assert out.shape == ref.shape and (out - ref).abs().max().item() < 1e-3

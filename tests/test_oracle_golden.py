@@ -202,3 +202,31 @@ def test_t1_inversion_loop(tinv):
     assert len(lat) == n + 1 == ref.shape[0]
     for a, b in zip(lat, ref):
         assert torch.equal(a, torch.from_numpy(b))
+
+
+# ---- PNDM / PLMS (dependency-owned, parity unpinned: closed forms and invariants only) ----------------
+def test_pndm_oracle_closed_forms():
+    from oracle import PNDMOracle
+    s = PNDMOracle()
+    assert s.set_timesteps(4).tolist() == [751, 501, 501, 251, 1]
+    ts = s.set_timesteps(50)
+    assert len(ts) == 51 and ts[:4].tolist() == [981, 961, 961, 941] and ts[-1] == 1
+    # a constant model output is a fixed point of every multistep combination (coefficients sum to 1), so the whole PLMS
+    # trajectory then equals repeated application of the transfer formula with that constant
+    s.set_timesteps(6)
+    g = torch.Generator().manual_seed(0)
+    eps, x = torch.randn(2, 3, generator=g), torch.randn(2, 3, generator=g)
+    y = x
+    for t in s.timesteps:
+        y = s.step(eps, int(t), y)
+    z, ratio = x, 1000 // 6
+    uniq = [int(t) for i, t in enumerate(s.timesteps) if i != 1]          # the repeated timestep re-does the first move
+    for t in uniq:
+        z = s._get_prev_sample(z, t, t - ratio, eps)
+    assert torch.allclose(y, z, rtol=1e-5, atol=1e-6)
+    # the first PLMS move is the eta = 0 DDIM move (formula (9) of PNDM reduces to it for a single model output)
+    d = DDIMOracle()
+    d.set_timesteps(6)
+    s.set_timesteps(6)
+    t0 = int(s.timesteps[0])
+    assert torch.allclose(s.step(eps, t0, x), d.step(eps, t0, x), rtol=1e-5, atol=1e-6)
