@@ -419,16 +419,19 @@ e2v_status e2v_generate(e2v_ctx* c, const float* latents, const float* cond, con
         std::vector<int64_t> ts(steps);
         e2v_ddim_timesteps(c, steps, ts.data());                                 // :287-288
         const int64_t ratio = c->cfg.num_train_timesteps / steps;
+        // latent_model_input = cat([latents] * 2) (:313) is not materialised: the UNet is told that its input stands for the
+        // pair, and computes what the two copies share (up to the first cross-attention) once
+        const bool pair = cfg_on && !c->unet.down[0].attn.empty();
         Act xin;
-        if (cfg_on) xin = Act(c->pool, (int64_t)N * P, Cl);
+        if (cfg_on && !pair) xin = Act(c->pool, (int64_t)N * P, Cl);
         for (int i = 0; i < steps; ++i) {                                        // :311
             const float* in = x.p;
-            if (cfg_on) {                                                        // latent_model_input = cat([latents]*2) (:313)
+            if (cfg_on && !pair) {
                 E2V_HIP(hipMemcpyAsync(xin.p, x.p, per * B * sizeof(float), hipMemcpyDeviceToDevice, s));
                 E2V_HIP(hipMemcpyAsync(xin.p + per * B, x.p, per * B * sizeof(float), hipMemcpyDeviceToDevice, s));
                 in = xin.p;
             }
-            Act eps = c->unet_forward_cl(in, &ts[i], 1, embp, N, F, h, w, T, s);  // :317
+            Act eps = c->unet_forward_cl(in, &ts[i], 1, embp, N, F, h, w, T, s, pair);  // :317
             float co[4];
             ddim_coeffs(c, ts[i], ts[i] - ratio, co);
             ddim_cfg_step(eps.p, cfg_on ? eps.p + per * B : nullptr, x.p, x.p, (long long)(per * B), guidance, co[0], co[1],

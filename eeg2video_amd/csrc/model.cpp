@@ -558,28 +558,50 @@ struct Runner {
     }
 
     // Transformer3DModel.forward + BasicTransformerBlock.forward (attention.py:89-136, 232-269)
-    Act transformer(const TransW& w, const Act& x, int n, int F, int HW, const float* cond, int T, int heads, int groups) {
+    Act twice(const Act& a) {                        // [a ; a] along the rows
+        Act d(pool(), 2 * a.rows, a.C);
+        const size_t bytes = (size_t)a.rows * a.C * sizeof(float);
+        E2V_HIP(hipMemcpyAsync(d.p, a.p, bytes, hipMemcpyDeviceToDevice, s));
+        E2V_HIP(hipMemcpyAsync(d.p + (size_t)a.rows * a.C, a.p, bytes, hipMemcpyDeviceToDevice, s));
+        return d;
+    }
+
+    // n_shared > 0: `x` holds only n_shared = n / 2 samples whose two copies (the uncond / cond halves of a classifier-free
+    // guidance batch, pipeline_tuneeeg2video.py:313) would be bit-identical up to the first use of the conditioning: the
+    // per-frame GroupNorm, proj_in and the whole sparse-causal self-attention run once, then the tokens are duplicated.
+    Act transformer(const TransW& w, const Act& x_in, int n, int F, int HW, const float* cond, int T, int heads, int groups,
+                    int n_shared = 0) {
         const int C = w.C, D = C / heads;
         const int64_t rows = (int64_t)n * F * HW;
+        const int n1 = n_shared > 0 ? n_shared : n;                       // samples up to and including attn1
+        const int64_t rows1 = (int64_t)n1 * F * HW;
+        E2V_REQUIRE(n_shared == 0 || 2 * n_shared == n, E2V_EINVAL, "shared prefix needs n == 2 * n_shared");
+        const Act* xp = &x_in;
         const float scale = 1.0f / std::sqrt((float)D);
         E2V_REQUIRE(C % heads == 0 && D % 8 == 0, E2V_EINVAL, "attention head dim must be a multiple of 8");
         Act t;
         {
-            Act hn = gn(w.norm, x.p, C, nullptr, 0, n * F, HW, groups, 1e-6f, false);                 // :99 (per frame)
-            t = linear(w.proj_in, hn.p, C, rows);                                                     // :101-103
+            Act hn = gn(w.norm, xp->p, C, nullptr, 0, n1 * F, HW, groups, 1e-6f, false);              // :99 (per frame)
+            t = linear(w.proj_in, hn.p, C, rows1);                                                    // :101-103
         }
         {   // attn1: sparse-causal self-attention                                                      :234-243
             Act nrm = ln(w.ln1, t);
-            Act qkv = linear(w.a1_qkv, nrm.p, C, rows);
+            Act qkv = linear(w.a1_qkv, nrm.p, C, rows1);
             nrm.reset();
-            Act ao(pool(), rows, C);
+            Act ao(pool(), rows1, C);
             AttnArgs a;
             a.q = qkv.p; a.ldq = 3 * C; a.k = qkv.p + C; a.v = qkv.p + 2 * C; a.ldkv = 3 * C; a.o = ao.p; a.ldo = C;
-            a.n = n; a.F = F; a.heads = heads; a.D = D; a.Nq = HW; a.Nk = HW; a.mode = 0; a.scale = scale;
+            a.n = n1; a.F = F; a.heads = heads; a.D = D; a.Nq = HW; a.Nk = HW; a.mode = 0; a.scale = scale;
             a.bf16 = c->bf16_compute ? 1 : 0;
             flash_attention(a, s);
             qkv.reset();
-            t = linear(w.a1_out, ao.p, C, rows, t.p, C);
+            t = linear(w.a1_out, ao.p, C, rows1, t.p, C);
+        }
+        Act x2;
+        if (n_shared > 0) {                          // from here on the two halves see different conditioning
+            t = twice(t);
+            x2 = twice(*xp);
+            xp = &x2;
         }
         {   // attn2: cross-attention to the cond tokens (identical for the F frames of a sample)         :245-255
             Act nrm = ln(w.ln2, t);
@@ -610,7 +632,7 @@ struct Runner {
             qkv.reset();
             t = linear(w.at_out, ao.p, C, rows, t.p, C);
         }
-        return linear(w.proj_out, t.p, C, rows, x.p, C);                                              // :123,130
+        return linear(w.proj_out, t.p, C, rows, xp->p, C);                                            // :123,130
     }
 
     // AttentionBlock of the VAE mid block (diffusers 0.11.1): one head over H*W tokens, per image
@@ -655,9 +677,13 @@ int down_size(int x) { return (x - 1) / 2 + 1; }     // 3x3, stride 2, padding 1
 // UNet3DConditionModel.forward (unet.py:278-413), channel-last in and out
 // -----------------------------------------------------------------------------------------------------
 Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int n_t, const float* cond, int N, int F,
-                             int H, int W, int T, hipStream_t s) {
+                             int H, int W, int T, hipStream_t s, bool cfg_pair) {
     E2V_REQUIRE(unet_ready, E2V_ESTATE, "UNet weights are not finalized");
     E2V_REQUIRE(n_t == 1 || n_t == N, E2V_EINVAL, "timesteps must have 1 or N entries");
+    // cfg_pair: `sample_cl` holds N / 2 samples standing for [x ; x] (one timestep): everything before the first use of the
+    // conditioning -- conv_in, the first resnet, the first transformer block up to its cross-attention -- is computed once
+    E2V_REQUIRE(!cfg_pair || (N % 2 == 0 && n_t == 1 && !unet.down[0].attn.empty()), E2V_EINVAL, "cfg_pair needs an even batch, one timestep and a first block with attention");
+    const int N1 = cfg_pair ? N / 2 : N;
     Runner R{this, s};
     const int heads = cfg.attention_heads, groups = cfg.norm_num_groups;
     const float eps = cfg.norm_eps;
@@ -693,7 +719,9 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
     auto P_of = [&](int l) { return F * hs[l] * ws[l]; };
     auto geo_of = [&](int l) { return Geo{N * F, hs[l], ws[l]}; };
 
-    Act x = R.conv3(unet.conv_in, sample_cl, unet.conv_in.cin_pad, nullptr, 0, geo_of(0), H, W, H, W, 1, 1);   // :358
+    Act x = R.conv3(unet.conv_in, sample_cl, unet.conv_in.cin_pad, nullptr, 0, Geo{N1 * F, hs[0], ws[0]}, H, W, H, W, 1, 1);   // :358
+    Act x_shared;                                     // cfg_pair: the N / 2-sample conv_in output feeding the first resnet
+    if (cfg_pair) { x_shared = std::move(x); x = R.twice(x_shared); }
     // The skip tensors alias the running activation in the reference; here the running tensor is moved
     // into the skip list and read from there (no copy) -- `x` then points at the list's last entry.
     auto keep = [&](Act&& a, int lvl) -> const Act& {
@@ -704,8 +732,16 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
     for (int i = 0; i < 4; ++i) {                                                                    // :362-373
         const UNetW::Block& b = unet.down[i];
         for (size_t j = 0; j < b.res.size(); ++j) {
-            Act h = R.resnet(b.res[j], cur->p, cur->C, nullptr, 0, N, P_of(i), geo_of(i), groups, eps, temb_silu.p, temb_dim);
-            if (!b.attn.empty()) h = R.transformer(b.attn[j], h, N, F, hs[i] * ws[i], cond, T, heads, groups);
+            Act h;
+            if (cfg_pair && i == 0 && j == 0) {      // shared prefix: N / 2 samples through the resnet and up to attn2
+                h = R.resnet(b.res[j], x_shared.p, x_shared.C, nullptr, 0, N1, P_of(i), Geo{N1 * F, hs[0], ws[0]}, groups, eps,
+                             temb_silu.p, temb_dim);
+                x_shared.reset();
+                h = R.transformer(b.attn[j], h, N, F, hs[i] * ws[i], cond, T, heads, groups, N1);
+            } else {
+                h = R.resnet(b.res[j], cur->p, cur->C, nullptr, 0, N, P_of(i), geo_of(i), groups, eps, temb_silu.p, temb_dim);
+                if (!b.attn.empty()) h = R.transformer(b.attn[j], h, N, F, hs[i] * ws[i], cond, T, heads, groups);
+            }
             cur = &keep(std::move(h), i);
         }
         if (b.resample) {                                                                            // resnet.py:99-107
