@@ -419,6 +419,13 @@ e2v_status e2v_generate(e2v_ctx* c, const float* latents, const float* cond, con
         std::vector<int64_t> ts(steps);
         e2v_ddim_timesteps(c, steps, ts.data());                                 // :287-288
         const int64_t ratio = c->cfg.num_train_timesteps / steps;
+        // everything that depends only on (t_i, conditioning) is computed once for the whole loop
+        struct CacheGuard {
+            e2v_ctx* c;
+            ~CacheGuard() { c->step_cache_on = false; c->temb_cache.clear(); c->kv_cache.clear(); }
+        } guard{c};
+        c->build_step_caches(ts.data(), steps, embp, N, T, s);
+        c->step_cache_on = true;
         // latent_model_input = cat([latents] * 2) (:313) is not materialised: the UNet is told that its input stands for the
         // pair, and computes what the two copies share (up to the first cross-attention) once
         const bool pair = cfg_on && !c->unet.down[0].attn.empty();
@@ -431,6 +438,7 @@ e2v_status e2v_generate(e2v_ctx* c, const float* latents, const float* cond, con
                 E2V_HIP(hipMemcpyAsync(xin.p + per * B, x.p, per * B * sizeof(float), hipMemcpyDeviceToDevice, s));
                 in = xin.p;
             }
+            c->step_cache_step = i;
             Act eps = c->unet_forward_cl(in, &ts[i], 1, embp, N, F, h, w, T, s, pair);  // :317
             float co[4];
             ddim_coeffs(c, ts[i], ts[i] - ratio, co);

@@ -392,6 +392,7 @@ struct Geo { int nimg, H, W; };     // images (= n*F frames) and their map size
 struct Runner {
     e2v_ctx* c;
     hipStream_t s;
+    int res_idx = 0, tr_idx = 0;      // position in the per-generate caches (resnets with a time embedding / transformers)
     Pool& pool() { return c->pool; }
 
     void gn_ws(int samples, int P, int C) {
@@ -479,7 +480,8 @@ struct Runner {
     // gn_P rows) is applied on the way in -- only valid when winograd() says so
     Act conv3(const ConvW& w, const float* x0, int c0, const float* x1, int c1, Geo geo, int Hi, int Wi, int Ho, int Wo,
               int stride, int pad, const float* rowbias = nullptr, int rows_per_sample = 1, const float* resid = nullptr,
-              int gn_P = 0) {
+              int gn_P = 0, int rb_ld = -1) {                  // rb_ld: stride between the samples' rowbias rows (0: one row for all)
+        if (rb_ld < 0) rb_ld = w.cout;
         E2V_REQUIRE(c0 + c1 == w.cin_pad, E2V_ESHAPE, "conv: input channels do not match the weight");
         Act out(pool(), (int64_t)geo.nimg * Ho * Wo, w.cout);
         if (const int wm = winograd(w, stride, pad, Hi, Wi, Ho, Wo)) {
@@ -495,7 +497,7 @@ struct Runner {
             if (gn_P > 0) { a.gn_scsh = c->gn_scale; a.gn_P = gn_P; a.gn_silu = 1; }
             a.U = wm == 4 ? w.wino4 : w.wino; a.N = w.cout; a.out = out.p; a.ldc = w.cout; a.bias = w.b;
             if (c->x3_compute) a.U3 = wm == 4 ? w.wino4_x3 : w.wino_x3;
-            a.rowbias = rowbias; a.rb_ld = w.cout; a.rows_per_sample = rows_per_sample; a.resid = resid; a.ldr = w.cout;
+            a.rowbias = rowbias; a.rb_ld = rb_ld; a.rows_per_sample = rows_per_sample; a.resid = resid; a.ldr = w.cout;
             const int chunk = wino_chunk_images(a, c->wino_ws_floats);
             const size_t need = wino_workspace_floats(a, chunk);
             Act ws(pool(), (int64_t)((need + 1023) / 1024), 1024);
@@ -507,7 +509,7 @@ struct Runner {
         g.a0 = x0; g.c0 = c0; g.lda0 = c0; g.a1 = x1; g.c1 = c1; g.lda1 = c1;
         E2V_REQUIRE(c1 == 0 || c0 % 32 == 0, E2V_ESHAPE, "conv: the concat seam must be a multiple of 32 channels");
         g.w = w.w; g.ldw = w.ldw; g.ldw16 = w.ldw16; g.out = out.p; g.ldc = w.cout; g.bias = w.b;
-        g.rowbias = rowbias; g.rb_ld = w.cout; g.rows_per_sample = rows_per_sample;
+        g.rowbias = rowbias; g.rb_ld = rb_ld; g.rows_per_sample = rows_per_sample;
         g.resid = resid; g.ldr = w.cout;
         g.M = (int)out.rows; g.N = w.cout; g.taps = 9;
         g.bf16 = c->bf16_compute ? 1 : 0; g.w16 = w.w16;
@@ -527,18 +529,26 @@ struct Runner {
                float eps, const float* temb_silu, int temb_dim) {
         E2V_REQUIRE(c0 + c1 == w.cin, E2V_ESHAPE, "resnet: channel mismatch");
         Act tp;
+        const float* tpp = nullptr;
+        int tp_ld = w.cout;
         if (w.temb.w) {
-            E2V_REQUIRE(temb_silu != nullptr, E2V_EINVAL, "resnet needs a time embedding");
-            tp = linear(w.temb, temb_silu, temb_dim, samples);                                        // :183
+            if (c->step_cache_on) {      // e2v_generate: time_emb_proj(SiLU(emb(t))) of every step was computed up front; one row
+                tpp = c->temb_cache[res_idx++].p + (size_t)c->step_cache_step * w.cout;    // serves all samples (stride 0)
+                tp_ld = 0;
+            } else {
+                E2V_REQUIRE(temb_silu != nullptr, E2V_EINVAL, "resnet needs a time embedding");
+                tp = linear(w.temb, temb_silu, temb_dim, samples);                                    // :183
+                tpp = tp.p;
+            }
         }
         Act h1;
         if (winograd(w.c1, 1, 1, geo.H, geo.W, geo.H, geo.W)) {        // GroupNorm + SiLU applied inside the conv's input transform
             gn_stats(w.n1, x0, c0, x1, c1, samples, P, groups, eps);                                  // :177-178
-            h1 = conv3(w.c1, x0, c0, x1, c1, geo, geo.H, geo.W, geo.H, geo.W, 1, 1, tp.p, P, nullptr, P);   // :180,186
+            h1 = conv3(w.c1, x0, c0, x1, c1, geo, geo.H, geo.W, geo.H, geo.W, 1, 1, tpp, P, nullptr, P, tp_ld);   // :180,186
         } else {
             Act hn = gn(w.n1, x0, c0, x1, c1, samples, P, groups, eps, true);                        // :177-178
             h1 = conv3(w.c1, hn.p, w.cin, nullptr, 0, geo, geo.H, geo.W, geo.H, geo.W, 1, 1,          // :180,186
-                       tp.p, P);
+                       tpp, P, nullptr, 0, tp_ld);
         }
         Act sc;
         const float* resid = x0;
@@ -607,7 +617,11 @@ struct Runner {
             Act nrm = ln(w.ln2, t);
             Act q = linear(w.a2_q, nrm.p, C, rows);
             nrm.reset();
-            Act kv = linear(w.a2_kv, cond, w.a2_kv.in, (int64_t)n * T);
+            Act kv_own;                        // e2v_generate computes to_k / to_v of the conditioning once for all steps
+            const bool cached = c->step_cache_on;
+            if (!cached) kv_own = linear(w.a2_kv, cond, w.a2_kv.in, (int64_t)n * T);
+            const Act& kv = cached ? c->kv_cache[tr_idx] : kv_own;
+            ++tr_idx;
             Act ao(pool(), rows, C);
             AttnArgs a;
             a.q = q.p; a.ldq = C; a.k = kv.p; a.v = kv.p + C; a.ldkv = 2 * C; a.o = ao.p; a.ldo = C;
@@ -699,7 +713,7 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
     static_assert(sizeof(long long) == sizeof(int64_t), "int64");
     E2V_HIP(hipMemcpyAsync(d_timesteps, host_t, sizeof(int64_t) * n_t, hipMemcpyHostToDevice, s));
     Act temb_silu;
-    {
+    if (!step_cache_on) {
         Act sin(pool, N, boc0);
         timestep_sinusoid(d_timesteps, n_t, sin.p, N, boc0, cfg.flip_sin_to_cos, cfg.freq_shift, s);
         Act e1 = R.linear(unet.te1, sin.p, boc0, N);
@@ -774,6 +788,35 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
     Act out = R.conv3(unet.conv_out, hn.p, hn.C, nullptr, 0, geo_of(0), H, W, H, W, 1, 1);             // :408
     E2V_HIP(hipGetLastError());
     return out;
+}
+
+// What a denoising loop can compute once instead of once per step ("precompute all 50 x 22 vectors once per
+// run"): the time-embedding MLP and every resnet's time_emb_proj for all timesteps (one GEMM of `steps` rows per resnet
+// instead of `steps` GEMMs of N identical rows), and to_k / to_v of the conditioning of every cross-attention.  Row-wise
+// the arithmetic is the uncached one, so results are bit-identical.
+void e2v_ctx::build_step_caches(const int64_t* ts, int steps, const float* cond, int N, int T, hipStream_t s) {
+    Runner R{this, s};
+    temb_cache.clear();
+    kv_cache.clear();
+    const int boc0 = cfg.block_out_channels[0], temb_dim = boc0 * 4;
+    if (d_timesteps_cap < steps) {
+        E2V_HIP(hipStreamSynchronize(s));
+        if (d_timesteps) (void)hipFree(d_timesteps);
+        E2V_HIP(hipMalloc((void**)&d_timesteps, sizeof(long long) * steps));
+        d_timesteps_cap = steps;
+    }
+    E2V_HIP(hipMemcpyAsync(d_timesteps, ts, sizeof(int64_t) * steps, hipMemcpyHostToDevice, s));
+    Act sin(pool, steps, boc0);
+    timestep_sinusoid(d_timesteps, steps, sin.p, steps, boc0, cfg.flip_sin_to_cos, cfg.freq_shift, s);
+    Act e1 = R.linear(unet.te1, sin.p, boc0, steps);
+    silu(e1.p, e1.p, (long long)steps * temb_dim, s);
+    Act emb = R.linear(unet.te2, e1.p, temb_dim, steps);
+    silu(emb.p, emb.p, (long long)steps * temb_dim, s);
+    auto add_res = [&](const ResW& r) { if (r.temb.w) temb_cache.push_back(R.linear(r.temb, emb.p, temb_dim, steps)); };
+    auto add_tr = [&](const TransW& w) { kv_cache.push_back(R.linear(w.a2_kv, cond, w.a2_kv.in, (int64_t)N * T)); };
+    for (const auto& b : unet.down) { for (const auto& r : b.res) add_res(r); for (const auto& a : b.attn) add_tr(a); }
+    add_res(unet.mid_r0); add_tr(unet.mid_attn); add_res(unet.mid_r1);
+    for (const auto& b : unet.up) { for (const auto& r : b.res) add_res(r); for (const auto& a : b.attn) add_tr(a); }
 }
 
 // -----------------------------------------------------------------------------------------------------

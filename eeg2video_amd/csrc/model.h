@@ -100,6 +100,11 @@ struct e2v_ctx {
     float* gn_part = nullptr; size_t gn_part_floats = 0;         // GroupNorm workspaces (grown on demand)
     float* gn_scale = nullptr; size_t gn_scale_floats = 0;
     long long* d_timesteps = nullptr; int d_timesteps_cap = 0;
+    // per-generate caches of what does not depend on the latents: time_emb_proj(SiLU(emb(t_i))) of every resnet and step
+    // ([steps][cout] each, call order) and to_k / to_v of the conditioning of every transformer ([N*T][2C] each)
+    bool step_cache_on = false; int step_cache_step = 0;
+    std::vector<e2v::Act> temb_cache, kv_cache;
+    void build_step_caches(const int64_t* ts, int steps, const float* cond, int N, int T, hipStream_t s);
 
     float* dev_alloc(size_t floats);
     void expected_keys();
