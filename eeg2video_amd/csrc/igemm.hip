@@ -94,7 +94,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
                 if (vec) {
                     f32x4 y;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = acc[mi][ni][4 * g + e] * p.alpha;
+                    for (int e = 0; e < 4; ++e) y[e] = acc[mi][ni][4 * g + e];
+                    if (p.alpha != 1.0f) y *= p.alpha;          // only the VAE attention scales; a multiply per output otherwise
                     if (p.bias) y += *reinterpret_cast<const f32x4*>(p.bias + n);
                     if (rbp) y += *reinterpret_cast<const f32x4*>(rbp + n);
                     if (rsp) y += *reinterpret_cast<const f32x4*>(rsp + n);
