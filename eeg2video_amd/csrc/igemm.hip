@@ -50,7 +50,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // stores (a short-K layer -- every Winograd-domain GEMM, every attention projection -- spends a tenth of its time here).
 template <int BM, int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)[TM][TN], float* __restrict__ out, const int bm,
-                                               const int n0, const int wm, const int wn, const int lane) {
+                                               const int n0, const int wm, const int wn, const int lane, float* stage) {
     const int mrow = lane & 31;
     const int nq = (lane >> 5) * 4;
     if (p.geglu) {
@@ -78,6 +78,50 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
         return;
     }
     const bool vec = ((p.N | p.ldc | p.ldr | p.rb_ld) & 3) == 0;   // strides of absent operands are 0
+    if (vec) {
+        // Row-contiguous epilogue: the wave transposes its WM x WN accumulator block through LDS (the tile buffers are dead: every
+        // real fragment read precedes the last barrier of the k-loop) so that a 16-byte access instruction covers whole rows --
+        // 64 / (WN / 4) rows x WN floats -- instead of 32 rows x 32 bytes.  Residual reads and stores then move full 128-byte
+        // lines (+5 % on the K = 320 layers, whose output write is a tenth of their time).
+        constexpr int SLD = WN + 4;                            // padded staging row: conflict-free b128 writes and reads
+        constexpr int LPR = WN / 4;                            // lanes per staged row
+        constexpr int RPI = 64 / LPR;                          // rows per access instruction
+        float* st = stage + (size_t)(threadIdx.x >> 6) * WM * SLD;   // one staging block per wave
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = acc[mi][ni][4 * g + e];
+                    *reinterpret_cast<f32x4*>(st + (mi * 32 + mrow) * SLD + ni * 32 + 8 * g + nq) = y;
+                }
+        const int col = (lane % LPR) * 4;
+        const int n = n0 + wn * WN + col;
+        if (n >= p.N) return;                                  // N % 4 == 0: the lane's four columns are in or out together
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int i = 0; i < WM / RPI; ++i) {
+            const int row = lane / LPR + RPI * i;
+            const int m = bm * BM + wm * WM + row;
+            if (m >= p.M) continue;
+            f32x4 y = *reinterpret_cast<const f32x4*>(st + row * SLD + col);
+            if (p.alpha != 1.0f) y *= p.alpha;                 // only the VAE attention scales
+            y += bias4;
+            if (p.rowbias) y += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)(m / p.rows_per_sample) * p.rb_ld + n);
+            if (p.resid) y += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + n);
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldc + n) = y;
+        }
+        return;
+    }
+    // scalar fallback (N, or a stride, not a multiple of 4: the VAE's 3-channel conv_out)
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int m = bm * BM + wm * WM + mi * 32 + mrow;
@@ -90,30 +134,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = n0 + wn * WN + ni * 32 + 8 * g + nq;
-                if (n >= p.N) continue;
-                if (vec) {
-                    f32x4 y;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = acc[mi][ni][4 * g + e];
-                    if (p.alpha != 1.0f) y *= p.alpha;          // only the VAE attention scales; a multiply per output otherwise
-                    if (p.bias) y += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    if (rbp) y += *reinterpret_cast<const f32x4*>(rbp + n);
-                    if (rsp) y += *reinterpret_cast<const f32x4*>(rsp + n);
-                    if (p.relu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
-                    }
-                    *reinterpret_cast<f32x4*>(orow + n) = y;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (n + e >= p.N) break;
-                        float v = acc[mi][ni][4 * g + e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
-                        if (rbp) v += rbp[n + e];
-                        if (rsp) v += rsp[n + e];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        orow[n + e] = v;
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= p.N) break;
+                    float v = acc[mi][ni][4 * g + e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
+                    if (rbp) v += rbp[n + e];
+                    if (rsp) v += rsp[n + e];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    orow[n + e] = v;
                 }
             }
     }
@@ -364,7 +392,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int rbg, co
     }
     if (ks < nk) kstep(std::integral_constant<int, 0>{});
 
-    igemm_epilogue<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane);
+    igemm_epilogue<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane, reinterpret_cast<float*>(smem));
 }
 
 // =====================================================================================================
@@ -560,7 +588,7 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmArgs& p, const int rbg,
         kstep(std::integral_constant<int, 1>{});
     }
     if (ks < nk) kstep(std::integral_constant<int, 0>{});
-    igemm_epilogue<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane);
+    igemm_epilogue<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane, reinterpret_cast<float*>(smem));
 }
 
 template <int ABLX>
@@ -588,7 +616,9 @@ __global__ __launch_bounds__(256) void igemm_x3_kernel(const IgemmArgs p) {
 
 static void launch_igemm_x3(const IgemmArgs& a, int ntiles, hipStream_t s) {
     static const int ablx = [] { const char* e = std::getenv("E2V_X3_ABLATE"); return e ? std::atoi(e) : 0; }();   // timing experiments only
-    constexpr size_t smem = (size_t)3 * (128 + 128) * 80 + 128 * sizeof(unsigned);
+    // tile planes + gather table, but at least the epilogue's staging area (4 waves x 64 rows x 68 floats)
+    constexpr size_t smem = (size_t)4 * 64 * 68 * sizeof(float);
+    static_assert(smem >= (size_t)3 * (128 + 128) * 80 + 128 * sizeof(unsigned), "LDS budget");
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
