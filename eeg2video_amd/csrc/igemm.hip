@@ -57,11 +57,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
         if constexpr (TN == 2) {
             const int nb = n0 + wn * WN;                           // value columns nb .. nb+31, gate columns nb+32 .. nb+63
             if (nb + 64 <= p.N) {
+                // v * gelu(g) in the accumulator layout, staged per wave as WM x 32 and written row-contiguously (8 lanes = one
+                // 128-byte row segment) like the plain epilogue below
+                constexpr int SLD = 36;
+                float* st = stage + (size_t)(threadIdx.x >> 6) * WM * SLD;
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi) {
-                    const int m = bm * BM + wm * WM + mi * 32 + mrow;
-                    if (m >= p.M) continue;
-                    float* orow = out + (size_t)m * p.ldc + nb / 2 + nq;
+                for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * g + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -70,8 +71,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_erf(acc[mi][1][4 * g + e] * p.alpha + bg[e]);
-                        *reinterpret_cast<f32x4*>(orow + 8 * g) = y;
+                        *reinterpret_cast<f32x4*>(st + (mi * 32 + mrow) * SLD + 8 * g + nq) = y;
                     }
+                const int col = (lane & 7) * 4;
+#pragma unroll
+                for (int i = 0; i < WM / 8; ++i) {
+                    const int row = (lane >> 3) + 8 * i;
+                    const int m = bm * BM + wm * WM + row;
+                    if (m < p.M)
+                        *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldc + nb / 2 + col) = *reinterpret_cast<const f32x4*>(st + row * SLD + col);
                 }
             }
         }
