@@ -60,9 +60,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
                 // v * gelu(g) in the accumulator layout, staged per wave as WM x 32 and written row-contiguously (8 lanes = one
                 // 128-byte row segment) like the plain epilogue below
                 constexpr int SLD = 36;
-                float* st = stage + (size_t)(threadIdx.x >> 6) * WM * SLD;
+                float* st = stage + (size_t)(threadIdx.x >> 6) * 32 * SLD;
+                const int col = (lane & 7) * 4;
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
+                for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * g + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -71,15 +72,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_erf(acc[mi][1][4 * g + e] * p.alpha + bg[e]);
-                        *reinterpret_cast<f32x4*>(st + (mi * 32 + mrow) * SLD + 8 * g + nq) = y;
+                        *reinterpret_cast<f32x4*>(st + mrow * SLD + 8 * g + nq) = y;
                     }
-                const int col = (lane & 7) * 4;
 #pragma unroll
-                for (int i = 0; i < WM / 8; ++i) {
-                    const int row = (lane >> 3) + 8 * i;
-                    const int m = bm * BM + wm * WM + row;
-                    if (m < p.M)
-                        *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldc + nb / 2 + col) = *reinterpret_cast<const f32x4*>(st + row * SLD + col);
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = (lane >> 3) + 8 * i;
+                        const int m = bm * BM + wm * WM + mi * 32 + row;
+                        if (m < p.M)
+                            *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldc + nb / 2 + col) = *reinterpret_cast<const f32x4*>(st + row * SLD + col);
+                    }
                 }
             }
         }
@@ -87,16 +88,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
     }
     const bool vec = ((p.N | p.ldc | p.ldr | p.rb_ld) & 3) == 0;   // strides of absent operands are 0
     if (vec) {
-        // Row-contiguous epilogue: the wave transposes its WM x WN accumulator block through LDS (the tile buffers are dead: every
+        // Row-contiguous epilogue: the wave transposes its accumulators, 32 rows at a time, through LDS (the tile buffers are dead: every
         // real fragment read precedes the last barrier of the k-loop) so that a 16-byte access instruction covers whole rows --
         // 64 / (WN / 4) rows x WN floats -- instead of 32 rows x 32 bytes.  Residual reads and stores then move full 128-byte
         // lines (+5 % on the K = 320 layers, whose output write is a tenth of their time).
         constexpr int SLD = WN + 4;                            // padded staging row: conflict-free b128 writes and reads
         constexpr int LPR = WN / 4;                            // lanes per staged row
         constexpr int RPI = 64 / LPR;                          // rows per access instruction
-        float* st = stage + (size_t)(threadIdx.x >> 6) * WM * SLD;   // one staging block per wave
+        float* st = stage + (size_t)(threadIdx.x >> 6) * 32 * SLD;   // one 32-row staging block per wave, reused per mi
+        const int col = (lane % LPR) * 4;
+        const int n = n0 + wn * WN + col;
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+        for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -104,28 +109,24 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
                     f32x4 y;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y[e] = acc[mi][ni][4 * g + e];
-                    *reinterpret_cast<f32x4*>(st + (mi * 32 + mrow) * SLD + ni * 32 + 8 * g + nq) = y;
+                    *reinterpret_cast<f32x4*>(st + mrow * SLD + ni * 32 + 8 * g + nq) = y;
                 }
-        const int col = (lane % LPR) * 4;
-        const int n = n0 + wn * WN + col;
-        if (n >= p.N) return;                                  // N % 4 == 0: the lane's four columns are in or out together
-        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-        for (int i = 0; i < WM / RPI; ++i) {
-            const int row = lane / LPR + RPI * i;
-            const int m = bm * BM + wm * WM + row;
-            if (m >= p.M) continue;
-            f32x4 y = *reinterpret_cast<const f32x4*>(st + row * SLD + col);
-            if (p.alpha != 1.0f) y *= p.alpha;                 // only the VAE attention scales
-            y += bias4;
-            if (p.rowbias) y += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)(m / p.rows_per_sample) * p.rb_ld + n);
-            if (p.resid) y += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + n);
-            if (p.relu) {
+            for (int i = 0; i < 32 / RPI; ++i) {
+                const int row = lane / LPR + RPI * i;
+                const int m = bm * BM + wm * WM + mi * 32 + row;
+                if (m >= p.M || n >= p.N) continue;            // N % 4 == 0: the lane's four columns are in or out together
+                f32x4 y = *reinterpret_cast<const f32x4*>(st + row * SLD + col);
+                if (p.alpha != 1.0f) y *= p.alpha;             // only the VAE attention scales
+                y += bias4;
+                if (p.rowbias) y += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)(m / p.rows_per_sample) * p.rb_ld + n);
+                if (p.resid) y += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + n);
+                if (p.relu) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+                    for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+                }
+                *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldc + n) = y;
             }
-            *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldc + n) = y;
         }
         return;
     }
@@ -624,9 +625,7 @@ __global__ __launch_bounds__(256) void igemm_x3_kernel(const IgemmArgs p) {
 
 static void launch_igemm_x3(const IgemmArgs& a, int ntiles, hipStream_t s) {
     static const int ablx = [] { const char* e = std::getenv("E2V_X3_ABLATE"); return e ? std::atoi(e) : 0; }();   // timing experiments only
-    // tile planes + gather table, but at least the epilogue's staging area (4 waves x 64 rows x 68 floats)
-    constexpr size_t smem = (size_t)4 * 64 * 68 * sizeof(float);
-    static_assert(smem >= (size_t)3 * (128 + 128) * 80 + 128 * sizeof(unsigned), "LDS budget");
+    constexpr size_t smem = (size_t)3 * (128 + 128) * 80 + 128 * sizeof(unsigned);   // tile planes + gather table (epilogue staging: 34 KB)
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -644,6 +643,157 @@ static void launch_igemm_x3(const IgemmArgs& a, int ntiles, hipStream_t s) {
     if (ablx == 1) hipLaunchKernelGGL(igemm_x3_kernel<1>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
     else if (ablx == 2) hipLaunchKernelGGL(igemm_x3_kernel<2>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
     else hipLaunchKernelGGL(igemm_x3_kernel<0>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// The fp32 tile for taps == 1 (linears, Winograd-domain GEMMs: 95 % of the igemm time) with 16-k stages.  LDS drops to 40 KB
+// per workgroup, so THREE workgroups fit a CU (3 waves per SIMD instead of 2) -- more phases to hide the prologue / epilogue
+// of short-K tiles and each other's barriers behind -- at the price of a barrier and the loop bookkeeping every 32 MFMAs
+// instead of every 64.  Measured against the 32-k tile (same box): linears +5-8 %, Winograd convs +3-5 %, whole pass +3.5 %.
+// Same k order, so results are bit-identical.  E2V_IGEMM_K16=0 falls back to the 32-k tile (which direct convs still use).
+// -----------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void igemm_tile_k16(const IgemmArgs& p, const int rbg, const int n0, float* smem) {
+    const int z = p.batch > 1 ? rbg / p.nbm_per : 0;
+    const int bm = rbg - z * p.nbm_per;
+    constexpr int BKE = 16, LD = 20;                // 16 floats + 4 pad per LDS row: conflict-free b128 reads
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int RPP = NT / 4;                     // rows per loader pass (4 lanes per 64-byte row piece)
+    constexpr int AR = BM / RPP;
+    constexpr int BR = (BN + RPP - 1) / RPP;        // BN = 64: one pass, upper half of the threads idle
+    float* As = smem;                               // [2][BM][LD]
+    float* Bs = smem + 2 * BM * LD;                 // [2][BN][LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const float* __restrict__ a0 = p.a0 + (size_t)z * p.sa0;
+    const char* __restrict__ w = reinterpret_cast<const char*>(p.w + (size_t)z * p.sw + (size_t)n0 * p.ldw);
+    float* __restrict__ out = p.out + (size_t)z * p.sout;
+    const int nk = (p.c0 + BKE - 1) / BKE + (p.c1 + BKE - 1) / BKE;
+    const int q = tid & 3, r0 = tid >> 2;
+    constexpr unsigned OOB = 0x80000000u;
+    const size_t row_base = (size_t)bm * BM;
+    const float* const a0b = a0 + row_base * p.lda0;
+    const float* const a1b = p.c1 > 0 ? p.a1 + row_base * p.lda1 : a0b;
+    auto rsrc_of = [](const void* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, 0x7FFFFFF0,
+                                                 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rw = rsrc_of(w);
+    unsigned a_row[AR], b_off[BR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) a_row[i] = (bm * BM + r0 + RPP * i < p.M) ? (unsigned)(r0 + RPP * i) : ~0u;
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int r = r0 + RPP * j;
+        b_off[j] = (r < BN && n0 + r < p.N) ? (unsigned)(r * p.ldw * 4 + q * 16) : OOB;
+    }
+    int k_src = 0, k_cb = 0, cseg = p.c0, ldb = p.lda0 * 4;
+    bool done = false;
+    f32x4 rga[2][AR], rgb[2][BR];
+    auto issue_loads = [&](f32x4 (&ra)[AR], f32x4 (&rb)[BR]) {
+        const unsigned colb = (unsigned)(k_cb + q * 4) * 4u;
+        const __amdgpu_buffer_rsrc_t rsa = rsrc_of(k_src ? a1b : a0b);
+        const bool cok = (!done) & (k_cb + q * 4 < cseg);
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const unsigned rowb = __umul24(a_row[i], (unsigned)ldb) + colb;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, ((a_row[i] != ~0u) & cok) ? rowb : OOB, 0, 0));
+        }
+        const int koffb = ((k_src ? p.c0 : 0) + k_cb) * 4;
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, cok ? b_off[j] : OOB, koffb, 0));
+        const int cb2 = k_cb + BKE;
+        const bool wrap = cb2 >= cseg;
+        k_cb = wrap ? 0 : cb2;
+        const bool more = k_src == 0 && p.c1 > 0;
+        done = done || (wrap && !more);
+        k_src = (wrap && more) ? 1 : k_src;
+        cseg = k_src ? p.c1 : p.c0;
+        ldb = (k_src ? p.lda1 : p.lda0) * 4;
+    };
+    auto store_tile = [&](int buf, const f32x4 (&ra)[AR], const f32x4 (&rb)[BR]) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(As + buf * BM * LD + (r0 + RPP * i) * LD + q * 4) = ra[i];
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+            if (r0 + RPP * j < BN) *reinterpret_cast<f32x4*>(Bs + buf * BN * LD + (r0 + RPP * j) * LD + q * 4) = rb[j];
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    issue_loads(rga[0], rgb[0]);
+    issue_loads(rga[1], rgb[1]);
+    store_tile(0, rga[0], rgb[0]);
+    __syncthreads();
+    const int frag_off = (lane & 31) * LD + (lane >> 5) * 4;
+    const float* Afr = As + wm * WM * LD + frag_off;
+    const float* Bfr = Bs + wn * WN * LD + frag_off;
+    f32x4 af[2][TM], bf[2][TN];
+    auto read_frags = [&](int set, int buf, int g) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) af[set][mi] = *reinterpret_cast<const f32x4*>(Afr + buf * BM * LD + mi * 32 * LD + g * 8);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf[set][ni] = *reinterpret_cast<const f32x4*>(Bfr + buf * BN * LD + ni * 32 * LD + g * 8);
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[set][ni][e], af[set][mi][e], acc[mi][ni], 0, 0, 0);
+    };
+    read_frags(0, 0, 0);
+    auto kstep = [&](auto Pc) {
+        constexpr int P = decltype(Pc)::value;
+        issue_loads(rga[P], rgb[P]);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(1, P, 1);
+        mma(0);
+        store_tile(P ^ 1, rga[P ^ 1], rgb[P ^ 1]);
+        __syncthreads();
+        read_frags(0, P ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1);
+    };
+    int ks = 0;
+    for (; ks + 1 < nk; ks += 2) {
+        kstep(std::integral_constant<int, 0>{});
+        kstep(std::integral_constant<int, 1>{});
+    }
+    if (ks < nk) kstep(std::integral_constant<int, 0>{});
+    igemm_epilogue<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane, smem);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void igemm_k16_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem_k16[];
+    const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
+    const int nrb = rb_hi - rb_lo;
+    const int tail = min(nrb, p.tail_rb);
+    const int per1 = p.w1 + p.s1;
+    const int n1 = (nrb - tail) * per1;
+    if (loc < n1) {
+        const int r = loc / per1, j = loc - r * per1;
+        if (j < p.w1) igemm_tile_k16<128, 128, 2, 2>(p, rb_lo + r, j * 128, smem_k16);
+        else igemm_tile_k16<128, 64, 2, 2>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_k16);
+    } else {
+        const int t = loc - n1;
+        if (t >= tail * p.s2) return;
+        const int r = t / p.s2;
+        igemm_tile_k16<128, 64, 2, 2>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_k16);
+    }
 }
 
 // One launch runs a MIX of tile shapes (IgemmArgs::rb1/w1/s1/s2): row blocks [0, rb1) are cut into w1 tiles of
@@ -760,6 +910,18 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
     }
     ntiles *= 8;
     if (use_x3) { launch_igemm_x3(a, ntiles, s); return; }
+    static const int k16 = [] { const char* e = std::getenv("E2V_IGEMM_K16"); return e ? std::atoi(e) : 1; }();   // 0: the 32-k tile for everything
+    if (k16 && !use_bf16 && a.taps == 1 && abl == 0) {
+        constexpr size_t smem16 = (size_t)2 * (128 + 128) * 20 * sizeof(float);   // 40 KB (epilogue staging: 4 x 32 x 68 floats = 34 KB)
+        static bool cfgd = false;
+        if (!cfgd) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_k16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
+            cfgd = true;
+        }
+        ProfScope ps(cls, 2.0 * a.M * a.N * (double)(a.c0 + a.c1) * a.batch, 0.0, s);
+        hipLaunchKernelGGL(igemm_k16_kernel, dim3(ntiles, 1, 1), dim3(256), smem16, s, a);
+        return;
+    }
     if (use_bf16 && abl == 0) { launch_igemm<0, true>(a, ntiles, cls, s); return; }
     if (abl == 1) launch_igemm<1>(a, ntiles, cls, s);
     else if (abl == 2) launch_igemm<2>(a, ntiles, cls, s);
