@@ -918,7 +918,13 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_k16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
             cfgd = true;
         }
-        ProfScope ps(cls, 2.0 * a.M * a.N * (double)(a.c0 + a.c1) * a.batch, 0.0, s);
+        const double K = (double)(a.c0 + a.c1);
+        std::string pname = cls;
+        if (profiler().on && profiler().detail)
+            pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t1" + (a.c1 ? " cat" : "") +
+                     (a.geglu ? " geglu" : "") + (a.batch > 1 ? " b" + std::to_string(a.batch) : "") + " k16";
+        ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
+                     4.0 * a.batch * ((double)a.M * K + (double)a.N * K + (double)a.M * (a.geglu ? a.N / 2 : a.N)), s);
         hipLaunchKernelGGL(igemm_k16_kernel, dim3(ntiles, 1, 1), dim3(256), smem16, s, a);
         return;
     }

@@ -9,7 +9,7 @@ kernel class over every launch in the run.
 """
 import collections, csv, glob, json, os, sys
 
-CLASSES = [("igemm_kernel<0, false>", "igemm_f32"), ("igemm_kernel<0, true>", "igemm_bf16"),
+CLASSES = [("igemm_kernel<0, false>", "igemm_f32"), ("igemm_k16_kernel", "igemm_f32"), ("igemm_x3_kernel", "igemm_f32x3"), ("igemm_kernel<0, true>", "igemm_bf16"),
            ("flash_attn_bf16", "flash_attn_bf16"), ("flash_attn", "flash_attn"), ("wino_in", "wino_in"), ("wino4_in", "wino_in"), ("wino_out", "wino_out"), ("wino4_out", "wino_out"),
            ("gn_partial", "gn_partial"), ("gn_apply", "gn_apply"), ("layernorm", "layernorm"), ("temporal_attn", "temporal_attn")]
 
