@@ -864,7 +864,11 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
     static const int sched = [] { const char* e = std::getenv("E2V_IGEMM_SCHED"); return e ? std::atoi(e) : 1; }();   // 0: no half-size tails
     a.nbm_per = (a.M + 127) / 128;
     const int nbm = a.nbm_per * a.batch;                     // batch entries are just more row blocks (dealt to the XCDs together)
-    const int slots = 512;                                   // 2 workgroups per CU x 256 CUs
+    static const int k16 = [] { const char* e = std::getenv("E2V_IGEMM_K16"); return e ? std::atoi(e) : 1; }();   // 0: the 32-k tile for everything
+    // The tail heuristics below size rounds of 512 tiles (2 workgroups per CU).  The 16-k tile runs 3 per CU, but sizing its
+    // rounds at 768 measured worse (level-2 linears 129 -> 116 TFLOP/s, UNet step 272.9 -> 278.9 ms): the third workgroup is
+    // better spent overlapping than being planned for.
+    const int slots = 512;
     a.s2 = (a.N + 63) / 64;
     a.w1 = a.N / 128;                                        // full 128-wide column tiles
     const int rem = a.N - a.w1 * 128;
@@ -910,7 +914,6 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
     }
     ntiles *= 8;
     if (use_x3) { launch_igemm_x3(a, ntiles, s); return; }
-    static const int k16 = [] { const char* e = std::getenv("E2V_IGEMM_K16"); return e ? std::atoi(e) : 1; }();   // 0: the 32-k tile for everything
     if (k16 && !use_bf16 && a.taps == 1 && abl == 0) {
         constexpr size_t smem16 = (size_t)2 * (128 + 128) * 20 * sizeof(float);   // 40 KB (epilogue staging: 4 x 32 x 68 floats = 34 KB)
         static bool cfgd = false;
