@@ -327,3 +327,32 @@ def test_bf16_attention(eng, d, nq, f, n, mode):
         close(y.reshape(n * f, nq, c), ref, rtol=2e-2, atol=2e-2)
     finally:
         eng.set_compute_dtype("fp32")
+
+
+def test_linear_16k_and_32k_tiles_are_bit_identical(monkeypatch):
+    """The taps == 1 layers run on the 16-k-stage tile (three workgroups per CU) by default; the 32-k tile (E2V_IGEMM_K16=0) walks
+    k in the same order, so the two must agree bit for bit -- on plain, residual and GEGLU epilogues, ragged M / N included."""
+    import subprocess, sys, os
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from eeg2video_amd.engine import Engine
+from eeg2video_amd.weights import TINY_UNET, TINY_VAE
+eng = Engine(TINY_UNET, TINY_VAE, 0)
+g = torch.Generator().manual_seed(5)
+outs = []
+for m, k, n, geglu in [(1000, 320, 960, False), (130, 40, 72, False), (864, 320, 2560, True), (4097, 1280, 320, False)]:
+    x, w, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) * 0.05, torch.randn(n, generator=g)
+    r = None if geglu else torch.randn(m, n, generator=g).cuda()
+    outs.append(eng.op_linear(x.cuda(), w.cuda(), b.cuda(), r, geglu=geglu).cpu())
+torch.save(outs, sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    res = []
+    for flag in ("1", "0"):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            env = dict(os.environ, E2V_IGEMM_K16=flag)
+            subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, timeout=300)
+            res.append(torch.load(f.name))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
