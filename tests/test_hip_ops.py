@@ -356,3 +356,10 @@ torch.save(outs, sys.argv[1])
             res.append(torch.load(f.name))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("m,k,n", [(133, 64, 70), (40, 320, 3), (257, 128, 129)])
+def test_linear_width_not_multiple_of_four(eng, m, k, n):
+    """N % 4 != 0 takes the scalar epilogue (no 16-byte accesses) of the tiles."""
+    x, w, b = rnd(m, k, seed=70), rnd(n, k, seed=71, scale=0.05), rnd(n, seed=72)
+    close(eng.op_linear(x.cuda(), w.cuda(), b.cuda()), F.linear(x, w, b))
