@@ -418,7 +418,10 @@ __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int rbg, co
 // First version: one 32-k LDS stage (61 KB, 2 workgroups per CU), two barriers per stage, 150-170 TFLOP/s fp32-equivalent
 // (36-40 % of the bf16 pipe / 6).  A variant with 16-k stages, double-buffered LDS, one barrier per stage and the split
 // interleaved with the MFMAs (sched_group_barrier) measured no better (136-160): the six piece products read one 16-byte
-// LDS fragment per MFMA, 4x the fp32 tile's LDS traffic per matrix-pipe cycle -- the next step is a 128x64 per-wave tile.
+// LDS fragment per MFMA, 4x the fp32 tile's LDS traffic per matrix-pipe cycle.  A third form -- one 16-k LDS stage (37 KB),
+// streamed activation-plane fragments, 132 registers, three workgroups per CU, loads one stage ahead -- gained 3 % on K = 320
+// and lost 10-17 % on K >= 1280 (prefetch too shallow).  tools/micro/lds_mfma.hip: the fragment-read + MFMA core alone
+// sustains 350-410 TFLOP/s fp32-equivalent, so the loss is in the load / split / store phases around it.
 // =====================================================================================================
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
