@@ -686,7 +686,7 @@ e2v_status e2v_op_attention(e2v_ctx* c, const float* q, int ldq, const float* k,
         E2V_REQUIRE(mode == 1 || Nq == Nk, E2V_ESHAPE, "self-attention needs Nq == Nk");
         AttnArgs a;
         a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv; a.o = o; a.ldo = ldo; a.n = n; a.F = F; a.heads = heads; a.D = D;
-        a.Nq = Nq; a.Nk = Nk; a.mode = mode; a.scale = scale; a.bf16 = c->bf16_compute ? 1 : 0;
+        a.Nq = Nq; a.Nk = Nk; a.mode = mode; a.scale = scale; a.bf16 = c->bf16_compute ? 1 : 0; a.x3 = c->x3_compute ? 1 : 0;
         flash_attention(a, S(stream));
         E2V_HIP(hipGetLastError());
     });

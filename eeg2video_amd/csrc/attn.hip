@@ -465,6 +465,284 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const AttnArgs p) 
     }
 }
 
+// =====================================================================================================
+// f32x3 attention (opt-in, AttnArgs::x3; see igemm.hip / DESIGN 3.7): both matmuls as six bf16-piece MFMAs over operands
+// split EXACTLY into three bf16 pieces by truncation -- Q once per wave, K and V on their way into LDS (three planes each),
+// the probabilities in registers.  Scores and outputs carry fp32-level error; what changes is the pipe: 42 bf16 MFMAs
+// (1344 cycles) per key tile instead of 36 fp32 ones (2304), on a pipe that leaves the vector ALUs to the softmax.
+// Same data flow as flash_attn_bf16_kernel: S^T = K Q^T with the query on the lane, P^T registers are the B operand.
+// =====================================================================================================
+__device__ __forceinline__ void split3(float x, unsigned& b1, unsigned& b2, unsigned& b3) {
+    b1 = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+    const float r1 = x - __builtin_bit_cast(float, b1);
+    b2 = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+    b3 = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, b2));
+}
+typedef unsigned au32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
+
+template <int D>
+__global__ __launch_bounds__(256) void flash_attn_x3_kernel(const AttnArgs p) {
+    constexpr int DP = (D + 15) / 16 * 16;
+    constexpr int KS = DP / 16;
+    constexpr int KROW = DP * 2 + 16;
+    constexpr int T = (D + 31) / 32;
+    constexpr int VROW = 72;
+    constexpr int KBYTES = 32 * KROW, VBYTES = T * 32 * VROW;       // one plane
+    constexpr int STAGE = (3 * (KBYTES + VBYTES) + 15) / 16 * 16;
+    constexpr int DQ = D / 4;
+    constexpr int NF4 = 32 * DQ;
+    constexpr int LPT = (NF4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem_x[];   // [2][3 x K rows | 3 x V^T rows]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int sf = blockIdx.z;
+    const int smp = sf / p.F, f = sf - smp * p.F;
+    const int head = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const bool active = q0 < p.Nq;
+
+    int nseg = 1;
+    size_t kvbase[2];
+    if (p.mode == 0) {
+        kvbase[0] = (size_t)(smp * p.F) * p.Nk;
+        kvbase[1] = (size_t)(smp * p.F + (f > 0 ? f - 1 : 0)) * p.Nk;
+        nseg = f >= 2 ? 2 : 1;
+    } else {
+        kvbase[0] = kvbase[1] = (size_t)smp * p.Nk;
+    }
+    const int tps = (p.Nk + 31) / 32;
+    const int ntiles = nseg * tps;
+
+    for (int i = tid * 16; i < 2 * STAGE; i += 256 * 16)            // pad columns / rows are never rewritten
+        *reinterpret_cast<f32x4*>(smem_x + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    au32x4 qf[3][KS];                                               // three planes of the lane's 8 k of every 16-step
+    {
+        const int qrow = min(q0 + j, p.Nq - 1);
+        const float* qp = p.q + ((size_t)sf * p.Nq + qrow) * p.ldq + head * D;
+        const float c = p.scale * 1.44269504088896340736f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k0 = 16 * s + 8 * h;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            if (k0 < D) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(qp + k0) * c;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(qp + k0 + 4) * c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned a1, a2, a3, b1, b2, b3;
+                split3(v[2 * e], a1, a2, a3);
+                split3(v[2 * e + 1], b1, b2, b3);
+                qf[0][s][e] = (a1 >> 16) | (b1 & 0xFFFF0000u);
+                qf[1][s][e] = (a2 >> 16) | (b2 & 0xFFFF0000u);
+                qf[2][s][e] = (a3 >> 16) | (b3 & 0xFFFF0000u);
+            }
+        }
+    }
+    __syncthreads();
+
+    constexpr unsigned OOB = 0x80000000u;
+    auto rsrc_of = [](const void* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, 0x7FFFFFF0,
+                                                 0x00020000);
+    };
+    int ld_row[LPT], ld_c4[LPT];
+    unsigned ld_off[LPT];
+#pragma unroll
+    for (int e = 0; e < LPT; ++e) {
+        const int idx = tid + 256 * e;
+        const int row = idx / DQ, c4 = idx - row * DQ;
+        ld_row[e] = row; ld_c4[e] = c4;
+        ld_off[e] = idx < NF4 ? (unsigned)(row * p.ldkv + c4 * 4) * 4u : OOB;
+    }
+    f32x4 kreg[LPT], vreg[LPT];
+    auto load_tile = [&](int tt) {
+        const int seg = tt / tps;
+        const int key0 = (tt - seg * tps) * 32;
+        const size_t first = (kvbase[seg] + key0) * p.ldkv + head * D;
+        const __amdgpu_buffer_rsrc_t rk = rsrc_of(p.k + first), rv = rsrc_of(p.v + first);
+        const int left = p.Nk - key0;
+#pragma unroll
+        for (int e = 0; e < LPT; ++e) {
+            unsigned off = ld_off[e];
+            if (left < 32) off = ld_row[e] < left ? off : OOB;
+            kreg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
+            vreg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* Kl = smem_x + buf * STAGE;
+        char* Vl = Kl + 3 * KBYTES;
+#pragma unroll
+        for (int e = 0; e < LPT; ++e) {
+            if (tid + 256 * e < NF4) {
+                const int row = ld_row[e], c4 = ld_c4[e];
+                unsigned k1[4], k2[4], k3[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) split3(kreg[e][x], k1[x], k2[x], k3[x]);
+                char* kd = Kl + row * KROW + c4 * 8;
+                *reinterpret_cast<au32x2*>(kd) = au32x2{(k1[0] >> 16) | (k1[1] & 0xFFFF0000u), (k1[2] >> 16) | (k1[3] & 0xFFFF0000u)};
+                *reinterpret_cast<au32x2*>(kd + KBYTES) = au32x2{(k2[0] >> 16) | (k2[1] & 0xFFFF0000u), (k2[2] >> 16) | (k2[3] & 0xFFFF0000u)};
+                *reinterpret_cast<au32x2*>(kd + 2 * KBYTES) = au32x2{(k3[0] >> 16) | (k3[1] & 0xFFFF0000u), (k3[2] >> 16) | (k3[3] & 0xFFFF0000u)};
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {                           // transpose: [value column][key]
+                    unsigned v1, v2, v3;
+                    split3(vreg[e][x], v1, v2, v3);
+                    char* vd = Vl + (c4 * 4 + x) * VROW + row * 2;
+                    *reinterpret_cast<unsigned short*>(vd) = (unsigned short)(v1 >> 16);
+                    *reinterpret_cast<unsigned short*>(vd + VBYTES) = (unsigned short)(v2 >> 16);
+                    *reinterpret_cast<unsigned short*>(vd + 2 * VBYTES) = (unsigned short)(v3 >> 16);
+                }
+            }
+        }
+    };
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    // (first piece index, second piece index) of the six products, smallest first
+    constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+    for (int tt = 0; tt < ntiles; ++tt) {
+        const int buf = tt & 1;
+        if (tt + 1 < ntiles) load_tile(tt + 1);
+        const int seg_c = tt / tps;
+        const int key0 = (tt - seg_c * tps) * 32;
+        if (active) {
+            const char* Kl = smem_x + buf * STAGE;
+            const char* Vl = Kl + 3 * KBYTES;
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            const char* kp = Kl + j * KROW + h * 16;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                abf16x8 kf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const abf16x8*>(kp + pl * KBYTES + s * 32);
+#pragma unroll
+                for (int t6 = 0; t6 < 6; ++t6)
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[TA[t6]], __builtin_bit_cast(abf16x8, qf[TB[t6]][s]), st, 0, 0, 0);
+            }
+            if (key0 + 32 > p.Nk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= p.Nk) st[r] = -INFINITY;
+                }
+            }
+            float mt = st[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mt = __builtin_fmaxf(mt, st[r]);
+            mt = __builtin_fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = __builtin_fmaxf(m_i, mt);
+            const bool moved = __any(m_new > m_i);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
+                ps += st[r];
+            }
+            float alpha = 1.0f;
+            if (moved) {
+                alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+                l_i *= alpha;
+            }
+            l_i += ps;
+            m_i = m_new;
+            au32x4 pf[3][2];                     // P^T pieces: registers 8s..8s+7 are k-step s as they stand
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned a1, a2, a3, b1, b2, b3;
+                    split3(st[8 * s + 2 * e], a1, a2, a3);
+                    split3(st[8 * s + 2 * e + 1], b1, b2, b3);
+                    pf[0][s][e] = (a1 >> 16) | (b1 & 0xFFFF0000u);
+                    pf[1][s][e] = (a2 >> 16) | (b2 & 0xFFFF0000u);
+                    pf[2][s][e] = (a3 >> 16) | (b3 & 0xFFFF0000u);
+                }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if (moved) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+                }
+                const char* vrow = Vl + min(t * 32 + j, D - 1) * VROW + h * 8;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    abf16x8 vf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const abf16x4 lo = *reinterpret_cast<const abf16x4*>(vrow + pl * VBYTES + s * 32);
+                        const abf16x4 hi = *reinterpret_cast<const abf16x4*>(vrow + pl * VBYTES + s * 32 + 16);
+                        vf[pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                    for (int t6 = 0; t6 < 6; ++t6)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[TA[t6]], __builtin_bit_cast(abf16x8, pf[TB[t6]][s]), acc[t], 0, 0, 0);
+                }
+            }
+        }
+        if (tt + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_i + __shfl_xor(l_i, 32);
+    if (active && q0 + j < p.Nq) {
+        const float inv = 1.0f / l_tot;
+        float* op = p.o + ((size_t)sf * p.Nq + q0 + j) * p.ldo + head * D;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int dv = t * 32 + 8 * rg + 4 * h;
+                if (dv < D) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[t][rg * 4 + e] * inv;
+                    *reinterpret_cast<f32x4*>(op + dv) = o;
+                }
+            }
+    }
+}
+template <int D>
+static void launch_flash_x3(const AttnArgs& a, hipStream_t s) {
+    static bool configured = false;
+    constexpr int DP = (D + 15) / 16 * 16;
+    constexpr size_t stage = ((size_t)3 * (32 * (DP * 2 + 16) + ((D + 31) / 32) * 32 * 72) + 15) / 16 * 16;
+    constexpr size_t smem = 2 * stage;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_x3_kernel<D>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        configured = true;
+    }
+    dim3 grid((a.Nq + 127) / 128, a.heads, a.n * a.F);
+    const double nk = a.mode == 0 ? 2.0 * a.Nk : (double)a.Nk;
+    const double probs = (double)a.n * a.F * a.heads;
+    ProfScope ps(a.mode == 0 ? "flash_attn_f32x3_sparse_causal" : "flash_attn_f32x3_cross", 4.0 * probs * a.Nq * nk * D,
+                 4.0 * probs * D * (2.0 * a.Nq + 2.0 * (a.mode == 0 ? a.Nk : (double)a.Nk / a.F)), s);
+    hipLaunchKernelGGL((flash_attn_x3_kernel<D>), grid, dim3(256), smem, s, a);
+}
+
 template <int D>
 static void launch_flash_bf16(const AttnArgs& a, hipStream_t s) {
     static bool configured = false;
@@ -502,6 +780,18 @@ static void launch_flash(const AttnArgs& a, hipStream_t s) {
 }
 
 void flash_attention(const AttnArgs& a, hipStream_t s) {
+    if (a.x3 && !a.bf16) {
+        switch (a.D) {
+            case 8: launch_flash_x3<8>(a, s); return;
+            case 16: launch_flash_x3<16>(a, s); return;
+            case 32: launch_flash_x3<32>(a, s); return;
+            case 40: launch_flash_x3<40>(a, s); return;
+            case 64: launch_flash_x3<64>(a, s); return;
+            case 80: launch_flash_x3<80>(a, s); return;
+            case 160: launch_flash_x3<160>(a, s); return;
+            default: break;
+        }
+    }
     if (a.bf16) {
         switch (a.D) {
             case 8: launch_flash_bf16<8>(a, s); break;

@@ -117,6 +117,7 @@ struct AttnArgs {
                        // 1: keys shared by all frames of a sample (cross-attention to the 77 cond tokens)
     float scale = 1.f;
     int bf16 = 0;      // 1: bf16 MFMA for QK^T and PV (fp32 softmax / accumulate)
+    int x3 = 0;        // 1: fp32-equivalent QK^T and PV from exactly split bf16 pieces (six MFMAs per product, f32x3 mode)
 };
 void flash_attention(const AttnArgs& a, hipStream_t s);
 // temporal self-attention over the F frames of every pixel (attention.py:261-267), qkv = [n*F*HW][3C]

@@ -603,6 +603,7 @@ struct Runner {
             a.q = qkv.p; a.ldq = 3 * C; a.k = qkv.p + C; a.v = qkv.p + 2 * C; a.ldkv = 3 * C; a.o = ao.p; a.ldo = C;
             a.n = n1; a.F = F; a.heads = heads; a.D = D; a.Nq = HW; a.Nk = HW; a.mode = 0; a.scale = scale;
             a.bf16 = c->bf16_compute ? 1 : 0;
+            a.x3 = c->x3_compute ? 1 : 0;
             flash_attention(a, s);
             qkv.reset();
             t = linear(w.a1_out, ao.p, C, rows1, t.p, C);
@@ -627,6 +628,7 @@ struct Runner {
             a.q = q.p; a.ldq = C; a.k = kv.p; a.v = kv.p + C; a.ldkv = 2 * C; a.o = ao.p; a.ldo = C;
             a.n = n; a.F = F; a.heads = heads; a.D = D; a.Nq = HW; a.Nk = T; a.mode = 1; a.scale = scale;
             a.bf16 = c->bf16_compute ? 1 : 0;
+            a.x3 = c->x3_compute ? 1 : 0;
             flash_attention(a, s);
             t = linear(w.a2_out, ao.p, C, rows, t.p, C);
         }
