@@ -471,6 +471,9 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const AttnArgs p) 
 // the probabilities in registers.  Scores and outputs carry fp32-level error; what changes is the pipe: 42 bf16 MFMAs
 // (1344 cycles) per key tile instead of 36 fp32 ones (2304), on a pipe that leaves the vector ALUs to the softmax.
 // Same data flow as flash_attn_bf16_kernel: S^T = K Q^T with the query on the lane, P^T registers are the B operand.
+// Measured and not adopted (level 0, 8.0-8.6 ms as it stands vs 9.7 fp32): splitting K / V once in a pre-pass instead of in
+// every query block (kernel 8.8 ms + 0.3 ms pre-pass: the split is not the bottleneck), and a three-stage software pipeline
+// issuing the next tile's score MFMAs under this tile's softmax with sched_group_barrier interleaving (8.9 ms).
 // =====================================================================================================
 __device__ __forceinline__ void split3(float x, unsigned& b1, unsigned& b2, unsigned& b3) {
     b1 = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
