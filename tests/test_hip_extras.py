@@ -57,3 +57,16 @@ def test_frames_to_uint8_bit_exact(eng):
     v[0, 0, 0, 0, :4] = torch.tensor([0.0, 1.0, 0.999999, 1.0 / 255.0])
     out = eng.frames_to_uint8(v.cuda())
     assert out.dtype == torch.uint8 and np.array_equal(out.cpu().numpy(), frames_to_uint8(v))
+
+
+def test_end_to_end_example_runs_on_the_tiny_configuration(monkeypatch):
+    """examples/inference_eeg2video.py: semantic predictor -> DANA noise -> TuneAVideoPipeline.__call__ -> uint8 frames, the flow
+    of the reference's inference script, on the tiny configuration."""
+    import importlib.util, os, sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "inference_eeg2video.py")
+    spec = importlib.util.spec_from_file_location("e2v_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["inference_eeg2video.py", "--tiny", "--steps", "3", "--clips", "2"])
+    video = mod.main()
+    assert tuple(video.shape) == (2, 3, 3, 32, 48)
