@@ -61,7 +61,14 @@ void make_alphas(e2v_ctx* c) {
     }
 }
 
-hipStream_t S(e2v_stream s) { return static_cast<hipStream_t>(s); }
+// Every entry point that enqueues work names its stream through here: the ctx's workspace cache hands a freed block to
+// the next launch on the assumption that launches of one ctx are stream-ordered, so when a call arrives on a DIFFERENT
+// stream than the previous one, the new stream is first made to wait for everything the old one was given.
+hipStream_t S(e2v_ctx* c, e2v_stream s) {
+    hipStream_t hs = static_cast<hipStream_t>(s);
+    c->enter_stream(hs);
+    return hs;
+}
 
 }  // namespace
 
@@ -100,6 +107,8 @@ e2v_status e2v_create(const e2v_config* cfg, int device, e2v_ctx** out) {
             E2V_REQUIRE(cfg->block_out_channels[i] % cfg->norm_num_groups == 0 && cfg->block_out_channels[i] % 32 == 0 &&
                             (cfg->block_out_channels[i] / cfg->attention_heads) % 8 == 0,
                         E2V_EINVAL, "block_out_channels must be multiples of 32, of norm_num_groups and of 8*heads");
+            E2V_REQUIRE(flash_attention_supports(cfg->block_out_channels[i] / cfg->attention_heads), E2V_EINVAL,
+                        "block_out_channels / attention_heads must be a head dim with a kernel instance (8, 16, 32, 40, 64, 80, 160)");
             E2V_REQUIRE(cfg->vae_block_out_channels[i] % cfg->vae_norm_num_groups == 0 && cfg->vae_block_out_channels[i] % 4 == 0,
                         E2V_EINVAL, "vae_block_out_channels must be multiples of 4 and of vae_norm_num_groups");
         }
@@ -130,6 +139,8 @@ void e2v_destroy(e2v_ctx* c) {
     (void)hipDeviceSynchronize();
     for (auto& kv : c->raw) if (kv.second.d) (void)hipFree(kv.second.d);
     for (float* p : c->owned) (void)hipFree(p);
+    for (auto& part : c->owned_part) for (float* p : part) (void)hipFree(p);
+    if (c->stream_ev) (void)hipEventDestroy(c->stream_ev);
     if (c->gn_part) (void)hipFree(c->gn_part);
     if (c->gn_scale) (void)hipFree(c->gn_scale);
     if (c->d_timesteps) (void)hipFree(c->d_timesteps);
@@ -204,13 +215,21 @@ e2v_status e2v_set_alphas_cumprod(e2v_ctx* c, const float* t, int n) {
     return E2V_OK;
 }
 
+e2v_status e2v_set_ddim_schedule(e2v_ctx* c, const float* t, int n, int steps_offset) {
+    if (!c || !t || n <= 0 || steps_offset < 0 || steps_offset >= n) return E2V_EINVAL;
+    c->cfg.num_train_timesteps = n;
+    c->cfg.steps_offset = steps_offset;
+    c->alphas.assign(t, t + n);
+    return E2V_OK;
+}
+
 // ---- SURVEY 8(f) rows ---------------------------------------------------------------------------------------
 e2v_status e2v_semantic_predict(e2v_ctx* c, const float* eeg, int B, float* out, e2v_stream stream) {
     if (!c) return E2V_EINVAL;
     return guarded(c, [&] {
         E2V_REQUIRE(c->sem_ready, E2V_ESTATE, "semantic predictor weights are not finalized");
         E2V_REQUIRE(eeg && out && B > 0, E2V_EINVAL, "bad arguments");
-        hipStream_t s = S(stream);
+        hipStream_t s = S(c, stream);
         Act x(c->pool, B, c->sem_in_pad);
         pad_cols(eeg, c->cfg.sem_in_features, x.p, c->sem_in_pad, B, s);
         for (size_t i = 0; i < c->sem.size(); ++i) {              // Linear -> ReLU ... -> Linear (train_semantic_predictor.py:14-28)
@@ -253,7 +272,7 @@ e2v_status e2v_dana_noise(e2v_ctx* c, const float* x0, const float* ed, const fl
             coef[2 * b] = std::sqrt(ac[(size_t)host_t[b]]);
             coef[2 * b + 1] = std::sqrt(1.f - ac[(size_t)host_t[b]]);
         }
-        hipStream_t s = S(stream);
+        hipStream_t s = S(c, stream);
         Act dc(c->pool, B, 2);
         E2V_HIP(hipMemcpyAsync(dc.p, coef.data(), coef.size() * sizeof(float), hipMemcpyHostToDevice, s));
         dana_noise(x0, ed, es, dc.p, std::sqrt(1.f - dyn_beta), std::sqrt(dyn_beta), out, B, F, C, H * W, s);
@@ -265,7 +284,7 @@ e2v_status e2v_frames_to_uint8(e2v_ctx* c, const float* videos, uint8_t* out, in
     if (!c) return E2V_EINVAL;
     return guarded(c, [&] {
         E2V_REQUIRE(videos && out && count >= 0, E2V_EINVAL, "bad arguments");
-        frames_to_u8(videos, out, count, S(stream));
+        frames_to_u8(videos, out, count, S(c, stream));
         E2V_HIP(hipGetLastError());
     });
 }
@@ -310,7 +329,7 @@ e2v_status e2v_unet_forward(e2v_ctx* c, const float* sample, const int64_t* host
     return guarded(c, [&] {
         E2V_REQUIRE(sample && host_t && cond && out, E2V_EINVAL, "null argument");
         E2V_REQUIRE(N > 0 && F > 0 && H > 0 && W > 0 && T > 0, E2V_ESHAPE, "non-positive dimension");
-        hipStream_t s = S(stream);
+        hipStream_t s = S(c, stream);
         const int Cin = c->cfg.in_channels, Cout = c->cfg.out_channels;
         const int FHW = F * H * W;
         Act x(c->pool, (int64_t)N * FHW, Cin);
@@ -338,7 +357,7 @@ e2v_status e2v_ddim_cfg_step(e2v_ctx* c, const float* eu, const float* ec, const
         E2V_REQUIRE(eu && x && xo && count >= 0, E2V_EINVAL, "null argument");
         float co[4];
         ddim_coeffs(c, t, t_prev, co);
-        ddim_cfg_step(eu, ec, x, xo, count, g, co[0], co[1], co[2], co[3], S(stream));
+        ddim_cfg_step(eu, ec, x, xo, count, g, co[0], co[1], co[2], co[3], S(c, stream));
         E2V_HIP(hipGetLastError());
     });
 }
@@ -359,7 +378,7 @@ e2v_status e2v_vae_decode(e2v_ctx* c, const float* latents, int B, int F, int h,
     return guarded(c, [&] {
         E2V_REQUIRE(latents && videos, E2V_EINVAL, "null argument");
         E2V_REQUIRE(B > 0 && F > 0 && h > 0 && w > 0, E2V_ESHAPE, "non-positive dimension");
-        hipStream_t s = S(stream);
+        hipStream_t s = S(c, stream);
         const int lat = c->cfg.vae_latent_channels;
         Act z(c->pool, (int64_t)B * F * h * w, lat);
         ncfhw_to_cl(latents, z.p, B, lat, lat, F * h * w, post ? (float)(1.0 / c->cfg.vae_scaling_factor) : 1.0f, s);   // :177
@@ -373,7 +392,7 @@ e2v_status e2v_vae_encode(e2v_ctx* c, const float* images, int n, int H, int W, 
     return guarded(c, [&] {
         E2V_REQUIRE(images && mean && logvar, E2V_EINVAL, "null argument");
         E2V_REQUIRE(n > 0 && H % 8 == 0 && W % 8 == 0 && H > 0 && W > 0, E2V_ESHAPE, "H and W must be positive multiples of 8");
-        hipStream_t s = S(stream);
+        hipStream_t s = S(c, stream);
         const int Cimg = c->cfg.vae_in_channels, Cp = c->vae.enc_in.cin_pad, lat = c->cfg.vae_latent_channels;
         Act x(c->pool, (int64_t)n * H * W, Cp);
         ncfhw_to_cl(images, x.p, n, Cimg, Cp, H * W, 1.0f, s);
@@ -397,7 +416,7 @@ e2v_status e2v_generate(e2v_ctx* c, const float* latents, const float* cond, con
         E2V_REQUIRE(eta == 0.0f, E2V_EINVAL, "only the deterministic DDIM update (eta = 0) is implemented");
         const bool cfg_on = guidance > 1.0f;                                     // pipeline_tuneeeg2video.py:281
         E2V_REQUIRE(!cfg_on || (uncond && (Bu == 1 || Bu == B)), E2V_EINVAL, "uncond must have batch 1 or B");
-        hipStream_t s = S(stream);
+        hipStream_t s = S(c, stream);
         const int Cl = c->cfg.in_channels, D = c->cfg.cross_attention_dim;
         const int P = F * h * w;
         const size_t per = (size_t)P * Cl;
@@ -465,7 +484,7 @@ e2v_status e2v_cfg_combine(e2v_ctx* c, const float* eu, const float* ec, float g
     if (!c) return E2V_EINVAL;
     return guarded(c, [&] {
         E2V_REQUIRE(eu && ec && out && count >= 0, E2V_EINVAL, "null argument");
-        cfg_combine(eu, ec, g, out, count, S(stream));
+        cfg_combine(eu, ec, g, out, count, S(c, stream));
         E2V_HIP(hipGetLastError());
     });
 }
@@ -475,7 +494,7 @@ e2v_status e2v_lincomb(e2v_ctx* c, int n, const float* const* xs, const float* c
     return guarded(c, [&] {
         E2V_REQUIRE(n >= 1 && n <= 5 && xs && coefs && out && count >= 0, E2V_EINVAL, "lincomb takes 1..5 terms");
         for (int k = 0; k < n; ++k) E2V_REQUIRE(xs[k] != nullptr, E2V_EINVAL, "null term");
-        lincomb(n, xs, coefs, out, count, S(stream));
+        lincomb(n, xs, coefs, out, count, S(c, stream));
         E2V_HIP(hipGetLastError());
     });
 }
@@ -502,7 +521,7 @@ e2v_status e2v_ddim_next_step(e2v_ctx* c, const float* eps, const float* x, floa
         E2V_REQUIRE(eps && x && xo && count >= 0, E2V_EINVAL, "null argument");
         float co[4];
         ddim_next_coeffs(c, t, num_inference_steps, co);
-        ddim_cfg_step(eps, nullptr, x, xo, count, 1.0f, co[0], co[1], co[2], co[3], S(stream));   // :63-65, same form as step()
+        ddim_cfg_step(eps, nullptr, x, xo, count, 1.0f, co[0], co[1], co[2], co[3], S(c, stream));   // :63-65, same form as step()
         E2V_HIP(hipGetLastError());
     });
 }
@@ -514,7 +533,7 @@ e2v_status e2v_ddim_invert(e2v_ctx* c, const float* latents, const float* cond, 
         E2V_REQUIRE(latents && cond && (all_latents || final_latent), E2V_EINVAL, "null argument");
         E2V_REQUIRE(B > 0 && F > 0 && h > 0 && w > 0 && T > 0, E2V_ESHAPE, "non-positive dimension");
         E2V_REQUIRE(num_inv_steps > 0 && num_inv_steps <= c->cfg.num_train_timesteps, E2V_EINVAL, "num_inv_steps out of range");
-        hipStream_t s = S(stream);
+        hipStream_t s = S(c, stream);
         const int Cl = c->cfg.in_channels;
         const int P = F * h * w;
         const size_t per = (size_t)B * P * Cl;
@@ -545,7 +564,7 @@ e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, 
     if (!c) return E2V_EINVAL;
     return guarded(c, [&] {
         E2V_REQUIRE(x0 && w_oihw && out && c0 % 4 == 0 && c1 % 4 == 0 && c0 > 0, E2V_EINVAL, "bad conv arguments");
-        hipStream_t s = S(stream);
+        hipStream_t s = S(c, stream);
         const int cin = c0 + c1;
         E2V_REQUIRE(c1 == 0 || c0 % 32 == 0, E2V_ESHAPE, "conv: the concat seam must be a multiple of 32 channels");
         const bool wino_shape = stride == 1 && pad_lo == 1 && Hi == Ho && Wi == Wo && cout % 4 == 0 && !c->bf16_compute;
@@ -611,7 +630,7 @@ e2v_status e2v_op_linear(e2v_ctx* c, const float* x, int ldx, int64_t M, int K, 
     if (!c) return E2V_EINVAL;
     return guarded(c, [&] {
         E2V_REQUIRE(x && w && out && K % 4 == 0 && ldx % 4 == 0, E2V_EINVAL, "bad linear arguments");
-        hipStream_t s = S(stream);
+        hipStream_t s = S(c, stream);
         IgemmArgs g;
         g.a0 = x; g.c0 = K; g.lda0 = ldx; g.ldw = K; g.out = out; g.M = (int)M; g.taps = 1; g.resid = resid;
         Act wp, bp;
@@ -653,7 +672,7 @@ e2v_status e2v_op_groupnorm(e2v_ctx* c, const float* x0, int c0, const float* x1
     return guarded(c, [&] {
         const int C = c0 + c1;
         E2V_REQUIRE(x0 && gamma && beta && out && c0 % 4 == 0 && c1 % 4 == 0 && C % groups == 0, E2V_EINVAL, "bad groupnorm arguments");
-        hipStream_t s = S(stream);
+        hipStream_t s = S(c, stream);
         Act part(c->pool, (int64_t)samples * groupnorm_chunks(P), C * 2);
         Act sc(c->pool, samples, C * 2);
         GroupNormArgs a;
@@ -670,7 +689,7 @@ e2v_status e2v_op_layernorm(e2v_ctx* c, const float* x, int64_t rows, int C, con
     if (!c) return E2V_EINVAL;
     return guarded(c, [&] {
         E2V_REQUIRE(x && gamma && beta && out && C % 4 == 0 && C <= 1280, E2V_EINVAL, "bad layernorm arguments");
-        layernorm(x, C, gamma, beta, out, C, (int)rows, C, eps, S(stream));
+        layernorm(x, C, gamma, beta, out, C, (int)rows, C, eps, S(c, stream));
         E2V_HIP(hipGetLastError());
     });
 }
@@ -687,7 +706,7 @@ e2v_status e2v_op_attention(e2v_ctx* c, const float* q, int ldq, const float* k,
         AttnArgs a;
         a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv; a.o = o; a.ldo = ldo; a.n = n; a.F = F; a.heads = heads; a.D = D;
         a.Nq = Nq; a.Nk = Nk; a.mode = mode; a.scale = scale; a.bf16 = c->bf16_compute ? 1 : 0; a.x3 = c->x3_compute ? 1 : 0;
-        flash_attention(a, S(stream));
+        flash_attention(a, S(c, stream));
         E2V_HIP(hipGetLastError());
     });
 }
@@ -698,19 +717,19 @@ e2v_status e2v_op_temporal_attention(e2v_ctx* c, const float* qkv, float* out, i
     return guarded(c, [&] {
         E2V_REQUIRE(qkv && out && F <= 8 && D % 4 == 0, E2V_EINVAL, "bad temporal attention arguments");
         const int C = heads * D;
-        temporal_attention(qkv, 3 * C, out, C, n, F, HW, heads, D, scale, S(stream));
+        temporal_attention(qkv, 3 * C, out, C, n, F, HW, heads, D, scale, S(c, stream));
         E2V_HIP(hipGetLastError());
     });
 }
 
 e2v_status e2v_op_to_channels_last(e2v_ctx* c, const float* in, float* out, int n, int C, int Cpad, int FHW, e2v_stream stream) {
     if (!c) return E2V_EINVAL;
-    return guarded(c, [&] { ncfhw_to_cl(in, out, n, C, Cpad, FHW, 1.0f, S(stream)); E2V_HIP(hipGetLastError()); });
+    return guarded(c, [&] { ncfhw_to_cl(in, out, n, C, Cpad, FHW, 1.0f, S(c, stream)); E2V_HIP(hipGetLastError()); });
 }
 
 e2v_status e2v_op_from_channels_last(e2v_ctx* c, const float* in, int ld, float* out, int n, int C, int FHW, e2v_stream stream) {
     if (!c) return E2V_EINVAL;
-    return guarded(c, [&] { cl_to_ncfhw(in, ld, out, n, C, FHW, 1.f, 0.f, 0, 0.f, 0.f, S(stream)); E2V_HIP(hipGetLastError()); });
+    return guarded(c, [&] { cl_to_ncfhw(in, ld, out, n, C, FHW, 1.f, 0.f, 0, 0.f, 0.f, S(c, stream)); E2V_HIP(hipGetLastError()); });
 }
 
 }  // extern "C"

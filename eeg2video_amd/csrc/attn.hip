@@ -14,6 +14,7 @@
 // trip, no transposes.  K and V tiles (32 keys) are staged through LDS, double-buffered.
 #include "kernels.h"
 #include "prof.h"
+#include "runtime.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -782,7 +783,18 @@ static void launch_flash(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((flash_attn_kernel<D>), grid, dim3(256), smem, s, a);
 }
 
+bool flash_attention_supports(int D) {
+    switch (D) {
+        case 8: case 16: case 32: case 40: case 64: case 80: case 160: return true;
+        default: return false;
+    }
+}
+
 void flash_attention(const AttnArgs& a, hipStream_t s) {
+    // every caller (graph walker and op wrapper alike) ends up here: an unsupported head dim must never fall through to
+    // "nothing launched, output uninitialised"
+    if (!flash_attention_supports(a.D))
+        throw Error(E2V_EINVAL, "attention head dim " + std::to_string(a.D) + " has no kernel instance (supported: 8, 16, 32, 40, 64, 80, 160)");
     if (a.x3 && !a.bf16) {
         switch (a.D) {
             case 8: launch_flash_x3<8>(a, s); return;
@@ -791,8 +803,7 @@ void flash_attention(const AttnArgs& a, hipStream_t s) {
             case 40: launch_flash_x3<40>(a, s); return;
             case 64: launch_flash_x3<64>(a, s); return;
             case 80: launch_flash_x3<80>(a, s); return;
-            case 160: launch_flash_x3<160>(a, s); return;
-            default: break;
+            default: launch_flash_x3<160>(a, s); return;
         }
     }
     if (a.bf16) {
@@ -803,8 +814,7 @@ void flash_attention(const AttnArgs& a, hipStream_t s) {
             case 40: launch_flash_bf16<40>(a, s); break;
             case 64: launch_flash_bf16<64>(a, s); break;
             case 80: launch_flash_bf16<80>(a, s); break;
-            case 160: launch_flash_bf16<160>(a, s); break;
-            default: break;
+            default: launch_flash_bf16<160>(a, s); break;
         }
         return;
     }
@@ -815,8 +825,7 @@ void flash_attention(const AttnArgs& a, hipStream_t s) {
         case 40: launch_flash<40>(a, s); break;
         case 64: launch_flash<64>(a, s); break;
         case 80: launch_flash<80>(a, s); break;
-        case 160: launch_flash<160>(a, s); break;
-        default: break;   // rejected by the host wrapper before it gets here
+        default: launch_flash<160>(a, s); break;
     }
 }
 

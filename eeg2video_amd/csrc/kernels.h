@@ -119,7 +119,8 @@ struct AttnArgs {
     int bf16 = 0;      // 1: bf16 MFMA for QK^T and PV (fp32 softmax / accumulate)
     int x3 = 0;        // 1: fp32-equivalent QK^T and PV from exactly split bf16 pieces (six MFMAs per product, f32x3 mode)
 };
-void flash_attention(const AttnArgs& a, hipStream_t s);
+void flash_attention(const AttnArgs& a, hipStream_t s);      // throws Error(E2V_EINVAL) for a head dim without a kernel instance
+bool flash_attention_supports(int D);
 // temporal self-attention over the F frames of every pixel (attention.py:261-267), qkv = [n*F*HW][3C]
 void temporal_attention(const float* qkv, int ld, float* out, int ldo, int n, int F, int HW, int heads, int D,
                         float scale, hipStream_t s);

@@ -140,10 +140,31 @@ void e2v_ctx::expected_keys() {
 
 float* e2v_ctx::dev_alloc(size_t floats) {
     void* p = nullptr;
-    E2V_HIP(hipMalloc(&p, std::max<size_t>(floats, 1) * sizeof(float)));
-    owned.push_back(static_cast<float*>(p));
-    weight_bytes += floats * sizeof(float);
+    const size_t bytes = std::max<size_t>(floats, 1) * sizeof(float);
+    E2V_HIP(hipMalloc(&p, bytes));
+    (alloc_part >= 0 ? owned_part[alloc_part] : owned).push_back(static_cast<float*>(p));
+    owned_bytes[p] = bytes;
+    weight_bytes += bytes;
     return static_cast<float*>(p);
+}
+
+void e2v_ctx::free_part(int part) {
+    for (float* p : owned_part[part]) {
+        auto it = owned_bytes.find(p);
+        if (it != owned_bytes.end()) { weight_bytes -= it->second; owned_bytes.erase(it); }
+        (void)hipFree(p);
+    }
+    owned_part[part].clear();
+}
+
+void e2v_ctx::enter_stream(hipStream_t s) {
+    if (has_last_stream && s != last_stream) {
+        if (!stream_ev) E2V_HIP(hipEventCreateWithFlags(&stream_ev, hipEventDisableTiming));
+        E2V_HIP(hipEventRecord(stream_ev, last_stream));
+        E2V_HIP(hipStreamWaitEvent(s, stream_ev, 0));
+    }
+    last_stream = s;
+    has_last_stream = true;
 }
 
 // =====================================================================================================
@@ -280,7 +301,11 @@ struct Packer {
 void e2v_ctx::finalize(int which) {
     Packer P{this};
     const int L = cfg.layers_per_block;
+    struct PartGuard { e2v_ctx* c; ~PartGuard() { c->alloc_part = -1; } } part_guard{this};
+    E2V_HIP(hipDeviceSynchronize());                 // a part finalized before may still be in use by queued work
     if (which & 1) {
+        free_part(0);
+        alloc_part = 0;
         UNetW u;
         u.conv_in = P.conv3("conv_in");
         u.te1 = P.lin("time_embedding.linear_1"); u.te2 = P.lin("time_embedding.linear_2");
@@ -310,6 +335,8 @@ void e2v_ctx::finalize(int which) {
         unet = std::move(u);
     }
     if (which & 2) {
+        free_part(1);
+        alloc_part = 1;
         VAEW v;
         const int VL = cfg.vae_layers_per_block;
         v.post_quant = P.lin("vae.post_quant_conv");
@@ -342,16 +369,28 @@ void e2v_ctx::finalize(int which) {
     }
     if (which & 4) {
         E2V_REQUIRE(cfg.sem_in_features > 0 && cfg.sem_hidden > 0, E2V_ESTATE, "the config has no semantic predictor");
+        free_part(2);
+        alloc_part = 2;
         sem.clear();
-        for (int i = 0; i < 5; ++i) sem.push_back(P.lin("semantic.mlp." + std::to_string(2 * i)));
-        sem_in_pad = (cfg.sem_in_features + 3) / 4 * 4;          // 310 -> 312: 16-byte rows for the gather
-        if (sem_in_pad != cfg.sem_in_features) {
-            float* wp = dev_alloc((size_t)sem[0].out * sem_in_pad);
-            pad_cols(sem[0].w, cfg.sem_in_features, wp, sem_in_pad, sem[0].out, nullptr);
-            sem[0].w = wp;
-            sem[0].in = sem_in_pad;
+        // the first layer's K (310) is padded to a multiple of 8 (320 -> 312 would do for fp32's 16-byte rows, but the bf16
+        // tile reads 8-element pieces): pad FIRST, then derive the bf16 / split copies from the padded matrix so that every
+        // form of the layer has the same row length
+        sem_in_pad = (cfg.sem_in_features + 7) / 8 * 8;
+        for (int i = 0; i < 5; ++i) {
+            const std::string n = "semantic.mlp." + std::to_string(2 * i);
+            if (i == 0 && sem_in_pad != cfg.sem_in_features) {
+                const WTensor& w = P.t(n + ".weight");
+                const int out = (int)w.shape[0];
+                float* wp = dev_alloc((size_t)out * sem_in_pad);
+                pad_cols(w.d, cfg.sem_in_features, wp, sem_in_pad, out, nullptr);
+                const size_t numel = (size_t)out * sem_in_pad;
+                sem.push_back(LinW{wp, P.t(n + ".bias").d, sem_in_pad, out, P.half(wp, numel), P.split3(wp, numel)});
+            } else {
+                sem.push_back(P.lin(n));
+            }
         }
     }
+    alloc_part = -1;
     E2V_HIP(hipStreamSynchronize(nullptr));
     E2V_HIP(hipGetLastError());
     // the torch-layout copies of re-laid-out tensors are no longer needed

@@ -106,6 +106,15 @@ struct e2v_ctx {
     std::vector<e2v::Act> temb_cache, kv_cache;
     void build_step_caches(const int64_t* ts, int steps, const float* cond, int N, int T, hipStream_t s);
 
+    // stream of the previous call (workspace reuse is stream-ordered): see enter_stream
+    hipStream_t last_stream = nullptr; bool has_last_stream = false; hipEvent_t stream_ev = nullptr;
+    void enter_stream(hipStream_t s);
+    // device blocks made by finalize(), per part (bit index of `which`), so that finalizing a part again frees what it replaces
+    std::vector<float*> owned_part[3];
+    std::unordered_map<void*, size_t> owned_bytes;
+    int alloc_part = -1;                                         // >= 0: dev_alloc files the block under owned_part[alloc_part]
+    void free_part(int part);
+
     float* dev_alloc(size_t floats);
     void expected_keys();
     void finalize(int which);

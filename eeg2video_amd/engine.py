@@ -149,6 +149,29 @@ class Engine:
         t = np.ascontiguousarray(table, dtype=np.float32)
         self._check(self.lib.e2v_set_alphas_cumprod(self.ctx, t.ctypes.data_as(C.POINTER(C.c_float)), t.size))
 
+    def set_ddim_schedule(self, alphas_cumprod: np.ndarray, steps_offset: int) -> None:
+        """Hand the ctx the schedule of the scheduler object the caller holds (table + ``steps_offset``), so that the
+        fused loop and a stepped loop driven by that scheduler agree."""
+        t = np.ascontiguousarray(alphas_cumprod, dtype=np.float32)
+        self._check(self.lib.e2v_set_ddim_schedule(self.ctx, t.ctypes.data_as(C.POINTER(C.c_float)), t.size, int(steps_offset)))
+        self._cfg.num_train_timesteps, self._cfg.steps_offset = int(t.size), int(steps_offset)
+
+    def _check_loop_inputs(self, x: torch.Tensor, cond: torch.Tensor, un: Optional[torch.Tensor]) -> None:
+        """Shapes the fused loops index device memory by: everything is checked here, on the host, because the library
+        copies ``B*T*D`` floats from ``cond`` / ``uncond`` whatever their real size."""
+        if x.dim() != 5 or cond.dim() != 3:
+            raise ValueError(f"expected latents [B,C,F,h,w] and cond [B,T,D], got {tuple(x.shape)} / {tuple(cond.shape)}")
+        b, c = x.shape[0], x.shape[1]
+        if c != self.unet_cfg.in_channels:
+            raise ValueError(f"latents have {c} channels, the UNet takes {self.unet_cfg.in_channels}")
+        if cond.shape[0] != b:
+            raise ValueError(f"cond batch {cond.shape[0]} != latent batch {b}")
+        if cond.shape[2] != self.unet_cfg.cross_attention_dim:
+            raise ValueError(f"cond feature dim {cond.shape[2]} != cross_attention_dim {self.unet_cfg.cross_attention_dim}")
+        if un is not None:
+            if un.dim() != 3 or un.shape[0] not in (1, b) or tuple(un.shape[1:]) != tuple(cond.shape[1:]):
+                raise ValueError(f"uncond must be [1 or {b},{cond.shape[1]},{cond.shape[2]}], got {tuple(un.shape)}")
+
     # ------------------------------------------------------------------ hot path
     def unet_forward(self, sample: torch.Tensor, timesteps: Sequence[int], cond: torch.Tensor) -> torch.Tensor:
         sample, cond = self._dev(sample, "sample"), self._dev(cond, "encoder_hidden_states")
@@ -203,9 +226,8 @@ class Engine:
         """DDIM inversion loop on the device (reference: tuneavideo/util.py ddim_loop); returns the list of n+1 latents
         (return_all) or only the last one."""
         x, cond = self._dev(latents, "latents"), self._dev(cond, "cond")
+        self._check_loop_inputs(x, cond, None)
         b, c, f, h, w = x.shape
-        if cond.shape[0] != b:
-            raise ValueError(f"cond batch {cond.shape[0]} != latent batch {b}")
         allb = torch.empty((num_inv_steps + 1,) + tuple(x.shape), device=self.device, dtype=torch.float32) if return_all else None
         last = torch.empty_like(x) if not return_all else None
         self._check(self.lib.e2v_ddim_invert(self.ctx, x.data_ptr(), cond.data_ptr(), b, f, h, w, cond.shape[1],
@@ -239,8 +261,11 @@ class Engine:
                  num_inference_steps: int = 50, guidance_scale: float = 7.5, eta: float = 0.0, decode: bool = True,
                  return_latents: bool = False):
         x, cond = self._dev(latents, "latents"), self._dev(cond, "cond")
-        b, c, f, h, w = x.shape
         un = self._dev(uncond, "uncond") if uncond is not None else None
+        self._check_loop_inputs(x, cond, un)
+        if guidance_scale > 1.0 and un is None:
+            raise ValueError("classifier-free guidance (guidance_scale > 1) needs `uncond`")
+        b, c, f, h, w = x.shape
         videos = torch.empty((b, self.vae_cfg.out_channels, f, 8 * h, 8 * w), device=self.device,
                              dtype=torch.float32) if decode else None
         lat_out = torch.empty_like(x) if return_latents else None

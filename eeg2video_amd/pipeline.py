@@ -199,6 +199,7 @@ class TuneAVideoPipeline:
         eng = self.unet.engine
         fused = callback is None and self.vae.engine is eng and isinstance(self.scheduler, DDIMScheduler)
         if fused:
+            self.scheduler.bind(eng)      # the fused loop walks the ctx's schedule: make it this scheduler's (table, steps_offset)
             with self.progress_bar(total=num_inference_steps) as bar:
                 video = eng.generate(latents, emb[b:] if do_cfg else emb, emb[:b] if do_cfg else None,
                                      num_inference_steps, guidance_scale, 0.0, decode=True)

@@ -56,7 +56,7 @@ class DDIMScheduler:
     def bind(self, engine):
         """Attach the HIP engine that executes ``step`` and hand it this host's alpha-bar table."""
         self.engine = engine
-        engine.set_alphas_cumprod(self.alphas_cumprod.numpy())
+        engine.set_ddim_schedule(self.alphas_cumprod.numpy(), self.config.steps_offset)
         return self
 
     def set_timesteps(self, num_inference_steps: int, device=None):

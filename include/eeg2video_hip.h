@@ -108,6 +108,11 @@ e2v_status e2v_ddim_timesteps(const e2v_ctx* ctx, int num_inference_steps, int64
  * install would build hands it in with e2v_set_alphas_cumprod (the Python mirror does). */
 e2v_status e2v_ddim_alphas_cumprod(const e2v_ctx* ctx, float* host_out);
 e2v_status e2v_set_alphas_cumprod(e2v_ctx* ctx, const float* host_table, int n);
+/* replaces: the scheduler config the pipeline reads (scheduler.config.steps_offset / num_train_timesteps,
+ * pipeline_tuneeeg2video.py:59-71; tuneavideo/util.py:58).  Hands the ctx the whole schedule of the scheduler object the
+ * caller holds -- table of n = num_train_timesteps alpha-bars and steps_offset -- so that the fused loop (e2v_generate,
+ * e2v_ddim_invert) and the caller's own stepped loop walk the same timesteps with the same coefficients. */
+e2v_status e2v_set_ddim_schedule(e2v_ctx* ctx, const float* host_alphas_cumprod, int n, int steps_offset);
 
 /* ---- the hot path --------------------------------------------------------------------------------- */
 /* replaces: UNet3DConditionModel.forward (unet.py:278-413).

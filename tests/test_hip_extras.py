@@ -35,6 +35,38 @@ def test_semantic_predictor_vs_oracle(eng, batch):
     assert err < 1e-5, err
 
 
+def _bf16(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("batch", [1, 130])
+def test_semantic_predictor_bf16_mode(eng, batch):
+    """bf16 arithmetic (e2v_set_compute_dtype): the first layer's K is padded (22 -> 24) and every weight form must share
+    that row length (the bf16 copy used to keep the unpadded stride).  Checked against the oracle with
+    operands rounded to bf16 per layer (fp32 accumulate), and loosely against the fp32 oracle."""
+    from eeg2video_amd.semantic import CLIP
+    from oracle import semantic_predictor
+    spec = semantic_param_spec(TINY_SEMANTIC, TINY_UNET.cross_attention_dim)
+    sd = synth_state_dict(spec, seed=44, mode="perturbed")
+    model = CLIP(TINY_SEMANTIC, engine=eng).load_state_dict({"state_dict": sd})
+    eeg = _t(counter_normal(3, "eeg", (batch, TINY_SEMANTIC.in_features)))
+    x = eeg
+    for i in range(5):
+        w, b = _t(sd[f"mlp.{2 * i}.weight"]), _t(sd[f"mlp.{2 * i}.bias"])
+        x = _bf16(x) @ _bf16(w).T + b
+        if i < 4:
+            x = x.relu()
+    ref32 = semantic_predictor({k: _t(v) for k, v in sd.items()}, eeg)
+    eng.set_compute_dtype("bf16")
+    try:
+        out = model(eeg.cuda()).cpu()
+    finally:
+        eng.set_compute_dtype("fp32")
+    scale = ref32.abs().max().item()
+    assert (out - x).abs().max().item() / scale < 2e-3
+    assert (out - ref32).abs().max().item() / scale < 5e-2
+
+
 def test_dana_noise_vs_oracle(eng):
     from oracle import dana_noise
     b, f, c, h, w = 3, 6, 4, 9, 8

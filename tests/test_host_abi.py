@@ -88,6 +88,37 @@ def test_alpha_table_matches_torch_to_the_last_bits(lib, host_ctx):
     assert np.array_equal(a, ref)
 
 
+def test_set_ddim_schedule_moves_offset_and_table(lib):
+    """DDIMScheduler.bind pushes (table, steps_offset) so that the fused loop and a stepped loop agree."""
+    cfg = _lib.E2VConfig()
+    lib.e2v_default_config(C.byref(cfg))
+    ctx = C.c_void_p()
+    assert lib.e2v_create(C.byref(cfg), -1, C.byref(ctx)) == 0
+    tab = np.linspace(0.999, 0.01, 500).astype(np.float32)
+    assert lib.e2v_set_ddim_schedule(ctx, tab.ctypes.data_as(C.POINTER(C.c_float)), 500, 0) == 0
+    out = np.empty(5, dtype=np.int64)
+    assert lib.e2v_ddim_timesteps(ctx, 5, out.ctypes.data_as(_lib.c_int64_p)) == 0
+    assert out.tolist() == [400, 300, 200, 100, 0]
+    got = np.empty(500, dtype=np.float32)
+    assert lib.e2v_ddim_alphas_cumprod(ctx, got.ctypes.data_as(C.POINTER(C.c_float))) == 0 and np.array_equal(got, tab)
+    assert lib.e2v_set_ddim_schedule(ctx, tab.ctypes.data_as(C.POINTER(C.c_float)), 500, 500) == _lib.E2V_EINVAL
+    lib.e2v_destroy(ctx)
+
+
+def test_create_rejects_head_dims_without_a_kernel(lib):
+    """block_out_channels / heads must be a head dim flash_attention has an instance for: D = 48 used to be accepted
+    and ran the UNet with an uninitialised attention output."""
+    cfg = _lib.E2VConfig()
+    lib.e2v_default_config(C.byref(cfg))
+    cfg.block_out_channels = (C.c_int * 4)(384, 640, 1280, 1280)       # 384 / 8 = 48
+    ctx = C.c_void_p()
+    assert lib.e2v_create(C.byref(cfg), -1, C.byref(ctx)) == _lib.E2V_EINVAL
+    assert b"head dim" in lib.e2v_last_error(None)
+    cfg.block_out_channels = (C.c_int * 4)(320, 640, 1280, 1280)
+    assert lib.e2v_create(C.byref(cfg), -1, C.byref(ctx)) == 0
+    lib.e2v_destroy(ctx)
+
+
 def test_device_entry_points_refuse_host_only_context(lib, host_ctx):
     assert lib.e2v_finalize_weights(host_ctx, 1) == _lib.E2V_ESTATE
     assert b"host-only" in lib.e2v_last_error(host_ctx)
