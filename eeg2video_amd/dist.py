@@ -29,11 +29,16 @@ def frames_to_uint8(frames: torch.Tensor) -> torch.Tensor:
     return (frames * 255).to(torch.uint8)
 
 
-def all_gather_frames(frames: torch.Tensor, group: Optional[dist.ProcessGroup] = None, as_uint8: bool = False) -> torch.Tensor:
+def all_gather_frames(frames: torch.Tensor, group: Optional[dist.ProcessGroup] = None, as_uint8: bool = False,
+                      force_collective: bool = False) -> torch.Tensor:
     """Every rank contributes ``[b_r, 3, F, H, W]`` (``b_r`` may differ by one between ranks) and receives the
-    clips of all ranks in rank order, ``[sum b_r, 3, F, H, W]``.  Single-process: returns the input."""
+    clips of all ranks in rank order, ``[sum b_r, 3, F, H, W]``.  Single-process: returns the input, unless
+    ``force_collective`` asks for the collective to run even over a one-rank group (``bench.py --dist-single``: the RCCL
+    code path on a one-GPU box)."""
     x = frames_to_uint8(frames) if as_uint8 else frames
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return x
+    if dist.get_world_size(group) == 1 and not force_collective:
         return x
     world = dist.get_world_size(group)
     counts = torch.tensor([x.shape[0]], device=x.device, dtype=torch.int64)
