@@ -230,17 +230,19 @@ e2v_status e2v_semantic_predict(e2v_ctx* c, const float* eeg, int B, float* out,
         E2V_REQUIRE(c->sem_ready, E2V_ESTATE, "semantic predictor weights are not finalized");
         E2V_REQUIRE(eeg && out && B > 0, E2V_EINVAL, "bad arguments");
         hipStream_t s = S(c, stream);
-        Act x(c->pool, B, c->sem_in_pad);
-        pad_cols(eeg, c->cfg.sem_in_features, x.p, c->sem_in_pad, B, s);
+        const bool b16 = c->bf16_compute;                        // bf16-activation mode: bf16 rows between the layers, fp32 result
+        Act x(c->pool, B, c->sem_in_pad, b16);
+        pad_cols(eeg, c->cfg.sem_in_features, x.p, c->sem_in_pad, B, s, b16 ? 1 : 0);
         for (size_t i = 0; i < c->sem.size(); ++i) {              // Linear -> ReLU ... -> Linear (train_semantic_predictor.py:14-28)
             const LinW& w = c->sem[i];
             const bool last = i + 1 == c->sem.size();
             Act y;
-            if (!last) y = Act(c->pool, B, w.out);
+            if (!last) y = Act(c->pool, B, w.out, b16);
             IgemmArgs g;
-            g.a0 = x.p; g.c0 = w.in; g.lda0 = w.in; g.w = w.w; g.ldw = w.in; g.bias = w.b;
-            g.out = last ? out : y.p; g.ldc = w.out; g.M = B; g.N = w.out; g.taps = 1; g.relu = last ? 0 : 1; g.ldw16 = w.in;
-            g.bf16 = c->bf16_compute ? 1 : 0; g.w16 = w.w16;
+            g.a0 = x.p; g.c0 = b16 ? w.in16 : w.in; g.lda0 = g.c0; g.w = w.w; g.ldw = w.in; g.bias = w.b;
+            g.out = last ? out : y.p; g.ldc = w.out; g.M = B; g.N = w.out; g.taps = 1; g.relu = last ? 0 : 1; g.ldw16 = w.in16;
+            g.w16 = w.w16;
+            if (b16) { g.a_bf16 = 1; g.out_f32 = last ? 1 : 0; }
             igemm(g, s);
             if (!last) x = std::move(y);
         }
@@ -567,7 +569,30 @@ e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, 
         hipStream_t s = S(c, stream);
         const int cin = c0 + c1;
         E2V_REQUIRE(c1 == 0 || c0 % 32 == 0, E2V_ESHAPE, "conv: the concat seam must be a multiple of 32 channels");
-        const bool wino_shape = stride == 1 && pad_lo == 1 && Hi == Ho && Wi == Wo && cout % 4 == 0 && !c->bf16_compute;
+        if (c->bf16_compute) {       // bf16-activation mode: operands rounded to bf16 once (channels zero-padded to 8), fp32 result
+            E2V_REQUIRE(c1 == 0 || c0 % 64 == 0, E2V_ESHAPE, "bf16 conv: the concat seam must be a multiple of 64 channels");
+            const int c0p = c1 > 0 ? c0 : (c0 + 7) / 8 * 8, c1p = (c1 + 7) / 8 * 8;
+            const int64_t rows_in = (int64_t)n_img * Hs * Ws;
+            Act a0(c->pool, rows_in, c0p, true), a1;
+            cvt_rows(x0, c0, 0, a0.p, c0p, 1, rows_in, c0, c0p, s);
+            if (c1 > 0) { a1 = Act(c->pool, rows_in, c1p, true); cvt_rows(x1, c1, 0, a1.p, c1p, 1, rows_in, c1, c1p, s); }
+            const int ld64 = conv3x3_packed_ld(cin, 64);
+            Act w64(c->pool, cout, ld64), w16(c->pool, cout, (ld64 + 1) / 2);
+            pack_conv3x3(w_oihw, w64.p, cout, cin, 64, s);
+            to_bf16(w64.p, w16.p, (size_t)cout * ld64, s);
+            IgemmArgs g;
+            g.a0 = a0.p; g.c0 = c0p; g.lda0 = c0p; g.a1 = c1 > 0 ? a1.p : nullptr; g.c1 = c1 > 0 ? c1p : 0; g.lda1 = c1p;
+            g.w16 = w16.p; g.ldw16 = ld64; g.ldw = ld64; g.out = out; g.ldc = cout; g.bias = bias;
+            g.rowbias = rowbias; g.rb_ld = cout; g.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+            g.resid = resid; g.ldr = cout; g.M = n_img * Ho * Wo; g.N = cout; g.taps = 9;
+            g.Ho = Ho; g.Wo = Wo; g.Hi = Hi; g.Wi = Wi; g.Hs = Hs; g.Ws = Ws; g.stride = stride; g.pad = pad_lo;
+            if (Hi != Hs || Wi != Ws) { g.upsample = 1; g.ups_h = (float)Hs / (float)Hi; g.ups_w = (float)Ws / (float)Wi; }
+            g.a_bf16 = 1; g.out_f32 = 1;
+            igemm(g, s);
+            E2V_HIP(hipGetLastError());
+            return;
+        }
+        const bool wino_shape = stride == 1 && pad_lo == 1 && Hi == Ho && Wi == Wo && cout % 4 == 0;
         int wm = 0;                                            // same policy as the graph runner (model.cpp: Runner::winograd)
         if (wino_shape && c->conv_algo == E2V_CONV_WINOGRAD) wm = 2;
         if (wino_shape && c->conv_algo == E2V_CONV_WINOGRAD4) wm = 4;
@@ -602,7 +627,7 @@ e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, 
             E2V_HIP(hipGetLastError());
             return;
         }
-        const int ld32 = conv3x3_packed_ld(cin, 32), ld64 = conv3x3_packed_ld(cin, 64);
+        const int ld32 = conv3x3_packed_ld(cin, 32);
         Act wp(c->pool, cout, ld32);
         pack_conv3x3(w_oihw, wp.p, cout, cin, 32, s);
         IgemmArgs g;
@@ -612,14 +637,6 @@ e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, 
         g.resid = resid; g.ldr = cout; g.M = n_img * Ho * Wo; g.N = cout; g.taps = 9;
         g.Ho = Ho; g.Wo = Wo; g.Hi = Hi; g.Wi = Wi; g.Hs = Hs; g.Ws = Ws; g.stride = stride; g.pad = pad_lo;
         if (Hi != Hs || Wi != Ws) { g.upsample = 1; g.ups_h = (float)Hs / (float)Hi; g.ups_w = (float)Ws / (float)Wi; }
-        Act w64, w16;
-        if (c->bf16_compute) {
-            w64 = Act(c->pool, cout, ld64);
-            pack_conv3x3(w_oihw, w64.p, cout, cin, 64, s);
-            w16 = Act(c->pool, cout, (ld64 + 1) / 2);
-            to_bf16(w64.p, w16.p, (size_t)cout * ld64, s);
-            g.bf16 = 1; g.w16 = w16.p; g.ldw16 = ld64;
-        }
         igemm(g, s);
         E2V_HIP(hipGetLastError());
     });
@@ -648,11 +665,15 @@ e2v_status e2v_op_linear(e2v_ctx* c, const float* x, int ldx, int64_t M, int K, 
         } else {
             g.w = w; g.bias = bias; g.N = N; g.ldc = N; g.ldr = N;
         }
-        Act w16;
-        if (c->bf16_compute) {
-            w16 = Act(c->pool, g.N, (K + 1) / 2);
-            to_bf16(g.w, w16.p, (size_t)g.N * K, s);
-            g.bf16 = 1; g.w16 = w16.p; g.ldw16 = K;
+        Act w16, wpad, a16;
+        if (c->bf16_compute) {       // bf16-activation mode: A and W rounded to bf16 once (K zero-padded to 8), fp32 result
+            const int K8 = (K + 7) / 8 * 8;
+            a16 = Act(c->pool, M, K8, true);
+            cvt_rows(x, ldx, 0, a16.p, K8, 1, M, K, K8, s);
+            w16 = Act(c->pool, g.N, K8, true);
+            cvt_rows(g.w, K, 0, w16.p, K8, 1, g.N, K, K8, s);
+            g.a0 = a16.p; g.c0 = K8; g.lda0 = K8;
+            g.a_bf16 = 1; g.out_f32 = 1; g.w16 = w16.p; g.ldw16 = K8;
         }
         Act w3;
         if (c->x3_compute) {
@@ -679,7 +700,17 @@ e2v_status e2v_op_groupnorm(e2v_ctx* c, const float* x0, int c0, const float* x1
         a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1; a.ld0 = c0; a.ld1 = c1; a.gamma = gamma; a.beta = beta;
         a.out = out; a.ldo = C; a.samples = samples; a.P = P; a.groups = groups; a.eps = eps; a.silu = act;
         a.ws_part = part.p; a.ws_scale = sc.p;
-        groupnorm(a, s);
+        if (c->bf16_compute) {       // bf16-activation mode: bf16 rows in and out (fp32 statistics), converted at this boundary
+            const int64_t rows = (int64_t)samples * P;
+            Act b0(c->pool, rows, c0, true), b1, bo(c->pool, rows, C, true);
+            cvt_rows(x0, c0, 0, b0.p, c0, 1, rows, c0, c0, s);
+            if (c1 > 0) { b1 = Act(c->pool, rows, c1, true); cvt_rows(x1, c1, 0, b1.p, c1, 1, rows, c1, c1, s); }
+            a.bf16 = 1; a.x0 = b0.p; a.x1 = c1 > 0 ? b1.p : nullptr; a.out = bo.p;
+            groupnorm(a, s);
+            cvt_rows(bo.p, C, 1, out, C, 0, rows, C, C, s);
+        } else {
+            groupnorm(a, s);
+        }
         E2V_HIP(hipGetLastError());
     });
 }
@@ -689,7 +720,15 @@ e2v_status e2v_op_layernorm(e2v_ctx* c, const float* x, int64_t rows, int C, con
     if (!c) return E2V_EINVAL;
     return guarded(c, [&] {
         E2V_REQUIRE(x && gamma && beta && out && C % 4 == 0 && C <= 1280, E2V_EINVAL, "bad layernorm arguments");
-        layernorm(x, C, gamma, beta, out, C, (int)rows, C, eps, S(c, stream));
+        hipStream_t s = S(c, stream);
+        if (c->bf16_compute) {
+            Act bi(c->pool, rows, C, true), bo(c->pool, rows, C, true);
+            cvt_rows(x, C, 0, bi.p, C, 1, rows, C, C, s);
+            layernorm(bi.p, C, gamma, beta, bo.p, C, (int)rows, C, eps, s, 1);
+            cvt_rows(bo.p, C, 1, out, C, 0, rows, C, C, s);
+        } else {
+            layernorm(x, C, gamma, beta, out, C, (int)rows, C, eps, s);
+        }
         E2V_HIP(hipGetLastError());
     });
 }
@@ -705,8 +744,21 @@ e2v_status e2v_op_attention(e2v_ctx* c, const float* q, int ldq, const float* k,
         E2V_REQUIRE(mode == 1 || Nq == Nk, E2V_ESHAPE, "self-attention needs Nq == Nk");
         AttnArgs a;
         a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv; a.o = o; a.ldo = ldo; a.n = n; a.F = F; a.heads = heads; a.D = D;
-        a.Nq = Nq; a.Nk = Nk; a.mode = mode; a.scale = scale; a.bf16 = c->bf16_compute ? 1 : 0; a.x3 = c->x3_compute ? 1 : 0;
-        flash_attention(a, S(c, stream));
+        a.Nq = Nq; a.Nk = Nk; a.mode = mode; a.scale = scale; a.x3 = c->x3_compute ? 1 : 0;
+        hipStream_t s = S(c, stream);
+        if (c->bf16_compute) {       // bf16-activation mode: Q, K, V rounded to bf16 rows once; O comes back as bf16
+            const int C = heads * D;
+            const int64_t qrows = (int64_t)n * F * Nq, krows = mode == 0 ? (int64_t)n * F * Nk : (int64_t)n * Nk;
+            Act bq(c->pool, qrows, C, true), bk(c->pool, krows, C, true), bv(c->pool, krows, C, true), bo(c->pool, qrows, C, true);
+            cvt_rows(q, ldq, 0, bq.p, C, 1, qrows, C, C, s);
+            cvt_rows(k, ldkv, 0, bk.p, C, 1, krows, C, C, s);
+            cvt_rows(v, ldkv, 0, bv.p, C, 1, krows, C, C, s);
+            a.q = bq.p; a.ldq = C; a.k = bk.p; a.v = bv.p; a.ldkv = C; a.o = bo.p; a.ldo = C; a.io_bf16 = 1;
+            flash_attention(a, s);
+            cvt_rows(bo.p, C, 1, o, ldo, 0, qrows, C, C, s);
+        } else {
+            flash_attention(a, s);
+        }
         E2V_HIP(hipGetLastError());
     });
 }
@@ -717,7 +769,16 @@ e2v_status e2v_op_temporal_attention(e2v_ctx* c, const float* qkv, float* out, i
     return guarded(c, [&] {
         E2V_REQUIRE(qkv && out && F <= 8 && D % 4 == 0, E2V_EINVAL, "bad temporal attention arguments");
         const int C = heads * D;
-        temporal_attention(qkv, 3 * C, out, C, n, F, HW, heads, D, scale, S(c, stream));
+        hipStream_t s = S(c, stream);
+        if (c->bf16_compute) {
+            const int64_t rows = (int64_t)n * F * HW;
+            Act bi(c->pool, rows, 3 * C, true), bo(c->pool, rows, C, true);
+            cvt_rows(qkv, 3 * C, 0, bi.p, 3 * C, 1, rows, 3 * C, 3 * C, s);
+            temporal_attention(bi.p, 3 * C, bo.p, C, n, F, HW, heads, D, scale, s, 1);
+            cvt_rows(bo.p, C, 1, out, C, 0, rows, C, C, s);
+        } else {
+            temporal_attention(qkv, 3 * C, out, C, n, F, HW, heads, D, scale, s);
+        }
         E2V_HIP(hipGetLastError());
     });
 }

@@ -15,6 +15,7 @@
 #include "kernels.h"
 #include "prof.h"
 #include "runtime.h"
+#include "act_io.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -466,6 +467,236 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const AttnArgs p) 
     }
 }
 
+// ---- bf16 in HBM (bf16-activation mode, AttnArgs::io_bf16) ----------------------------------------------------
+// Q, K, V arrive as bf16 rows and O leaves as bf16: nothing is converted on the way in.  K and V tiles go to LDS as they
+// are (16-byte pieces, row-major, padded rows); the V^T fragment of O^T = V^T P^T comes out of the row-major V image
+// through the transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads 4 keys x 16 value columns and gets them
+// column-major), so there is no transposed staging.  The softmax scale rides in the exponent's FMA instead of being
+// multiplied into a bf16 Q.  Scores, softmax and the O accumulator are fp32.
+template <int D>
+__global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p) {
+    constexpr int DP = (D + 15) / 16 * 16;      // head dim padded to the 16-deep MFMA step
+    constexpr int KS = DP / 16;
+    constexpr int T = (D + 31) / 32;            // 32-row tiles of O^T
+    constexpr int KROW = DP * 2 + 16;           // bytes per K row: conflict-free ds_read_b128 of 16 rows
+    constexpr int VROW = T * 64 + 16;           // bytes per V row (the tr reads of the last tile may run past D: they stay inside the row)
+    constexpr int KBYTES = 32 * KROW, VBYTES = 32 * VROW;
+    constexpr int STAGE = (KBYTES + VBYTES + 15) / 16 * 16;
+    constexpr int C8 = D / 8;                   // 16-byte pieces per row
+    constexpr int NP = 32 * C8;
+    constexpr int LPT = (NP + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem_h[];      // [2][K rows | V rows]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int sf = blockIdx.z;
+    const int smp = sf / p.F, f = sf - smp * p.F;
+    const int head = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const bool active = q0 < p.Nq;
+    const __bf16* __restrict__ Q = reinterpret_cast<const __bf16*>(p.q);
+    const __bf16* __restrict__ K = reinterpret_cast<const __bf16*>(p.k);
+    const __bf16* __restrict__ V = reinterpret_cast<const __bf16*>(p.v);
+
+    int nseg = 1;
+    size_t kvbase[2];
+    if (p.mode == 0) {
+        kvbase[0] = (size_t)(smp * p.F) * p.Nk;
+        kvbase[1] = (size_t)(smp * p.F + (f > 0 ? f - 1 : 0)) * p.Nk;
+        nseg = f >= 2 ? 2 : 1;
+    } else {
+        kvbase[0] = kvbase[1] = (size_t)smp * p.Nk;
+    }
+    const int tps = (p.Nk + 31) / 32;
+    const int ntiles = nseg * tps;
+
+    for (int i = tid * 16; i < 2 * STAGE; i += 256 * 16)                // pad columns are never rewritten: keep them finite
+        *reinterpret_cast<f32x4*>(smem_h + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    abf16x8 qf[KS];
+    {
+        const int qrow = min(q0 + j, p.Nq - 1);
+        const __bf16* qp = Q + ((size_t)sf * p.Nq + qrow) * p.ldq + head * D;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k0 = 16 * s + 8 * h;
+            abf16x8 a;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = (__bf16)0.f;
+            if (k0 < D) a = *reinterpret_cast<const abf16x8*>(qp + k0);
+            qf[s] = a;
+        }
+    }
+    const float sc = p.scale * 1.44269504088896340736f;                 // scores are exponentiated as exp2(sc * s - m)
+    __syncthreads();
+
+    constexpr unsigned OOB = 0x80000000u;
+    auto rsrc_of = [](const void* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, 0x7FFFFFF0,
+                                                 0x00020000);
+    };
+    int ld_row[LPT], ld_c8[LPT];
+    unsigned ld_off[LPT];
+#pragma unroll
+    for (int e = 0; e < LPT; ++e) {
+        const int idx = tid + 256 * e;
+        const int row = idx / C8, c8 = idx - row * C8;
+        ld_row[e] = row; ld_c8[e] = c8;
+        ld_off[e] = idx < NP ? (unsigned)(row * p.ldkv + c8 * 8) * 2u : OOB;
+    }
+    f32x4 kreg[LPT], vreg[LPT];
+    auto load_tile = [&](int tt) {
+        const int seg = tt / tps;
+        const int key0 = (tt - seg * tps) * 32;
+        const size_t first = (kvbase[seg] + key0) * p.ldkv + head * D;
+        const __amdgpu_buffer_rsrc_t rk = rsrc_of(K + first), rv = rsrc_of(V + first);
+        const int left = p.Nk - key0;                           // keys this tile really has (uniform)
+#pragma unroll
+        for (int e = 0; e < LPT; ++e) {
+            unsigned off = ld_off[e];
+            if (left < 32) off = ld_row[e] < left ? off : OOB;  // ragged last tile of a segment only
+            kreg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
+            vreg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* Kl = smem_h + buf * STAGE;
+        char* Vl = Kl + KBYTES;
+#pragma unroll
+        for (int e = 0; e < LPT; ++e) {
+            if (tid + 256 * e < NP) {
+                *reinterpret_cast<f32x4*>(Kl + ld_row[e] * KROW + ld_c8[e] * 16) = kreg[e];
+                *reinterpret_cast<f32x4*>(Vl + ld_row[e] * VROW + ld_c8[e] * 16) = vreg[e];
+            }
+        }
+    };
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    // transposing read of the V^T fragment: 16-lane group g = lane >> 4 covers value columns 16 (g & 1) .. + 15 of the tile
+    // and keys 4 (g >> 1) .. + 3 of each 8-key half of the k-step; lane 4 q + p of the group supplies row q, columns 4 p ..
+    const int ti = lane & 15;
+    const int tr_off = (4 * h + (ti >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (ti & 3)) * 2;
+    typedef __attribute__((address_space(3))) abf16x4* lds_b4;
+
+    for (int tt = 0; tt < ntiles; ++tt) {
+        const int buf = tt & 1;
+        if (tt + 1 < ntiles) load_tile(tt + 1);
+        const int seg_c = tt / tps;
+        const int key0 = (tt - seg_c * tps) * 32;
+        if (active) {
+            const char* Kl = smem_h + buf * STAGE;
+            const char* Vl = Kl + KBYTES;
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 st;
+            const char* kp = Kl + j * KROW + h * 16;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const abf16x8 kf = *reinterpret_cast<const abf16x8*>(kp + s * 32);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? zero16 : st, 0, 0, 0);
+            }
+            if (key0 + 32 > p.Nk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= p.Nk) st[r] = -INFINITY;
+                }
+            }
+            float mt = st[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mt = __builtin_fmaxf(mt, st[r]);
+            mt = __builtin_fmaxf(mt, __shfl_xor(mt, 32)) * sc;             // sc > 0: max commutes with the scaling
+            const float m_new = __builtin_fmaxf(m_i, mt);
+            const bool moved = __any(m_new > m_i);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc, -m_new));
+                ps += st[r];
+            }
+            float alpha = 1.0f;
+            if (moved) {
+                alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+                l_i *= alpha;
+            }
+            l_i += ps;
+            m_i = m_new;
+            abf16x8 pf[2];                       // P^T fragments: registers 8s..8s+7 are k-step s as they stand
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[s][e] = (__bf16)st[8 * s + e];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if (moved) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+                }
+                const char* vb = Vl + tr_off + t * 64;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const abf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s) * VROW));       // keys 16s + 4h + 0..3
+                    const abf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s + 8) * VROW));   // keys 16s + 8 + 4h + 0..3
+                    const abf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        if (tt + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_i + __shfl_xor(l_i, 32);
+    if (active && q0 + j < p.Nq) {
+        const float inv = 1.0f / l_tot;
+        __bf16* op = reinterpret_cast<__bf16*>(p.o) + ((size_t)sf * p.Nq + q0 + j) * p.ldo + head * D;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int dv = t * 32 + 8 * rg + 4 * h;
+                if (dv < D) {
+                    abf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[t][rg * 4 + e] * inv);
+                    *reinterpret_cast<abf16x4*>(op + dv) = o;
+                }
+            }
+    }
+}
+
+template <int D>
+static void launch_flash_b16io(const AttnArgs& a, hipStream_t s) {
+    static bool configured = false;
+    constexpr int DP = (D + 15) / 16 * 16, T = (D + 31) / 32;
+    constexpr size_t stage = ((size_t)32 * (DP * 2 + 16) + (size_t)32 * (T * 64 + 16) + 15) / 16 * 16;
+    constexpr size_t smem = 2 * stage;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_b16io_kernel<D>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        configured = true;
+    }
+    dim3 grid((a.Nq + 127) / 128, a.heads, a.n * a.F);
+    const double nk = a.mode == 0 ? 2.0 * a.Nk : (double)a.Nk;
+    const double probs = (double)a.n * a.F * a.heads;
+    ProfScope ps(a.mode == 0 ? "flash_attn_bf16_sparse_causal" : "flash_attn_bf16_cross", 4.0 * probs * a.Nq * nk * D,
+                 2.0 * probs * D * (2.0 * a.Nq + 2.0 * (a.mode == 0 ? a.Nk : (double)a.Nk / a.F)), s);
+    hipLaunchKernelGGL((flash_attn_b16io_kernel<D>), grid, dim3(256), smem, s, a);
+}
+
 // =====================================================================================================
 // f32x3 attention (opt-in, AttnArgs::x3; see igemm.hip / DESIGN 3.7): both matmuls as six bf16-piece MFMAs over operands
 // split EXACTLY into three bf16 pieces by truncation -- Q once per wave, K and V on their way into LDS (three planes each),
@@ -795,6 +1026,18 @@ void flash_attention(const AttnArgs& a, hipStream_t s) {
     // "nothing launched, output uninitialised"
     if (!flash_attention_supports(a.D))
         throw Error(E2V_EINVAL, "attention head dim " + std::to_string(a.D) + " has no kernel instance (supported: 8, 16, 32, 40, 64, 80, 160)");
+    if (a.io_bf16) {
+        if ((a.ldq | a.ldkv | a.ldo) & 7) throw Error(E2V_ESHAPE, "bf16 attention: row strides must be multiples of 8 elements");
+        switch (a.D) {
+            case 8: launch_flash_b16io<8>(a, s); return;
+            case 16: launch_flash_b16io<16>(a, s); return;
+            case 32: launch_flash_b16io<32>(a, s); return;
+            case 40: launch_flash_b16io<40>(a, s); return;
+            case 64: launch_flash_b16io<64>(a, s); return;
+            case 80: launch_flash_b16io<80>(a, s); return;
+            default: launch_flash_b16io<160>(a, s); return;
+        }
+    }
     if (a.x3 && !a.bf16) {
         switch (a.D) {
             case 8: launch_flash_x3<8>(a, s); return;
@@ -833,7 +1076,8 @@ void flash_attention(const AttnArgs& a, hipStream_t s) {
 // The reference transposes (b f) d c -> (b d) f c and back (attention.py:262,267); with channel-last
 // rows (sample, frame, pixel) the F rows of one pixel are HW rows apart and are read in place.
 static constexpr int FMAX = 8;
-__global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restrict__ qkv, int ld, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict__ qkv, int ld, T* __restrict__ out,
                                                             int ldo, int n, int F, int HW, int heads, int D, float scale) {
     const size_t total = (size_t)n * HW * heads * F;
     const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -845,19 +1089,19 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
     const int smp = ph / HW;
     const int C = heads * D;
     const size_t row0 = (size_t)smp * F * HW + pix;          // frame 0 row; frame f is f*HW rows further
-    const float* qp = qkv + (row0 + (size_t)i * HW) * ld + head * D;
-    const float* kp = qkv + row0 * ld + C + head * D;
-    const float* vp = qkv + row0 * ld + 2 * C + head * D;
+    const T* qp = qkv + (row0 + (size_t)i * HW) * ld + head * D;
+    const T* kp = qkv + row0 * ld + C + head * D;
+    const T* vp = qkv + row0 * ld + 2 * C + head * D;
     const size_t fstride = (size_t)HW * ld;
     float s[FMAX];
 #pragma unroll
     for (int jf = 0; jf < FMAX; ++jf) s[jf] = 0.f;
     for (int c = 0; c < D; c += 4) {
-        const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + c);
+        const f32x4 qv = ld4(qp + c);
 #pragma unroll
         for (int jf = 0; jf < FMAX; ++jf)
             if (jf < F) {
-                const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + jf * fstride + c);
+                const f32x4 kv = ld4(kp + jf * fstride + c);
                 s[jf] += qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
             }
     }
@@ -876,22 +1120,23 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
             l += s[jf];
         }
     const float inv = 1.0f / l;
-    float* op = out + (row0 + (size_t)i * HW) * ldo + head * D;
+    T* op = out + (row0 + (size_t)i * HW) * ldo + head * D;
     for (int c = 0; c < D; c += 4) {
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int jf = 0; jf < FMAX; ++jf)
             if (jf < F) {
-                const f32x4 vv = *reinterpret_cast<const f32x4*>(vp + jf * fstride + c);
+                const f32x4 vv = ld4(vp + jf * fstride + c);
                 o += vv * (s[jf] * inv);
             }
-        *reinterpret_cast<f32x4*>(op + c) = o;
+        st4(op + c, o);
     }
 }
 
 // LDS-staged version: a block stages q, k, v of PB pixels x F frames for a slab of CS channels (whole heads) with fully
 // coalesced row reads, then one thread per (pixel, head, query frame) works out of LDS.  HBM sees every byte once.
-__global__ __launch_bounds__(128) void temporal_attn_lds_kernel(const float* __restrict__ qkv, int ld, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(128) void temporal_attn_lds_kernel(const T* __restrict__ qkv, int ld, T* __restrict__ out,
                                                                 int ldo, int F, int HW, int C, int D, float scale, int PB,
                                                                 int CS, int npg) {
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [F][PB][q | k | v][CS]
@@ -907,7 +1152,7 @@ __global__ __launch_bounds__(128) void temporal_attn_lds_kernel(const float* __r
         const int f = r / PB;
         const int pix = p0 + pp;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pix < HW) v = *reinterpret_cast<const f32x4*>(qkv + ((size_t)(smp * F + f) * HW + pix) * ld + part * C + c_base + c4 * 4);
+        if (pix < HW) v = ld4(qkv + ((size_t)(smp * F + f) * HW + pix) * ld + part * C + c_base + c4 * 4);
         *reinterpret_cast<f32x4*>(sm + (size_t)idx * 4) = v;
     }
     __syncthreads();
@@ -950,7 +1195,7 @@ __global__ __launch_bounds__(128) void temporal_attn_lds_kernel(const float* __r
                 l += s[jf];
             }
         const float inv = 1.0f / l;
-        float* op = out + ((size_t)(smp * F + i) * HW + pix) * ldo + c_base + hh * D;
+        T* op = out + ((size_t)(smp * F + i) * HW + pix) * ldo + c_base + hh * D;
         for (int c = 0; c < D; c += 4) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -959,19 +1204,33 @@ __global__ __launch_bounds__(128) void temporal_attn_lds_kernel(const float* __r
                     const f32x4 vv = *reinterpret_cast<const f32x4*>(v + jf * fs + c);
                     o += vv * (s[jf] * inv);
                 }
-            *reinterpret_cast<f32x4*>(op + c) = o;
+            st4(op + c, o);
         }
     }
 }
 
+template <typename T>
+static void temporal_attention_launch(const T* qkv, int ld, T* out, int ldo, int n, int F, int HW, int heads, int D, float scale,
+                                      hipStream_t s);
+
 void temporal_attention(const float* qkv, int ld, float* out, int ldo, int n, int F, int HW, int heads, int D, float scale,
-                        hipStream_t s) {
+                        hipStream_t s, int bf16) {
     const size_t total = (size_t)n * HW * heads * F;
     if (!total) return;
-    ProfScope ps("temporal_attn", 4.0 * total * F * D, 4.0 * 4.0 * (double)n * F * HW * heads * D, s);
+    ProfScope ps("temporal_attn", 4.0 * total * F * D, 4.0 * (bf16 ? 2.0 : 4.0) * (double)n * F * HW * heads * D, s);
+    if (bf16)
+        temporal_attention_launch(reinterpret_cast<const __bf16*>(qkv), ld, reinterpret_cast<__bf16*>(out), ldo, n, F, HW, heads, D, scale, s);
+    else
+        temporal_attention_launch(qkv, ld, out, ldo, n, F, HW, heads, D, scale, s);
+}
+
+template <typename T>
+static void temporal_attention_launch(const T* qkv, int ld, T* out, int ldo, int n, int F, int HW, int heads, int D, float scale,
+                                      hipStream_t s) {
+    const size_t total = (size_t)n * HW * heads * F;
     const int C = heads * D;
-    // slab of whole heads and pixel count such that the staged q/k/v fit 16 KB: with 48 KB (3 blocks of 2 waves per CU) the
-    // load phase had too little in flight -- 0.60 -> 0.33 ms at level 0 (1.9 -> 3.4 TB/s algorithmic)
+    // slab of whole heads and pixel count such that the staged q/k/v (fp32 in LDS whatever the storage type) fit 16 KB: with
+    // 48 KB (3 blocks of 2 waves per CU) the load phase had too little in flight -- 0.60 -> 0.33 ms at level 0
     static const size_t budget = [] { const char* e = std::getenv("E2V_TATTN_LDS_KB"); return (size_t)(e ? std::atoi(e) : 16) * 1024; }();
     int hs = heads;
     while (hs > 1 && (size_t)F * 3 * hs * D * 4 > budget) hs = (hs + 1) / 2;
@@ -981,17 +1240,17 @@ void temporal_attention(const float* qkv, int ld, float* out, int ldo, int n, in
     PB = PB < 1 ? 1 : (PB > 8 ? 8 : PB);
     const size_t smem = (size_t)F * PB * 3 * CS * 4;
     if (smem > 64 * 1024) {           // does not fit the default LDS window: per-thread global version
-        hipLaunchKernelGGL(temporal_attn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv, ld, out, ldo, n, F, HW,
+        hipLaunchKernelGGL(temporal_attn_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv, ld, out, ldo, n, F, HW,
                            heads, D, scale);
         return;
     }
     const int npg = (HW + PB - 1) / PB;
-    hipLaunchKernelGGL(temporal_attn_lds_kernel, dim3((unsigned)(n * npg), C / CS), dim3(128), smem, s, qkv, ld, out, ldo, F, HW, C,
+    hipLaunchKernelGGL(temporal_attn_lds_kernel<T>, dim3((unsigned)(n * npg), C / CS), dim3(128), smem, s, qkv, ld, out, ldo, F, HW, C,
                        D, scale, PB, CS, npg);
 }
 
 // ---- row softmax in place (single-head VAE attention, 2304 keys, fp32 as the dep computes it) ----------
-__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int ld, int rows, int cols) {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int ld, int rows, int cols, __bf16* __restrict__ out16) {
     __shared__ float red[4];
     const int row = blockIdx.x;
     float* xr = x + (size_t)row * ld;
@@ -1016,13 +1275,18 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
     __syncthreads();
     l = (red[0] + red[1]) + (red[2] + red[3]);
     const float inv = 1.0f / l;
-    for (int c = threadIdx.x; c < cols; c += 256) xr[c] *= inv;
+    if (out16) {                      // bf16-activation mode: the probabilities feed a bf16 GEMM
+        __bf16* orow = out16 + (size_t)row * ld;
+        for (int c = threadIdx.x; c < cols; c += 256) orow[c] = (__bf16)(xr[c] * inv);
+    } else {
+        for (int c = threadIdx.x; c < cols; c += 256) xr[c] *= inv;
+    }
 }
 
-void softmax_rows(float* x, int ld, int rows, int cols, hipStream_t s) {
+void softmax_rows(float* x, int ld, int rows, int cols, hipStream_t s, void* out_bf16) {
     if (rows <= 0) return;
-    ProfScope ps("softmax_rows", 8.0 * rows * cols, 2.0 * 4.0 * rows * (double)cols, s);
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, x, ld, rows, cols);
+    ProfScope ps("softmax_rows", 8.0 * rows * cols, (out_bf16 ? 10.0 : 12.0) * rows * (double)cols, s);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, x, ld, rows, cols, static_cast<__bf16*>(out_bf16));
 }
 
 }  // namespace e2v

@@ -44,9 +44,14 @@ struct IgemmArgs {
     int x3 = 0;                    // 1: fp32 products from three bf16 pieces per operand on the bf16 MFMA (igemm_tile_x3); needs w3
     const void* w3 = nullptr;      // three bf16 planes of w ([N][K] each, w3_plane elements apart; batch entries sw apart)
     long long w3_plane = 0;
+    // bf16-ACTIVATION mode (bgemm.hip; e2v_set_compute_dtype(E2V_BF16)): a0 / a1 point at bf16 rows (lda in elements), the weights
+    // are w16, the product is v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  out is bf16 unless out_f32; resid is bf16 iff
+    // resid_bf16 (it is an activation) -- bias and rowbias stay fp32.
+    int a_bf16 = 0, out_f32 = 0, resid_bf16 = 0;
     int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, nbm_per = 0, tail_rb = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
 };
 void igemm(const IgemmArgs& a, hipStream_t s);
+void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s);      // bgemm.hip: the a_bf16 kernels (schedule already in `a`)
 
 // weight re-layout helpers (one-off, at finalize)
 // [O][I][3][3] -> [O][ceil(I/bke)][9][bke] (bke = 32 for the fp32 kernel, 64 for the bf16 one); row length below
@@ -93,6 +98,7 @@ struct GroupNormArgs {
     float* out = nullptr; int ldo = 0;                           // [samples*P][c0+c1]
     int samples = 0, P = 0, groups = 32;
     float eps = 1e-5f; int silu = 0;
+    int bf16 = 0;                  // 1: x0 / x1 / out are bf16 (statistics, scale / shift and the arithmetic stay fp32)
     float* ws_part = nullptr;      // workspace: samples*chunks*(c0+c1)*2 floats
     float* ws_scale = nullptr;     // workspace: samples*(c0+c1)*2 floats
 };
@@ -102,7 +108,7 @@ void groupnorm(const GroupNormArgs& a, hipStream_t s);
 // (+ SiLU) itself while it reads the tensor anyway (the Winograd input transform)
 void groupnorm_stats(const GroupNormArgs& a, hipStream_t s);
 void layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* out, int ldo,
-               int rows, int C, float eps, hipStream_t s);
+               int rows, int C, float eps, hipStream_t s, int bf16 = 0);      // bf16: x / out are bf16 rows
 
 // ---------------------------------------------------------------------------------------
 // attention (attn.hip)
@@ -118,18 +124,20 @@ struct AttnArgs {
     float scale = 1.f;
     int bf16 = 0;      // 1: bf16 MFMA for QK^T and PV (fp32 softmax / accumulate)
     int x3 = 0;        // 1: fp32-equivalent QK^T and PV from exactly split bf16 pieces (six MFMAs per product, f32x3 mode)
+    int io_bf16 = 0;   // 1: q / k / v / o are bf16 rows (strides in elements, multiples of 8); implies the bf16 MFMA
 };
 void flash_attention(const AttnArgs& a, hipStream_t s);      // throws Error(E2V_EINVAL) for a head dim without a kernel instance
 bool flash_attention_supports(int D);
 // temporal self-attention over the F frames of every pixel (attention.py:261-267), qkv = [n*F*HW][3C]
 void temporal_attention(const float* qkv, int ld, float* out, int ldo, int n, int F, int HW, int heads, int D,
-                        float scale, hipStream_t s);
-void softmax_rows(float* x, int ld, int rows, int cols, hipStream_t s);     // in place (VAE attention)
+                        float scale, hipStream_t s, int bf16 = 0);          // bf16: qkv / out are bf16 rows
+// in place (VAE attention); out_bf16 != null: the normalised probabilities are written there as bf16 ([rows][ld]) instead
+void softmax_rows(float* x, int ld, int rows, int cols, hipStream_t s, void* out_bf16 = nullptr);
 
 // ---------------------------------------------------------------------------------------
 // element-wise / layout (misc.hip)
 // ---------------------------------------------------------------------------------------
-void ncfhw_to_cl(const float* in, float* out, int n, int C, int Cpad, int FHW, float scale, hipStream_t s);
+void ncfhw_to_cl(const float* in, float* out, int n, int C, int Cpad, int FHW, float scale, hipStream_t s, int out_bf16 = 0);
 void cl_to_ncfhw(const float* in, int ld, float* out, int n, int C, int FHW, float mul, float add, int clamp, float lo,
                  float hi, hipStream_t s);
 void nchw_frames_to_ncfhw(const float* in, int ld, float* out, int n, int F, int C, int HW, float mul, float add,
@@ -138,7 +146,7 @@ void timestep_sinusoid(const long long* t, int nt, float* out, int n, int dim, i
                        hipStream_t s);
 void silu(const float* in, float* out, long long count, hipStream_t s);
 void transpose2d(const float* in, int ld_in, float* out, int ld_out, int rows, int cols, int batch,
-                 long long sb_in, long long sb_out, hipStream_t s);
+                 long long sb_in, long long sb_out, hipStream_t s, int bf16 = 0);
 // eps = eps_u + g (eps_c - eps_u); DDIM eta = 0 update (pipeline_tuneeeg2video.py:320-325)
 void ddim_cfg_step(const float* eps_u, const float* eps_c, const float* x, float* x_out, long long count,
                    float guidance, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_p, float sqrt_1m_a_p,
@@ -156,6 +164,10 @@ void dana_noise(const float* x0, const float* eps_div, const float* eps_same, co
                 float sqrt_beta, float* out, int B, int F, int C, int HW, hipStream_t s);
 // (x * 255) truncated to uint8, as save_videos_grid does (tuneavideo/util.py:29)
 void frames_to_u8(const float* in, unsigned char* out, long long count, hipStream_t s);
-void pad_cols(const float* in, int cols, float* out, int cols_pad, long long rows, hipStream_t s);
+void pad_cols(const float* in, int cols, float* out, int cols_pad, long long rows, hipStream_t s, int out_bf16 = 0);   // fp32 in; out fp32 or bf16
+
+// strided row copy between storage types (fp32 <-> bf16), zero-filling columns cols .. cols_out-1 of the output
+void cvt_rows(const void* in, int ld_in, int in_bf16, void* out, int ld_out, int out_bf16, long long rows, int cols, int cols_out,
+              hipStream_t s);
 
 }  // namespace e2v

@@ -3,6 +3,7 @@
 // guidance + DDIM update, the timestep sinusoid, SiLU, and a tiled transpose for the VAE attention.
 #include "kernels.h"
 #include "prof.h"
+#include "act_io.h"
 
 namespace e2v {
 
@@ -14,7 +15,8 @@ static inline int grid_for(size_t total, int cap = 8192) {
 }
 
 // in [n][C][FHW] -> out [n][FHW][Cpad] (extra channels zero), times `scale`
-__global__ void ncfhw_to_cl_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int C, int Cpad, int FHW,
+template <typename T>
+__global__ void ncfhw_to_cl_kernel(const float* __restrict__ in, T* __restrict__ out, int n, int C, int Cpad, int FHW,
                                    float scale) {
     const size_t total = (size_t)n * FHW * Cpad;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -22,12 +24,16 @@ __global__ void ncfhw_to_cl_kernel(const float* __restrict__ in, float* __restri
         const size_t r = i / Cpad;
         const int p = r % FHW;
         const int b = r / FHW;
-        out[i] = c < C ? in[((size_t)b * C + c) * FHW + p] * scale : 0.f;
+        out[i] = (T)(c < C ? in[((size_t)b * C + c) * FHW + p] * scale : 0.f);
     }
 }
-void ncfhw_to_cl(const float* in, float* out, int n, int C, int Cpad, int FHW, float scale, hipStream_t s) {
+void ncfhw_to_cl(const float* in, float* out, int n, int C, int Cpad, int FHW, float scale, hipStream_t s, int out_bf16) {
     const size_t total = (size_t)n * FHW * Cpad;
-    hipLaunchKernelGGL(ncfhw_to_cl_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, n, C, Cpad, FHW, scale);
+    if (out_bf16)
+        hipLaunchKernelGGL(ncfhw_to_cl_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s, in, reinterpret_cast<__bf16*>(out), n, C, Cpad,
+                           FHW, scale);
+    else
+        hipLaunchKernelGGL(ncfhw_to_cl_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, in, out, n, C, Cpad, FHW, scale);
 }
 
 // in [n][FHW][ld] (first C channels) -> out [n][C][FHW]; y = x*mul + add, optional clamp to [0,1]
@@ -107,16 +113,17 @@ void silu(const float* in, float* out, long long count, hipStream_t s) {
 }
 
 // out[b][c][r] = in[b][r][c], 32x32 LDS tiles
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, int ld_in, T* __restrict__ out,
                                                         int ld_out, int rows, int cols, long long sb_in, long long sb_out) {
-    __shared__ float tile[32][33];
-    const float* src = in + (size_t)blockIdx.z * sb_in;
-    float* dst = out + (size_t)blockIdx.z * sb_out;
+    __shared__ T tile[32][33];
+    const T* src = in + (size_t)blockIdx.z * sb_in;
+    T* dst = out + (size_t)blockIdx.z * sb_out;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     for (int k = ty; k < 32; k += 8) {
         const int r = r0 + k, c = c0 + tx;
-        tile[k][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_in + c] : 0.f;
+        tile[k][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_in + c] : (T)0.f;
     }
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
@@ -125,9 +132,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 void transpose2d(const float* in, int ld_in, float* out, int ld_out, int rows, int cols, int batch, long long sb_in,
-                 long long sb_out, hipStream_t s) {
+                 long long sb_out, hipStream_t s, int bf16) {
     dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, ld_in, out, ld_out, rows, cols, sb_in, sb_out);
+    if (bf16)
+        hipLaunchKernelGGL(transpose_kernel<__bf16>, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(in), ld_in,
+                           reinterpret_cast<__bf16*>(out), ld_out, rows, cols, sb_in, sb_out);
+    else
+        hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, s, in, ld_in, out, ld_out, rows, cols, sb_in, sb_out);
 }
 
 // pipeline_tuneeeg2video.py:320-325 fused: guidance, then DDIM (eta = 0):
@@ -227,17 +238,46 @@ void frames_to_u8(const float* in, unsigned char* out, long long count, hipStrea
     hipLaunchKernelGGL(frames_to_u8_kernel, dim3(grid_for((size_t)count / 4 + 1)), dim3(256), 0, s, in, out, (size_t)count);
 }
 
-__global__ void pad_cols_kernel(const float* __restrict__ in, int cols, float* __restrict__ out, int cp, size_t rows) {
+template <typename T>
+__global__ void pad_cols_kernel(const float* __restrict__ in, int cols, T* __restrict__ out, int cp, size_t rows) {
     const size_t total = rows * cp;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = i % cp;
         const size_t r = i / cp;
-        out[i] = c < cols ? in[r * cols + c] : 0.f;
+        out[i] = (T)(c < cols ? in[r * cols + c] : 0.f);
     }
 }
-void pad_cols(const float* in, int cols, float* out, int cols_pad, long long rows, hipStream_t s) {
+void pad_cols(const float* in, int cols, float* out, int cols_pad, long long rows, hipStream_t s, int out_bf16) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL(pad_cols_kernel, dim3(grid_for((size_t)rows * cols_pad)), dim3(256), 0, s, in, cols, out, cols_pad, (size_t)rows);
+    if (out_bf16)
+        hipLaunchKernelGGL(pad_cols_kernel<__bf16>, dim3(grid_for((size_t)rows * cols_pad)), dim3(256), 0, s, in, cols,
+                           reinterpret_cast<__bf16*>(out), cols_pad, (size_t)rows);
+    else
+        hipLaunchKernelGGL(pad_cols_kernel<float>, dim3(grid_for((size_t)rows * cols_pad)), dim3(256), 0, s, in, cols, out, cols_pad, (size_t)rows);
+}
+
+// strided row copy with a storage-type change: out[r][c] = in[r][c] for c < cols, 0 for cols <= c < cols_out
+template <typename TI, typename TO>
+__global__ void cvt_rows_kernel(const TI* __restrict__ in, int ld_in, TO* __restrict__ out, int ld_out, size_t rows, int cols, int cols_out) {
+    const size_t total = rows * cols_out;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % cols_out;
+        const size_t r = i / cols_out;
+        out[r * ld_out + c] = c < cols ? (TO)(float)in[r * ld_in + c] : (TO)0.f;
+    }
+}
+void cvt_rows(const void* in, int ld_in, int in_bf16, void* out, int ld_out, int out_bf16, long long rows, int cols, int cols_out,
+              hipStream_t s) {
+    if (rows <= 0 || cols_out <= 0) return;
+    const dim3 g(grid_for((size_t)rows * cols_out)), b(256);
+    if (in_bf16 && out_bf16)
+        hipLaunchKernelGGL((cvt_rows_kernel<__bf16, __bf16>), g, b, 0, s, static_cast<const __bf16*>(in), ld_in, static_cast<__bf16*>(out), ld_out, (size_t)rows, cols, cols_out);
+    else if (in_bf16)
+        hipLaunchKernelGGL((cvt_rows_kernel<__bf16, float>), g, b, 0, s, static_cast<const __bf16*>(in), ld_in, static_cast<float*>(out), ld_out, (size_t)rows, cols, cols_out);
+    else if (out_bf16)
+        hipLaunchKernelGGL((cvt_rows_kernel<float, __bf16>), g, b, 0, s, static_cast<const float*>(in), ld_in, static_cast<__bf16*>(out), ld_out, (size_t)rows, cols, cols_out);
+    else
+        hipLaunchKernelGGL((cvt_rows_kernel<float, float>), g, b, 0, s, static_cast<const float*>(in), ld_in, static_cast<float*>(out), ld_out, (size_t)rows, cols, cols_out);
 }
 
 }  // namespace e2v

@@ -186,6 +186,24 @@ struct Packer {
         to_bf16(w, d, n, s);
         return d;
     }
+    // every form of one [out][in] matrix: fp32 as it is, bf16 with rows padded to a multiple of 8 (16-byte pieces), f32x3 planes
+    LinW mk_lin(const float* w, const float* b, int in, int out) {
+        const int in16 = (in + 7) / 8 * 8;
+        const void* w16;
+        if (in16 == in) {
+            w16 = half(w, (size_t)out * in);
+        } else {
+            float* tmp = nullptr;
+            E2V_HIP(hipMalloc((void**)&tmp, (size_t)out * in16 * sizeof(float)));
+            pad_cols(w, in, tmp, in16, out, s);
+            w16 = half(tmp, (size_t)out * in16);
+            E2V_HIP(hipStreamSynchronize(s));
+            (void)hipFree(tmp);
+        }
+        LinW l{w, b, in, out, w16, split3(w, (size_t)out * in)};
+        l.in16 = in16;
+        return l;
+    }
     const void* split3(const float* w, size_t n) {           // three bf16 planes (f32x3 mode only)
         if (!c->x3_compute) return nullptr;
         float* d = c->dev_alloc((3 * n + 1) / 2);
@@ -195,7 +213,7 @@ struct Packer {
     NormW norm(const std::string& n) { return NormW{t(n + ".weight").d, t(n + ".bias").d, (int)t(n + ".weight").shape[0]}; }
     LinW lin(const std::string& n, bool bias = true) {       // Linear or 1x1 conv: [out][in] as it is
         const WTensor& w = t(n + ".weight");
-        return LinW{w.d, bias ? t(n + ".bias").d : nullptr, (int)w.shape[1], (int)w.shape[0], half(w.d, w.numel), split3(w.d, w.numel)};
+        return mk_lin(w.d, bias ? t(n + ".bias").d : nullptr, (int)w.shape[1], (int)w.shape[0]);
     }
     // [O][I][3][3] -> [O][chunk][tap][32] (+ a bf16 copy in chunks of 64) (+ Winograd-domain weights for stride-1 convs)
     ConvW conv3(const std::string& n, bool stride1 = true) {
@@ -230,7 +248,9 @@ struct Packer {
                 wino4_x3 = split3(u4, (size_t)36 * co * ci);
             }
         }
-        return ConvW{d, t(n + ".bias").d, ci, cp, co, d16, ld32, ld64, wino, wino4, wino_x3, wino4_x3};
+        ConvW cw{d, t(n + ".bias").d, ci, cp, co, d16, ld32, ld64, wino, wino4, wino_x3, wino4_x3};
+        cw.cin_pad16 = (ci + 7) / 8 * 8;
+        return cw;
     }
     LinW fuse_rows(const std::vector<std::string>& names, bool bias) {   // stack Linear weights along `out`
         int in = 0, out = 0;
@@ -244,7 +264,7 @@ struct Packer {
             if (bias) copy_rows(t(n + ".bias").d, (int)w.shape[0], b + r, (int)w.shape[0], 1, (int)w.shape[0], s);
             r += (int)w.shape[0];
         }
-        return LinW{d, b, in, out, half(d, (size_t)out * in), split3(d, (size_t)out * in)};
+        return mk_lin(d, b, in, out);
     }
     LinW geglu(const std::string& n) {        // rows [value 0..4C) | gate 0..4C)] -> per 64: [32 value | 32 gate]
         const WTensor& w = t(n + ".weight");
@@ -259,7 +279,7 @@ struct Packer {
             copy_rows(bsrc.d + q * 32, 32, b + q * 64, 32, 1, 32, s);
             copy_rows(bsrc.d + half + q * 32, 32, b + q * 64 + 32, 32, 1, 32, s);
         }
-        return LinW{d, b, in, out, this->half(d, (size_t)out * in), split3(d, (size_t)out * in)};
+        return mk_lin(d, b, in, out);
     }
     ResW resnet(const std::string& p, bool temb) {
         ResW r;
@@ -383,8 +403,7 @@ void e2v_ctx::finalize(int which) {
                 const int out = (int)w.shape[0];
                 float* wp = dev_alloc((size_t)out * sem_in_pad);
                 pad_cols(w.d, cfg.sem_in_features, wp, sem_in_pad, out, nullptr);
-                const size_t numel = (size_t)out * sem_in_pad;
-                sem.push_back(LinW{wp, P.t(n + ".bias").d, sem_in_pad, out, P.half(wp, numel), P.split3(wp, numel)});
+                sem.push_back(P.mk_lin(wp, P.t(n + ".bias").d, sem_in_pad, out));
             } else {
                 sem.push_back(P.lin(n));
             }
@@ -433,6 +452,16 @@ struct Runner {
     hipStream_t s;
     int res_idx = 0, tr_idx = 0;      // position in the per-generate caches (resnets with a time embedding / transformers)
     Pool& pool() { return c->pool; }
+    // bf16-activation mode (e2v_set_compute_dtype(E2V_BF16)): every activation the graph stores in HBM is bf16; accumulation,
+    // GroupNorm / LayerNorm statistics, softmax and the time-embedding rows stay fp32
+    bool bf() const { return c->bf16_compute; }
+    Act new_act(int64_t rows, int C) { return Act(pool(), rows, C, bf()); }
+    // fp32 rows -> bf16 rows padded to `cpad` channels (boundary tensors: latents, z, images, conditioning)
+    Act to_act16(const float* x, int cols, int cpad, int64_t rows) {
+        Act o(pool(), rows, cpad, true);
+        pad_cols(x, cols, o.p, cpad, rows, s, 1);
+        return o;
+    }
 
     void gn_ws(int samples, int P, int C) {
         const size_t need_p = (size_t)samples * groupnorm_chunks(P) * C * 2;
@@ -456,8 +485,9 @@ struct Runner {
         const int C = c0 + c1;
         E2V_REQUIRE(C == w.c && C % groups == 0 && c0 % 4 == 0 && c1 % 4 == 0, E2V_ESHAPE, "GroupNorm channel mismatch");
         gn_ws(samples, P, C);
-        Act out(pool(), (int64_t)samples * P, C);
+        Act out = new_act((int64_t)samples * P, C);
         GroupNormArgs a;
+        a.bf16 = bf() ? 1 : 0;
         a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1; a.ld0 = c0; a.ld1 = c1;
         a.gamma = w.g; a.beta = w.b; a.out = out.p; a.ldo = C;
         a.samples = samples; a.P = P; a.groups = groups; a.eps = eps; a.silu = act ? 1 : 0;
@@ -472,6 +502,7 @@ struct Runner {
         E2V_REQUIRE(C == w.c && C % groups == 0 && c0 % 4 == 0 && c1 % 4 == 0, E2V_ESHAPE, "GroupNorm channel mismatch");
         gn_ws(samples, P, C);
         GroupNormArgs a;
+        a.bf16 = bf() ? 1 : 0;
         a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1; a.ld0 = c0; a.ld1 = c1;
         a.gamma = w.g; a.beta = w.b; a.samples = samples; a.P = P; a.groups = groups; a.eps = eps;
         a.ws_part = c->gn_part; a.ws_scale = c->gn_scale;
@@ -493,22 +524,28 @@ struct Runner {
 
     Act ln(const NormW& w, const Act& x) {
         E2V_REQUIRE(x.C == w.c && x.C % 4 == 0 && x.C <= 1280, E2V_ESHAPE, "LayerNorm width unsupported");
-        Act out(pool(), x.rows, x.C);
-        layernorm(x.p, x.C, w.g, w.b, out.p, x.C, (int)x.rows, x.C, 1e-5f, s);
+        Act out = new_act(x.rows, x.C);
+        layernorm(x.p, x.C, w.g, w.b, out.p, x.C, (int)x.rows, x.C, 1e-5f, s, bf() ? 1 : 0);
         return out;
     }
 
-    // out[M][N] = A[M][K] W^T + b (+ resid); geglu: out[M][N/2]
+    // out[M][N] = A[M][K] W^T + b (+ resid); geglu: out[M][N/2].
+    // bf16-activation mode: A, resid and out are bf16 unless `f32_io` (the time-embedding MLP: fp32 rows in, fp32 rows out,
+    // fp32 arithmetic) or `out_f32` (a boundary tensor: VAE moments, attention scores)
     Act linear(const LinW& w, const float* a, int lda, int64_t M, const float* resid = nullptr, int ldr = 0,
-               bool geglu = false, const float* a1 = nullptr, int c1 = 0, int lda1 = 0) {
-        const int K0 = w.in - c1;
-        E2V_REQUIRE(K0 > 0 && K0 % 4 == 0 && c1 % 4 == 0 && lda % 4 == 0, E2V_ESHAPE, "linear: K must be a multiple of 4");
-        Act out(pool(), M, geglu ? w.out / 2 : w.out);
+               bool geglu = false, const float* a1 = nullptr, int c1 = 0, int lda1 = 0, bool f32_io = false, bool out_f32 = false) {
+        const bool b16 = bf() && !f32_io;
+        const int K = b16 ? w.in16 : w.in;
+        const int K0 = K - c1;
+        const int gran = b16 ? 8 : 4;
+        E2V_REQUIRE(K0 > 0 && K0 % gran == 0 && c1 % gran == 0 && lda % gran == 0, E2V_ESHAPE, "linear: K must be a multiple of 4 (bf16: 8)");
+        Act out(pool(), M, geglu ? w.out / 2 : w.out, b16 && !out_f32);
         IgemmArgs g;
         g.a0 = a; g.c0 = K0; g.lda0 = lda; g.a1 = a1; g.c1 = c1; g.lda1 = lda1;
-        g.w = w.w; g.ldw = w.in; g.ldw16 = w.in; g.out = out.p; g.ldc = out.C; g.bias = w.b;
+        g.w = w.w; g.ldw = w.in; g.ldw16 = w.in16; g.out = out.p; g.ldc = out.C; g.bias = w.b;
         g.resid = resid; g.ldr = ldr; g.M = (int)M; g.N = w.out; g.taps = 1; g.geglu = geglu ? 1 : 0;
-        g.bf16 = c->bf16_compute ? 1 : 0; g.w16 = w.w16;
+        g.w16 = w.w16;
+        if (b16) { g.a_bf16 = 1; g.out_f32 = out_f32 ? 1 : 0; g.resid_bf16 = resid ? 1 : 0; }
         if (c->x3_compute && w.w3) { g.x3 = 1; g.w3 = w.w3; g.w3_plane = (long long)w.out * w.in; }
         igemm(g, s);
         return out;
@@ -519,10 +556,10 @@ struct Runner {
     // gn_P rows) is applied on the way in -- only valid when winograd() says so
     Act conv3(const ConvW& w, const float* x0, int c0, const float* x1, int c1, Geo geo, int Hi, int Wi, int Ho, int Wo,
               int stride, int pad, const float* rowbias = nullptr, int rows_per_sample = 1, const float* resid = nullptr,
-              int gn_P = 0, int rb_ld = -1) {                  // rb_ld: stride between the samples' rowbias rows (0: one row for all)
+              int gn_P = 0, int rb_ld = -1, bool out_f32 = false) {   // rb_ld: stride between the samples' rowbias rows (0: one row for all)
         if (rb_ld < 0) rb_ld = w.cout;
-        E2V_REQUIRE(c0 + c1 == w.cin_pad, E2V_ESHAPE, "conv: input channels do not match the weight");
-        Act out(pool(), (int64_t)geo.nimg * Ho * Wo, w.cout);
+        E2V_REQUIRE(c0 + c1 == (bf() ? w.cin_pad16 : w.cin_pad), E2V_ESHAPE, "conv: input channels do not match the weight");
+        Act out(pool(), (int64_t)geo.nimg * Ho * Wo, w.cout, bf() && !out_f32);
         if (const int wm = winograd(w, stride, pad, Hi, Wi, Ho, Wo)) {
             WinoArgs a;
             a.m = wm;
@@ -551,7 +588,8 @@ struct Runner {
         g.rowbias = rowbias; g.rb_ld = rb_ld; g.rows_per_sample = rows_per_sample;
         g.resid = resid; g.ldr = w.cout;
         g.M = (int)out.rows; g.N = w.cout; g.taps = 9;
-        g.bf16 = c->bf16_compute ? 1 : 0; g.w16 = w.w16;
+        g.w16 = w.w16;
+        if (bf()) { g.a_bf16 = 1; g.out_f32 = out_f32 ? 1 : 0; g.resid_bf16 = resid ? 1 : 0; }
         g.Ho = Ho; g.Wo = Wo; g.Hi = Hi; g.Wi = Wi; g.Hs = geo.H; g.Ws = geo.W; g.stride = stride; g.pad = pad;
         if (Hi != geo.H || Wi != geo.W) {
             g.upsample = 1;
@@ -576,7 +614,7 @@ struct Runner {
                 tp_ld = 0;
             } else {
                 E2V_REQUIRE(temb_silu != nullptr, E2V_EINVAL, "resnet needs a time embedding");
-                tp = linear(w.temb, temb_silu, temb_dim, samples);                                    // :183
+                tp = linear(w.temb, temb_silu, temb_dim, samples, nullptr, 0, false, nullptr, 0, 0, true);   // :183 (fp32 rows)
                 tpp = tp.p;
             }
         }
@@ -608,16 +646,17 @@ struct Runner {
 
     // Transformer3DModel.forward + BasicTransformerBlock.forward (attention.py:89-136, 232-269)
     Act twice(const Act& a) {                        // [a ; a] along the rows
-        Act d(pool(), 2 * a.rows, a.C);
-        const size_t bytes = (size_t)a.rows * a.C * sizeof(float);
+        Act d(pool(), 2 * a.rows, a.C, a.bf16);
+        const size_t bytes = a.bytes();
         E2V_HIP(hipMemcpyAsync(d.p, a.p, bytes, hipMemcpyDeviceToDevice, s));
-        E2V_HIP(hipMemcpyAsync(d.p + (size_t)a.rows * a.C, a.p, bytes, hipMemcpyDeviceToDevice, s));
+        E2V_HIP(hipMemcpyAsync(reinterpret_cast<char*>(d.p) + bytes, a.p, bytes, hipMemcpyDeviceToDevice, s));
         return d;
     }
 
     // n_shared > 0: `x` holds only n_shared = n / 2 samples whose two copies (the uncond / cond halves of a classifier-free
     // guidance batch, pipeline_tuneeeg2video.py:313) would be bit-identical up to the first use of the conditioning: the
     // per-frame GroupNorm, proj_in and the whole sparse-causal self-attention run once, then the tokens are duplicated.
+    // `cond` is in the activation type (bf16 mode: already converted, see unet_forward_cl).
     Act transformer(const TransW& w, const Act& x_in, int n, int F, int HW, const float* cond, int T, int heads, int groups,
                     int n_shared = 0) {
         const int C = w.C, D = C / heads;
@@ -628,6 +667,7 @@ struct Runner {
         const Act* xp = &x_in;
         const float scale = 1.0f / std::sqrt((float)D);
         E2V_REQUIRE(C % heads == 0 && D % 8 == 0, E2V_EINVAL, "attention head dim must be a multiple of 8");
+        const int io16 = bf() ? 1 : 0;
         Act t;
         {
             Act hn = gn(w.norm, xp->p, C, nullptr, 0, n1 * F, HW, groups, 1e-6f, false);              // :99 (per frame)
@@ -637,11 +677,11 @@ struct Runner {
             Act nrm = ln(w.ln1, t);
             Act qkv = linear(w.a1_qkv, nrm.p, C, rows1);
             nrm.reset();
-            Act ao(pool(), rows1, C);
+            Act ao = new_act(rows1, C);
             AttnArgs a;
-            a.q = qkv.p; a.ldq = 3 * C; a.k = qkv.p + C; a.v = qkv.p + 2 * C; a.ldkv = 3 * C; a.o = ao.p; a.ldo = C;
+            a.q = qkv.p; a.ldq = 3 * C; a.k = qkv.at(C); a.v = qkv.at(2 * C); a.ldkv = 3 * C; a.o = ao.p; a.ldo = C;
             a.n = n1; a.F = F; a.heads = heads; a.D = D; a.Nq = HW; a.Nk = HW; a.mode = 0; a.scale = scale;
-            a.bf16 = c->bf16_compute ? 1 : 0;
+            a.io_bf16 = io16;
             a.x3 = c->x3_compute ? 1 : 0;
             flash_attention(a, s);
             qkv.reset();
@@ -662,11 +702,11 @@ struct Runner {
             if (!cached) kv_own = linear(w.a2_kv, cond, w.a2_kv.in, (int64_t)n * T);
             const Act& kv = cached ? c->kv_cache[tr_idx] : kv_own;
             ++tr_idx;
-            Act ao(pool(), rows, C);
+            Act ao = new_act(rows, C);
             AttnArgs a;
-            a.q = q.p; a.ldq = C; a.k = kv.p; a.v = kv.p + C; a.ldkv = 2 * C; a.o = ao.p; a.ldo = C;
+            a.q = q.p; a.ldq = C; a.k = kv.p; a.v = kv.at(C); a.ldkv = 2 * C; a.o = ao.p; a.ldo = C;
             a.n = n; a.F = F; a.heads = heads; a.D = D; a.Nq = HW; a.Nk = T; a.mode = 1; a.scale = scale;
-            a.bf16 = c->bf16_compute ? 1 : 0;
+            a.io_bf16 = io16;
             a.x3 = c->x3_compute ? 1 : 0;
             flash_attention(a, s);
             t = linear(w.a2_out, ao.p, C, rows, t.p, C);
@@ -682,42 +722,47 @@ struct Runner {
             Act nrm = ln(w.lnt, t);
             Act qkv = linear(w.at_qkv, nrm.p, C, rows);
             nrm.reset();
-            Act ao(pool(), rows, C);
-            temporal_attention(qkv.p, 3 * C, ao.p, C, n, F, HW, heads, D, scale, s);
+            Act ao = new_act(rows, C);
+            temporal_attention(qkv.p, 3 * C, ao.p, C, n, F, HW, heads, D, scale, s, io16);
             qkv.reset();
             t = linear(w.at_out, ao.p, C, rows, t.p, C);
         }
         return linear(w.proj_out, t.p, C, rows, xp->p, C);                                            // :123,130
     }
 
-    // AttentionBlock of the VAE mid block (diffusers 0.11.1): one head over H*W tokens, per image
+    // AttentionBlock of the VAE mid block (diffusers 0.11.1): one head over H*W tokens, per image.  The scores and the softmax
+    // are fp32 in both modes; in bf16-activation mode the probabilities are rounded once, on their way into the PV product.
     Act vae_attention(const VAEAttnW& w, const Act& x, int nimg, int HW, int groups, float eps) {
         const int C = w.C;
-        E2V_REQUIRE(HW % 4 == 0, E2V_EINVAL, "VAE attention needs H*W to be a multiple of 4");
+        E2V_REQUIRE(HW % (bf() ? 8 : 4) == 0, E2V_EINVAL, "VAE attention needs H*W to be a multiple of 4 (bf16: 8)");
         const int64_t rows = (int64_t)nimg * HW;
         Act qkv;
         {
             Act hn = gn(w.norm, x.p, C, nullptr, 0, nimg, HW, groups, eps, false);
             qkv = linear(w.qkv, hn.p, C, rows);
         }
-        Act sc(pool(), rows, HW);
+        Act sc(pool(), rows, HW);                                   // fp32 scores
         {
             IgemmArgs g;
-            g.a0 = qkv.p; g.c0 = C; g.lda0 = 3 * C; g.w = qkv.p + C; g.ldw = 3 * C;
+            g.a0 = qkv.p; g.c0 = C; g.lda0 = 3 * C; g.w = qkv.at(C); g.ldw = 3 * C;
             g.out = sc.p; g.ldc = HW; g.M = HW; g.N = HW; g.taps = 1; g.alpha = 1.0f / std::sqrt((float)C);
             g.batch = nimg; g.sa0 = (long long)HW * 3 * C; g.sw = (long long)HW * 3 * C; g.sout = (long long)HW * HW;
+            if (bf()) { g.a_bf16 = 1; g.out_f32 = 1; g.w16 = qkv.at(C); g.ldw16 = 3 * C; }
             igemm(g, s);
         }
-        softmax_rows(sc.p, HW, (int)rows, HW, s);
-        Act vt(pool(), (int64_t)nimg * C, HW);
-        transpose2d(qkv.p + 2 * C, 3 * C, vt.p, HW, HW, C, nimg, (long long)HW * 3 * C, (long long)C * HW, s);
+        Act p16;
+        if (bf()) p16 = Act(pool(), rows, HW, true);
+        softmax_rows(sc.p, HW, (int)rows, HW, s, bf() ? p16.p : nullptr);
+        Act vt = new_act((int64_t)nimg * C, HW);
+        transpose2d(qkv.at(2 * C), 3 * C, vt.p, HW, HW, C, nimg, (long long)HW * 3 * C, (long long)C * HW, s, bf() ? 1 : 0);
         qkv.reset();
-        Act o(pool(), rows, C);
+        Act o = new_act(rows, C);
         {
             IgemmArgs g;
-            g.a0 = sc.p; g.c0 = HW; g.lda0 = HW; g.w = vt.p; g.ldw = HW; g.out = o.p; g.ldc = C;
+            g.a0 = bf() ? p16.p : sc.p; g.c0 = HW; g.lda0 = HW; g.w = vt.p; g.ldw = HW; g.out = o.p; g.ldc = C;
             g.M = HW; g.N = C; g.taps = 1; g.batch = nimg;
             g.sa0 = (long long)HW * HW; g.sw = (long long)C * HW; g.sout = (long long)HW * C;
+            if (bf()) { g.a_bf16 = 1; g.w16 = vt.p; g.ldw16 = HW; }
             igemm(g, s);
         }
         return linear(w.proj, o.p, C, rows, x.p, C);
@@ -757,11 +802,23 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
     if (!step_cache_on) {
         Act sin(pool, N, boc0);
         timestep_sinusoid(d_timesteps, n_t, sin.p, N, boc0, cfg.flip_sin_to_cos, cfg.freq_shift, s);
-        Act e1 = R.linear(unet.te1, sin.p, boc0, N);
+        Act e1 = R.linear(unet.te1, sin.p, boc0, N, nullptr, 0, false, nullptr, 0, 0, true);        // fp32 rows in both modes
         silu(e1.p, e1.p, (long long)N * temb_dim, s);
-        Act emb = R.linear(unet.te2, e1.p, temb_dim, N);
+        Act emb = R.linear(unet.te2, e1.p, temb_dim, N, nullptr, 0, false, nullptr, 0, 0, true);
         silu(emb.p, emb.p, (long long)N * temb_dim, s);
         temb_silu = std::move(emb);
+    }
+    // bf16-activation mode: the two fp32 boundary tensors are converted once -- the latents (zero-padded to 8 channels, the
+    // 16-byte granule of the bf16 kernels) and, when no per-run cache holds to_k / to_v already, the conditioning
+    Act sample16, cond16;
+    const int cin_act = R.bf() ? unet.conv_in.cin_pad16 : unet.conv_in.cin_pad;
+    if (R.bf()) {
+        sample16 = R.to_act16(sample_cl, unet.conv_in.cin_pad, cin_act, (int64_t)N1 * F * H * W);
+        sample_cl = sample16.p;
+        if (!step_cache_on) {
+            cond16 = R.to_act16(cond, cfg.cross_attention_dim, cfg.cross_attention_dim, (int64_t)N * T);
+            cond = cond16.p;
+        }
     }
 
     int hs[4], ws[4];
@@ -774,7 +831,7 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
     auto P_of = [&](int l) { return F * hs[l] * ws[l]; };
     auto geo_of = [&](int l) { return Geo{N * F, hs[l], ws[l]}; };
 
-    Act x = R.conv3(unet.conv_in, sample_cl, unet.conv_in.cin_pad, nullptr, 0, Geo{N1 * F, hs[0], ws[0]}, H, W, H, W, 1, 1);   // :358
+    Act x = R.conv3(unet.conv_in, sample_cl, cin_act, nullptr, 0, Geo{N1 * F, hs[0], ws[0]}, H, W, H, W, 1, 1);   // :358
     Act x_shared;                                     // cfg_pair: the N / 2-sample conv_in output feeding the first resnet
     if (cfg_pair) { x_shared = std::move(x); x = R.twice(x_shared); }
     // The skip tensors alias the running activation in the reference; here the running tensor is moved
@@ -826,7 +883,7 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
     }
     Act hn = R.gn(unet.norm_out, h.p, h.C, nullptr, 0, N, P_of(0), groups, eps, true);                 // :406-407
     h.reset();
-    Act out = R.conv3(unet.conv_out, hn.p, hn.C, nullptr, 0, geo_of(0), H, W, H, W, 1, 1);             // :408
+    Act out = R.conv3(unet.conv_out, hn.p, hn.C, nullptr, 0, geo_of(0), H, W, H, W, 1, 1, nullptr, 1, nullptr, 0, -1, true);   // :408 (eps: fp32)
     E2V_HIP(hipGetLastError());
     return out;
 }
@@ -849,11 +906,18 @@ void e2v_ctx::build_step_caches(const int64_t* ts, int steps, const float* cond,
     E2V_HIP(hipMemcpyAsync(d_timesteps, ts, sizeof(int64_t) * steps, hipMemcpyHostToDevice, s));
     Act sin(pool, steps, boc0);
     timestep_sinusoid(d_timesteps, steps, sin.p, steps, boc0, cfg.flip_sin_to_cos, cfg.freq_shift, s);
-    Act e1 = R.linear(unet.te1, sin.p, boc0, steps);
+    Act e1 = R.linear(unet.te1, sin.p, boc0, steps, nullptr, 0, false, nullptr, 0, 0, true);
     silu(e1.p, e1.p, (long long)steps * temb_dim, s);
-    Act emb = R.linear(unet.te2, e1.p, temb_dim, steps);
+    Act emb = R.linear(unet.te2, e1.p, temb_dim, steps, nullptr, 0, false, nullptr, 0, 0, true);
     silu(emb.p, emb.p, (long long)steps * temb_dim, s);
-    auto add_res = [&](const ResW& r) { if (r.temb.w) temb_cache.push_back(R.linear(r.temb, emb.p, temb_dim, steps)); };
+    Act cond16;
+    if (R.bf()) {
+        cond16 = R.to_act16(cond, cfg.cross_attention_dim, cfg.cross_attention_dim, (int64_t)N * T);
+        cond = cond16.p;
+    }
+    auto add_res = [&](const ResW& r) {
+        if (r.temb.w) temb_cache.push_back(R.linear(r.temb, emb.p, temb_dim, steps, nullptr, 0, false, nullptr, 0, 0, true));
+    };
     auto add_tr = [&](const TransW& w) { kv_cache.push_back(R.linear(w.a2_kv, cond, w.a2_kv.in, (int64_t)N * T)); };
     for (const auto& b : unet.down) { for (const auto& r : b.res) add_res(r); for (const auto& a : b.attn) add_tr(a); }
     add_res(unet.mid_r0); add_tr(unet.mid_attn); add_res(unet.mid_r1);
@@ -870,8 +934,21 @@ void e2v_ctx::vae_decode_frames(const float* z_cl, int nf, int h, int w, float* 
     const float eps = cfg.vae_norm_eps;
     const int lat = cfg.vae_latent_channels;
     int H = h, W = w;
-    Act x = R.linear(vae.post_quant, z_cl, lat, (int64_t)nf * H * W);
-    x = R.conv3(vae.dec_in, x.p, lat, nullptr, 0, Geo{nf, H, W}, H, W, H, W, 1, 1);
+    Act z16;
+    int zc = lat;
+    if (R.bf()) {                                // bf16-activation mode: z zero-padded to the 8-channel granule
+        zc = vae.post_quant.in16;
+        z16 = R.to_act16(z_cl, lat, zc, (int64_t)nf * H * W);
+        z_cl = z16.p;
+    }
+    Act x = R.linear(vae.post_quant, z_cl, zc, (int64_t)nf * H * W);
+    if (R.bf() && x.C != vae.dec_in.cin_pad16) {         // 4 -> 8 channels for the 3x3 conv's 16-byte pieces
+        Act xp(pool, x.rows, vae.dec_in.cin_pad16, true);
+        E2V_HIP(hipMemsetAsync(xp.p, 0, xp.bytes(), s));
+        E2V_HIP(hipMemcpy2DAsync(xp.p, (size_t)xp.C * 2, x.p, (size_t)x.C * 2, (size_t)x.C * 2, (size_t)x.rows, hipMemcpyDeviceToDevice, s));
+        x = std::move(xp);
+    }
+    x = R.conv3(vae.dec_in, x.p, x.C, nullptr, 0, Geo{nf, H, W}, H, W, H, W, 1, 1);
     x = R.resnet(vae.dec_mid0, x.p, x.C, nullptr, 0, nf, H * W, Geo{nf, H, W}, g, eps, nullptr, 0);
     x = R.vae_attention(vae.dec_attn, x, nf, H * W, g, eps);
     x = R.resnet(vae.dec_mid1, x.p, x.C, nullptr, 0, nf, H * W, Geo{nf, H, W}, g, eps, nullptr, 0);
@@ -885,7 +962,7 @@ void e2v_ctx::vae_decode_frames(const float* z_cl, int nf, int h, int w, float* 
     }
     Act hn = R.gn(vae.dec_norm_out, x.p, x.C, nullptr, 0, nf, H * W, g, eps, true);
     x.reset();
-    Act y = R.conv3(vae.dec_out, hn.p, hn.C, nullptr, 0, Geo{nf, H, W}, H, W, H, W, 1, 1);
+    Act y = R.conv3(vae.dec_out, hn.p, hn.C, nullptr, 0, Geo{nf, H, W}, H, W, H, W, 1, 1, nullptr, 1, nullptr, 0, -1, true);   // frames: fp32
     E2V_HIP(hipMemcpyAsync(out_cl, y.p, (size_t)y.rows * y.C * sizeof(float), hipMemcpyDeviceToDevice, s));
     E2V_HIP(hipGetLastError());
 }
@@ -896,7 +973,14 @@ void e2v_ctx::vae_encode_frames(const float* img_cl4, int n, int H0, int W0, flo
     const int g = cfg.vae_norm_num_groups;
     const float eps = cfg.vae_norm_eps;
     int H = H0, W = W0;
-    Act x = R.conv3(vae.enc_in, img_cl4, vae.enc_in.cin_pad, nullptr, 0, Geo{n, H, W}, H, W, H, W, 1, 1);
+    Act img16;
+    int ic = vae.enc_in.cin_pad;
+    if (R.bf()) {
+        ic = vae.enc_in.cin_pad16;
+        img16 = R.to_act16(img_cl4, vae.enc_in.cin_pad, ic, (int64_t)n * H * W);
+        img_cl4 = img16.p;
+    }
+    Act x = R.conv3(vae.enc_in, img_cl4, ic, nullptr, 0, Geo{n, H, W}, H, W, H, W, 1, 1);
     for (size_t i = 0; i < vae.enc_down.size(); ++i) {
         const VAEW::Block& b = vae.enc_down[i];
         for (const ResW& r : b.res) x = R.resnet(r, x.p, x.C, nullptr, 0, n, H * W, Geo{n, H, W}, g, eps, nullptr, 0);
@@ -912,7 +996,7 @@ void e2v_ctx::vae_encode_frames(const float* img_cl4, int n, int H0, int W0, flo
     Act hn = R.gn(vae.enc_norm_out, x.p, x.C, nullptr, 0, n, H * W, g, eps, true);
     x.reset();
     Act y = R.conv3(vae.enc_out, hn.p, hn.C, nullptr, 0, Geo{n, H, W}, H, W, H, W, 1, 1);
-    Act m = R.linear(vae.quant, y.p, y.C, y.rows);
+    Act m = R.linear(vae.quant, y.p, y.C, y.rows, nullptr, 0, false, nullptr, 0, 0, false, true);          // moments: fp32
     E2V_HIP(hipMemcpyAsync(moments_cl, m.p, (size_t)m.rows * m.C * sizeof(float), hipMemcpyDeviceToDevice, s));
     E2V_HIP(hipGetLastError());
 }

@@ -14,11 +14,13 @@ namespace e2v {
 
 struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
 struct LinW { const float* w = nullptr; const float* b = nullptr; int in = 0, out = 0; const void* w16 = nullptr;
-              const void* w3 = nullptr; };      // three bf16 planes of w (out*in elements apart) for the f32x3 mode
+              const void* w3 = nullptr;         // three bf16 planes of w (out*in elements apart) for the f32x3 mode
+              int in16 = 0; };                  // row length of w16: `in` rounded up to 8 (zero columns; 16-byte DMA pieces)
 struct ConvW { const float* w = nullptr; const float* b = nullptr; int cin = 0, cin_pad = 0, cout = 0; const void* w16 = nullptr; int ldw = 0, ldw16 = 0;
                const float* wino = nullptr;      // [16][cout][cin] Winograd F(2x2,3x3)-domain weights (stride-1 convs wide enough to profit)
                const float* wino4 = nullptr;     // [36][cout][cin] F(4x4,3x3)-domain weights (only when that form is enabled)
-               const void* wino_x3 = nullptr; const void* wino4_x3 = nullptr; };   // their three-plane bf16 splits (f32x3 mode)
+               const void* wino_x3 = nullptr; const void* wino4_x3 = nullptr;     // their three-plane bf16 splits (f32x3 mode)
+               int cin_pad16 = 0; };             // channels of the bf16 input: cin rounded up to 8
 
 struct ResW {
     NormW n1, n2;

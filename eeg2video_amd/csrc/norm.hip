@@ -10,6 +10,7 @@
 // (unet_blocks.py:487), whose groups may straddle the seam (1920/32 = 60 does not divide 1280).
 #include "kernels.h"
 #include "prof.h"
+#include "act_io.h"
 
 namespace e2v {
 
@@ -28,7 +29,8 @@ static int quad_tile(int cq) {
 }
 
 // grid (chunks, slabs); part[((slab*chunks + chunk)*Ctot + coff + c)*2 + {0,1}]
-__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int ld, int C, int P, int chunks,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int ld, int C, int P, int chunks,
                                                          float* __restrict__ part, int Ctot, int coff, int QT) {
     __shared__ f32x4 red[2][256];
     const int chunk = blockIdx.x, slab = blockIdx.y;
@@ -36,24 +38,24 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     const int q = threadIdx.x % QT, r = threadIdx.x / QT;
     const int p0 = chunk * GN_ROWS_PER_CHUNK;
     const int p1 = min(P, p0 + GN_ROWS_PER_CHUNK);
-    const float* base = x + (size_t)slab * P * ld;
+    const T* base = x + (size_t)slab * P * ld;
     float* dst = part + ((size_t)(slab * chunks + chunk) * Ctot + coff) * 2;
     const int CQ = C / 4;
     for (int q0 = 0; q0 < CQ; q0 += QT) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
         if (r < R) {
-            const float* col = base + (q0 + q) * 4;
+            const T* col = base + (q0 + q) * 4;
             int pr = p0 + r;
             for (; pr + 3 * R < p1; pr += 4 * R) {          // four rows in flight per thread
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(col + (size_t)pr * ld);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(col + (size_t)(pr + R) * ld);
-                const f32x4 v2 = *reinterpret_cast<const f32x4*>(col + (size_t)(pr + 2 * R) * ld);
-                const f32x4 v3 = *reinterpret_cast<const f32x4*>(col + (size_t)(pr + 3 * R) * ld);
+                const f32x4 v0 = ld4(col + (size_t)pr * ld);
+                const f32x4 v1 = ld4(col + (size_t)(pr + R) * ld);
+                const f32x4 v2 = ld4(col + (size_t)(pr + 2 * R) * ld);
+                const f32x4 v3 = ld4(col + (size_t)(pr + 3 * R) * ld);
                 s += (v0 + v1) + (v2 + v3);
                 ss += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
             }
             for (; pr < p1; pr += R) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(col + (size_t)pr * ld);
+                const f32x4 v = ld4(col + (size_t)pr * ld);
                 s += v;
                 ss += v * v;
             }
@@ -112,9 +114,10 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int c0,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int c0,
                                                        int c1, int ld0, int ld1, const float* __restrict__ scsh,
-                                                       float* __restrict__ out, int ldo, int P, size_t rows, int act) {
+                                                       T* __restrict__ out, int ldo, int P, size_t rows, int act) {
     const int Ctot = c0 + c1;
     const int CQ = Ctot / 4;
     const size_t total = rows * CQ;
@@ -123,8 +126,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         row = i / CQ;
         c = (int)(i - row * CQ) * 4;
         const int slab = (int)(row / P);
-        v = (c < c0) ? *reinterpret_cast<const f32x4*>(x0 + row * ld0 + c)
-                     : *reinterpret_cast<const f32x4*>(x1 + row * ld1 + (c - c0));
+        v = (c < c0) ? ld4(x0 + row * ld0 + c) : ld4(x1 + row * ld1 + (c - c0));
         const float* sc = scsh + ((size_t)slab * Ctot + c) * 2;
         a = *reinterpret_cast<const f32x4*>(sc);
         b = *reinterpret_cast<const f32x4*>(sc + 4);
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = silu_f(y[e]);
         }
-        *reinterpret_cast<f32x4*>(out + row * ldo + c) = y;
+        st4(out + row * ldo + c, y);
     };
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     for (; i + stride < total; i += 2 * stride) {           // two elements in flight per thread
@@ -163,55 +165,61 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 static void groupnorm_stats_launch(const GroupNormArgs& a, hipStream_t s) {
     const int Ctot = a.c0 + a.c1;
     const int chunks = groupnorm_chunks(a.P);
-    {
-        const int qt = quad_tile(a.c0 / 4);
-        hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, a.samples), dim3(256), 0, s, a.x0, a.ld0, a.c0, a.P, chunks,
-                           a.ws_part, Ctot, 0, qt);
-    }
-    if (a.c1 > 0) {
-        const int qt = quad_tile(a.c1 / 4);
-        hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, a.samples), dim3(256), 0, s, a.x1, a.ld1, a.c1, a.P, chunks,
-                           a.ws_part, Ctot, a.c0, qt);
-    }
+    auto part = [&](const float* x, int ld, int C, int coff) {
+        const int qt = quad_tile(C / 4);
+        if (a.bf16)
+            hipLaunchKernelGGL(gn_partial_kernel<__bf16>, dim3(chunks, a.samples), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), ld, C,
+                               a.P, chunks, a.ws_part, Ctot, coff, qt);
+        else
+            hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(chunks, a.samples), dim3(256), 0, s, x, ld, C, a.P, chunks, a.ws_part, Ctot,
+                               coff, qt);
+    };
+    part(a.x0, a.ld0, a.c0, 0);
+    if (a.c1 > 0) part(a.x1, a.ld1, a.c1, a.c0);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.samples), dim3(64), 0, s, a.ws_part, chunks, Ctot, a.groups,
                        a.P, a.eps, a.gamma, a.beta, a.ws_scale);
 }
 
 void groupnorm_stats(const GroupNormArgs& a, hipStream_t s) {
     const double elems = (double)a.samples * a.P * (a.c0 + a.c1);
-    ProfScope ps("groupnorm_stats", 3.0 * elems, 4.0 * elems, s);                               // algorithmic: one read
+    ProfScope ps("groupnorm_stats", 3.0 * elems, (a.bf16 ? 2.0 : 4.0) * elems, s);              // algorithmic: one read
     groupnorm_stats_launch(a, s);
 }
 
 void groupnorm(const GroupNormArgs& a, hipStream_t s) {
     const int Ctot = a.c0 + a.c1;
     const double elems = (double)a.samples * a.P * Ctot;
-    ProfScope ps(a.silu ? "groupnorm_silu" : "groupnorm", 8.0 * elems, 2.0 * 4.0 * elems, s);   // algorithmic: read + write
+    ProfScope ps(a.silu ? "groupnorm_silu" : "groupnorm", 8.0 * elems, 2.0 * (a.bf16 ? 2.0 : 4.0) * elems, s);   // algorithmic: read + write
     groupnorm_stats_launch(a, s);
     const size_t rows = (size_t)a.samples * a.P;
     const size_t total = rows * (Ctot / 4);
     const int blocks = (int)((total + 511) / 512 < 16384 ? (total + 511) / 512 : 16384);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, s, a.x0, a.x1, a.c0, a.c1, a.ld0, a.ld1, a.ws_scale,
-                       a.out, a.ldo, a.P, rows, a.silu);
+    if (a.bf16)
+        hipLaunchKernelGGL(gn_apply_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0),
+                           reinterpret_cast<const __bf16*>(a.x1), a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<__bf16*>(a.out), a.ldo,
+                           a.P, rows, a.silu);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(blocks), dim3(256), 0, s, a.x0, a.x1, a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, a.out,
+                           a.ldo, a.P, rows, a.silu);
 }
 
 // ---- LayerNorm: one wave per row, row held in registers (C <= 64*4*NV) ------------------------------
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float* __restrict__ out, int ldo,
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ out, int ldo,
                                                         int rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int CQ = C / 4;
-    const float* xr = x + (size_t)row * ldx;
+    const T* xr = x + (size_t)row * ldx;
     f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int q = lane + 64 * k;
         if (q < CQ) {
-            v[k] = *reinterpret_cast<const f32x4*>(xr + q * 4);
+            v[k] = ld4(xr + q * 4);
             s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
         } else {
             v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
     const float rstd = rsqrtf(ss / (float)C + eps);
-    float* orow = out + (size_t)row * ldo;
+    T* orow = out + (size_t)row * ldo;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int q = lane + 64 * k;
@@ -245,21 +253,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = (v[k][e] - mean) * rstd * g[e] + b[e];
-            *reinterpret_cast<f32x4*>(orow + q * 4) = y;
+            st4(orow + q * 4, y);
         }
     }
 }
 
-void layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* out, int ldo, int rows, int C,
-               float eps, hipStream_t s) {
+template <typename T>
+static void layernorm_launch(const T* x, int ldx, const float* gamma, const float* beta, T* out, int ldo, int rows, int C, float eps,
+                             hipStream_t s) {
     const int blocks = (rows + 3) / 4;
-    ProfScope ps("layernorm", 8.0 * rows * C, 2.0 * 4.0 * rows * C, s);
     if (C <= 256)
-        hipLaunchKernelGGL((layernorm_kernel<1>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
+        hipLaunchKernelGGL((layernorm_kernel<1, T>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
     else if (C <= 768)
-        hipLaunchKernelGGL((layernorm_kernel<3>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
+        hipLaunchKernelGGL((layernorm_kernel<3, T>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
     else
-        hipLaunchKernelGGL((layernorm_kernel<5>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
+        hipLaunchKernelGGL((layernorm_kernel<5, T>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
+}
+
+void layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* out, int ldo, int rows, int C,
+               float eps, hipStream_t s, int bf16) {
+    ProfScope ps("layernorm", 8.0 * rows * C, 2.0 * (bf16 ? 2.0 : 4.0) * rows * C, s);
+    if (bf16)
+        layernorm_launch(reinterpret_cast<const __bf16*>(x), ldx, gamma, beta, reinterpret_cast<__bf16*>(out), ldo, rows, C, eps, s);
+    else
+        layernorm_launch(x, ldx, gamma, beta, out, ldo, rows, C, eps, s);
 }
 
 }  // namespace e2v

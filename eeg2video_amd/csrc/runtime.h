@@ -83,21 +83,27 @@ private:
     size_t total_ = 0;
 };
 
-// channel-last activation [rows][C] living in the pool
+// channel-last activation [rows][C] living in the pool; fp32, or bf16 (bf16-activation mode: `p` then points at 2-byte elements)
 struct Act {
     float* p = nullptr;
     int64_t rows = 0;
     int C = 0;
     Pool* pool = nullptr;
+    bool bf16 = false;
     Act() = default;
-    Act(Pool& pl, int64_t r, int c) : p(pl.get((size_t)r * c)), rows(r), C(c), pool(&pl) {}
+    Act(Pool& pl, int64_t r, int c, bool half = false)
+        : p(pl.get(half ? ((size_t)r * c + 1) / 2 : (size_t)r * c)), rows(r), C(c), pool(&pl), bf16(half) {}
+    size_t bytes() const { return (size_t)rows * C * (bf16 ? 2 : 4); }
+    const float* at(int64_t elem) const {          // address of element `elem` (counted in elements of the storage type)
+        return reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + (size_t)elem * (bf16 ? 2 : 4));
+    }
     Act(const Act&) = delete;
     Act& operator=(const Act&) = delete;
     Act(Act&& o) noexcept { *this = std::move(o); }
     Act& operator=(Act&& o) noexcept {
         if (this != &o) {
             reset();
-            p = o.p; rows = o.rows; C = o.C; pool = o.pool;
+            p = o.p; rows = o.rows; C = o.C; pool = o.pool; bf16 = o.bf16;
             o.p = nullptr; o.pool = nullptr;
         }
         return *this;

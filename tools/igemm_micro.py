@@ -11,6 +11,7 @@ if "DTYPE" in os.environ:
 eng.set_conv_algo(os.environ.get("ALGO", "direct"))
 reps = int(os.environ.get("REPS", "5"))
 only = os.environ.get("ONLY", "")
+scale = int(os.environ.get("SCALE", "1"))      # 4 = the B = 32 shapes of BASELINE configs[2]
 shapes = [
     # name, kind, n_img, H, W, Cin, Cout
     ("conv L0 320->320", "conv", 96, 36, 64, 320, 320),
@@ -27,6 +28,7 @@ shapes = [
 for name, kind, n, h, w, ci, co in shapes:
     if only and only not in name:
         continue
+    n *= scale
     if kind == "conv":
         x = torch.randn(n * h * w, ci, device="cuda")
         wt = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
