@@ -55,6 +55,7 @@ SIGNATURES = {
     "e2v_set_alphas_cumprod": (_i, [_ctx, C.POINTER(C.c_float), _i]),
     "e2v_set_ddim_schedule": (_i, [_ctx, C.POINTER(C.c_float), _i, _i]),
     "e2v_unet_forward": (_i, [_ctx, _p, c_int64_p, _i, _p, _i, _i, _i, _i, _i, _p, _stream]),
+    "e2v_unet_forward_ft": (_i, [_ctx, _p, C.POINTER(C.c_float), _i, _p, _i, _i, _i, _i, _i, _p, _stream]),
     "e2v_ddim_cfg_step": (_i, [_ctx, _p, _p, _p, _p, _i64, _f, _i64, _i64, _stream]),
     "e2v_vae_decode": (_i, [_ctx, _p, _i, _i, _i, _i, _i, _p, _stream]),
     "e2v_vae_encode": (_i, [_ctx, _p, _i, _i, _i, _p, _p, _stream]),

@@ -342,6 +342,23 @@ e2v_status e2v_unet_forward(e2v_ctx* c, const float* sample, const int64_t* host
     });
 }
 
+e2v_status e2v_unet_forward_ft(e2v_ctx* c, const float* sample, const float* host_t, int n_t, const float* cond, int N,
+                               int F, int H, int W, int T, float* out, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(sample && host_t && cond && out, E2V_EINVAL, "null argument");
+        E2V_REQUIRE(N > 0 && F > 0 && H > 0 && W > 0 && T > 0, E2V_ESHAPE, "non-positive dimension");
+        hipStream_t s = S(c, stream);
+        const int Cin = c->cfg.in_channels, Cout = c->cfg.out_channels;
+        const int FHW = F * H * W;
+        Act x(c->pool, (int64_t)N * FHW, Cin);
+        ncfhw_to_cl(sample, x.p, N, Cin, Cin, FHW, 1.0f, s);
+        Act y = c->unet_forward_cl(x.p, nullptr, n_t, cond, N, F, H, W, T, s, false, host_t);
+        cl_to_ncfhw(y.p, Cout, out, N, Cout, FHW, 1.0f, 0.0f, 0, 0.f, 0.f, s);
+        E2V_HIP(hipGetLastError());
+    });
+}
+
 static void ddim_coeffs(const e2v_ctx* c, int64_t t, int64_t t_prev, float co[4]) {
     E2V_REQUIRE(t >= 0 && t < (int64_t)c->alphas.size() && t_prev < (int64_t)c->alphas.size(), E2V_EINVAL, "timestep out of range");
     const float a_t = c->alphas[(size_t)t];
@@ -646,7 +663,8 @@ e2v_status e2v_op_linear(e2v_ctx* c, const float* x, int ldx, int64_t M, int K, 
                          const float* resid, int geglu, float* out, e2v_stream stream) {
     if (!c) return E2V_EINVAL;
     return guarded(c, [&] {
-        E2V_REQUIRE(x && w && out && K % 4 == 0 && ldx % 4 == 0, E2V_EINVAL, "bad linear arguments");
+        // fp32 arithmetic reads 16-byte row pieces of the caller's tensor; the bf16-activation mode re-lays its operands out (K padded to 8)
+        E2V_REQUIRE(x && w && out && (c->bf16_compute || (K % 4 == 0 && ldx % 4 == 0)), E2V_EINVAL, "bad linear arguments");
         hipStream_t s = S(c, stream);
         IgemmArgs g;
         g.a0 = x; g.c0 = K; g.lda0 = ldx; g.ldw = K; g.out = out; g.M = (int)M; g.taps = 1; g.resid = resid;

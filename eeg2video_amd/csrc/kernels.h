@@ -143,7 +143,7 @@ void cl_to_ncfhw(const float* in, int ld, float* out, int n, int C, int FHW, flo
 void nchw_frames_to_ncfhw(const float* in, int ld, float* out, int n, int F, int C, int HW, float mul, float add,
                           int clamp01, hipStream_t s);
 void timestep_sinusoid(const long long* t, int nt, float* out, int n, int dim, int flip_sin_to_cos, float freq_shift,
-                       hipStream_t s);
+                       hipStream_t s, int t_is_f32 = 0);      // t_is_f32: `t` points at nt floats instead
 void silu(const float* in, float* out, long long count, hipStream_t s);
 void transpose2d(const float* in, int ld_in, float* out, int ld_out, int rows, int cols, int batch,
                  long long sb_in, long long sb_out, hipStream_t s, int bf16 = 0);

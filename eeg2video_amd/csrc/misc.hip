@@ -82,7 +82,8 @@ void nchw_frames_to_ncfhw(const float* in, int ld, float* out, int n, int F, int
 
 // diffusers get_timestep_embedding: w_i = exp(-ln(10000) i / (half - shift)),
 // emb = [sin(t w), cos(t w)], swapped to [cos, sin] when flip_sin_to_cos.  t has nt entries (1 = broadcast).
-__global__ void timestep_sinusoid_kernel(const long long* __restrict__ t, int nt, float* __restrict__ out, int n, int dim,
+template <typename TT>
+__global__ void timestep_sinusoid_kernel(const TT* __restrict__ t, int nt, float* __restrict__ out, int n, int dim,
                                          int flip, float shift) {
     const int half = dim / 2;
     const int total = n * half;
@@ -96,9 +97,13 @@ __global__ void timestep_sinusoid_kernel(const long long* __restrict__ t, int nt
         if (flip) { o[k] = cv; o[half + k] = sv; } else { o[k] = sv; o[half + k] = cv; }
     }
 }
-void timestep_sinusoid(const long long* t, int nt, float* out, int n, int dim, int flip, float shift, hipStream_t s) {
-    hipLaunchKernelGGL(timestep_sinusoid_kernel, dim3(grid_for((size_t)n * dim / 2)), dim3(256), 0, s, t, nt, out, n, dim, flip,
-                       shift);
+void timestep_sinusoid(const long long* t, int nt, float* out, int n, int dim, int flip, float shift, hipStream_t s, int t_is_f32) {
+    if (t_is_f32)       // fractional timesteps of the sigma-space schedulers (Euler, LMS): the fp32 value the reference's .float() makes
+        hipLaunchKernelGGL(timestep_sinusoid_kernel<float>, dim3(grid_for((size_t)n * dim / 2)), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(t), nt, out, n, dim, flip, shift);
+    else
+        hipLaunchKernelGGL(timestep_sinusoid_kernel<long long>, dim3(grid_for((size_t)n * dim / 2)), dim3(256), 0, s, t, nt, out, n, dim,
+                           flip, shift);
 }
 
 __global__ void silu_kernel(const float* __restrict__ in, float* __restrict__ out, size_t count) {

@@ -777,7 +777,7 @@ int down_size(int x) { return (x - 1) / 2 + 1; }     // 3x3, stride 2, padding 1
 // UNet3DConditionModel.forward (unet.py:278-413), channel-last in and out
 // -----------------------------------------------------------------------------------------------------
 Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int n_t, const float* cond, int N, int F,
-                             int H, int W, int T, hipStream_t s, bool cfg_pair) {
+                             int H, int W, int T, hipStream_t s, bool cfg_pair, const float* host_tf) {
     E2V_REQUIRE(unet_ready, E2V_ESTATE, "UNet weights are not finalized");
     E2V_REQUIRE(n_t == 1 || n_t == N, E2V_EINVAL, "timesteps must have 1 or N entries");
     // cfg_pair: `sample_cl` holds N / 2 samples standing for [x ; x] (one timestep): everything before the first use of the
@@ -797,11 +797,12 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
         d_timesteps_cap = N;
     }
     static_assert(sizeof(long long) == sizeof(int64_t), "int64");
-    E2V_HIP(hipMemcpyAsync(d_timesteps, host_t, sizeof(int64_t) * n_t, hipMemcpyHostToDevice, s));
+    if (host_tf) E2V_HIP(hipMemcpyAsync(d_timesteps, host_tf, sizeof(float) * n_t, hipMemcpyHostToDevice, s));
+    else E2V_HIP(hipMemcpyAsync(d_timesteps, host_t, sizeof(int64_t) * n_t, hipMemcpyHostToDevice, s));
     Act temb_silu;
     if (!step_cache_on) {
         Act sin(pool, N, boc0);
-        timestep_sinusoid(d_timesteps, n_t, sin.p, N, boc0, cfg.flip_sin_to_cos, cfg.freq_shift, s);
+        timestep_sinusoid(d_timesteps, n_t, sin.p, N, boc0, cfg.flip_sin_to_cos, cfg.freq_shift, s, host_tf ? 1 : 0);
         Act e1 = R.linear(unet.te1, sin.p, boc0, N, nullptr, 0, false, nullptr, 0, 0, true);        // fp32 rows in both modes
         silu(e1.p, e1.p, (long long)N * temb_dim, s);
         Act emb = R.linear(unet.te2, e1.p, temb_dim, N, nullptr, 0, false, nullptr, 0, 0, true);

@@ -94,7 +94,10 @@ class Engine:
         """Upload tensors keyed by the reference's state-dict names (``prefix='vae.'`` for the VAE)."""
         for k, v in sd.items():
             if isinstance(v, torch.Tensor):
-                v = v.detach().cpu().numpy()
+                v = v.detach().cpu()
+                if v.dtype not in (torch.float32, torch.float16):      # bf16 / fp64 checkpoints: widened (or narrowed) to fp32 here
+                    v = v.float()
+                v = v.numpy()
             a = np.ascontiguousarray(v)
             if a.dtype == np.float16:
                 dt = _lib.E2V_F16
@@ -180,8 +183,14 @@ class Engine:
         n, c, f, h, w = sample.shape
         if c != self.unet_cfg.in_channels or cond.shape[2] != self.unet_cfg.cross_attention_dim:
             raise ValueError("channel count of `sample` or feature dim of `encoder_hidden_states` does not match the config")
-        ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int64).reshape(-1))
         out = torch.empty((n, self.unet_cfg.out_channels, f, h, w), device=self.device, dtype=torch.float32)
+        tarr = np.asarray(timesteps).reshape(-1)
+        if np.issubdtype(tarr.dtype, np.floating) and not np.all(tarr == np.round(tarr)):
+            tf = np.ascontiguousarray(tarr, dtype=np.float32)        # fractional timesteps (Euler / LMS schedules)
+            self._check(self.lib.e2v_unet_forward_ft(self.ctx, sample.data_ptr(), tf.ctypes.data_as(C.POINTER(C.c_float)), tf.size,
+                                                     cond.data_ptr(), n, f, h, w, cond.shape[1], out.data_ptr(), _stream()))
+            return out
+        ts = np.ascontiguousarray(tarr.astype(np.int64))
         self._check(self.lib.e2v_unet_forward(self.ctx, sample.data_ptr(), ts.ctypes.data_as(_lib.c_int64_p), ts.size,
                                               cond.data_ptr(), n, f, h, w, cond.shape[1], out.data_ptr(), _stream()))
         return out

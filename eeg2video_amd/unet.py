@@ -196,9 +196,12 @@ class UNet3DConditionModel:
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is not used on the generation path")
         if torch.is_tensor(timestep):                                                            # unet.py:324-337
-            ts = timestep.detach().reshape(-1).to("cpu", torch.int64).numpy()
+            tt = timestep.detach().reshape(-1).to("cpu")
+            ts = tt.numpy() if tt.is_floating_point() else tt.to(torch.int64).numpy()
         else:
-            ts = np.asarray([timestep], dtype=np.int64)
+            ts = np.asarray([timestep])
+            if not np.issubdtype(ts.dtype, np.floating):
+                ts = ts.astype(np.int64)
         if ts.size not in (1, sample.shape[0]):
             raise ValueError(f"timestep has {ts.size} entries for a batch of {sample.shape[0]}")
         out = self.engine.unet_forward(sample, ts, encoder_hidden_states)

@@ -121,6 +121,12 @@ e2v_status e2v_set_ddim_schedule(e2v_ctx* ctx, const float* host_alphas_cumprod,
 e2v_status e2v_unet_forward(e2v_ctx* ctx, const float* sample, const int64_t* host_timesteps, int n_t,
                             const float* cond, int N, int F, int H, int W, int T, float* out, e2v_stream stream);
 
+/* The same with FRACTIONAL timesteps, as the sigma-space schedulers the pipeline's constructor accepts produce them
+ * (pipeline_tuneeeg2video.py:48-55: LMSDiscrete / EulerDiscrete / EulerAncestralDiscrete: timesteps = linspace(0, T-1, n)[::-1];
+ * unet.py:324-339 turns a float timestep into the fp32 argument of the sinusoid).  host_timesteps: n_t floats. */
+e2v_status e2v_unet_forward_ft(e2v_ctx* ctx, const float* sample, const float* host_timesteps, int n_t, const float* cond,
+                               int N, int F, int H, int W, int T, float* out, e2v_stream stream);
+
 /* replaces: noise_pred chunk + guidance + scheduler.step (pipeline_tuneeeg2video.py:320-325), eta = 0.
  * eps_cond may be NULL (guidance off).  t, t_prev are train timesteps (t_prev < 0 -> final alpha = abar[0]). */
 e2v_status e2v_ddim_cfg_step(e2v_ctx* ctx, const float* eps_uncond, const float* eps_cond, const float* x,
