@@ -21,7 +21,8 @@ from typing import Callable, List, Optional, Union
 import numpy as np
 import torch
 
-from .scheduler import DDIMScheduler, PNDMScheduler  # noqa: F401
+from .scheduler import (DDIMScheduler, DPMSolverMultistepScheduler, EulerAncestralDiscreteScheduler,  # noqa: F401
+                        EulerDiscreteScheduler, LMSDiscreteScheduler, PNDMScheduler, scheduler_from_pretrained)
 from .unet import UNet3DConditionModel
 from .vae import AutoencoderKL
 
@@ -48,6 +49,44 @@ class TuneAVideoPipeline:
         if scheduler.engine is None:
             scheduler.bind(unet.engine)
         self._progress = True
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path: str, unet: Optional[UNet3DConditionModel] = None, vae: Optional[AutoencoderKL] = None,
+                        scheduler=None, tokenizer=None, torch_dtype=None, device: int = 0, **kwargs):
+        """``TuneAVideoPipeline.from_pretrained(pretrained_model_path, unet=unet, torch_dtype=torch.float16)``
+        (``inference_eeg2video.py:70``) for a LOCAL Stable-Diffusion directory: ``model_index.json`` names the components,
+        ``vae/`` (config.json + weights) and ``scheduler/scheduler_config.json`` (DDIM in the tuned checkpoints, PNDM in the
+        stock SD-v1-4 one; any of the six types the constructor accepts) are loaded here, components passed in are used as
+        they are.  The VAE is created on the UNet's engine so that the fused device loop applies.  ``torch_dtype`` is accepted
+        for drop-in use: checkpoints of any float type are widened to fp32 at load and the arithmetic is chosen with
+        ``pipe.unet.engine.set_compute_dtype`` (fp32 by default; ``"bf16"`` is the reduced-precision mode of this library)."""
+        import json
+        import os
+        index_file = os.path.join(pretrained_model_path, "model_index.json")
+        index = {}
+        if os.path.isfile(index_file):
+            with open(index_file) as f:
+                index = json.load(f)
+        elif not os.path.isdir(pretrained_model_path):
+            raise RuntimeError(f"{pretrained_model_path} does not exist")
+        if unet is None:
+            vcfg = vae.vcfg if vae is not None else AutoencoderKL.config_from_dir(os.path.join(pretrained_model_path, "vae"))
+            unet = UNet3DConditionModel.from_pretrained(pretrained_model_path, subfolder="unet", torch_dtype=torch_dtype, device=device,
+                                                        vae_config=vcfg)
+        if vae is None:
+            vae = AutoencoderKL.from_pretrained(pretrained_model_path, subfolder="vae", torch_dtype=torch_dtype, engine=unet.engine)
+        if scheduler is None:
+            scheduler = scheduler_from_pretrained(pretrained_model_path, "scheduler", engine=unet.engine)
+            named = index.get("scheduler")
+            if isinstance(named, (list, tuple)) and len(named) == 2 and named[1] != type(scheduler).__name__:
+                raise RuntimeError(f"model_index.json names the scheduler {named[1]}, scheduler_config.json builds {type(scheduler).__name__}")
+        if tokenizer is None and os.path.isdir(os.path.join(pretrained_model_path, "tokenizer")):
+            try:                                   # unused on the EEG path (the conditioning is the Semantic Predictor's output)
+                from transformers import CLIPTokenizer
+                tokenizer = CLIPTokenizer.from_pretrained(os.path.join(pretrained_model_path, "tokenizer"))
+            except Exception:
+                tokenizer = None
+        return cls(vae=vae, tokenizer=tokenizer, unet=unet, scheduler=scheduler)
 
     # -- small API of DiffusionPipeline the callers use ------------------------------------------------
     @property
@@ -192,12 +231,15 @@ class TuneAVideoPipeline:
         timesteps = self.scheduler.timesteps
         latents = self.prepare_latents(batch_size * num_videos_per_eeg, self.unet.in_channels, video_length, height,
                                        width, torch.float32, device, generator, latents)          # :291-302
+        if getattr(self.scheduler, "engine", None) is None:      # a scheduler swapped in after construction (pipe.scheduler = ...)
+            self.scheduler.bind(self.unet.engine)
         extra = self.prepare_extra_step_kwargs(generator, eta)                                    # :306
-        if extra.get("eta", 0.0) != 0.0:
-            raise NotImplementedError("only the deterministic DDIM update (eta = 0) is implemented")
         b = latents.shape[0]
         eng = self.unet.engine
-        fused = callback is None and self.vae.engine is eng and isinstance(self.scheduler, DDIMScheduler)
+        # the fused device loop is the deterministic DDIM one; a stochastic update (eta > 0 draws torch noise per step), another
+        # scheduler type or a per-step callback step through the public entry points exactly as the reference's loop does
+        fused = (callback is None and self.vae.engine is eng and isinstance(self.scheduler, DDIMScheduler)
+                 and extra.get("eta", 0.0) == 0.0)
         if fused:
             self.scheduler.bind(eng)      # the fused loop walks the ctx's schedule: make it this scheduler's (table, steps_offset)
             with self.progress_bar(total=num_inference_steps) as bar:
@@ -211,7 +253,7 @@ class TuneAVideoPipeline:
                     x_in = torch.cat([latents] * 2) if do_cfg else latents                        # :313
                     x_in = self.scheduler.scale_model_input(x_in, t)                              # :314
                     eps = self.unet(x_in, t, encoder_hidden_states=emb).sample                    # :317
-                    if do_cfg and isinstance(self.scheduler, DDIMScheduler):                      # :320-325, one kernel
+                    if do_cfg and isinstance(self.scheduler, DDIMScheduler) and extra.get("eta", 0.0) == 0.0:   # :320-325, one kernel
                         eu, ec = eps.chunk(2)
                         latents = eng.ddim_cfg_step(eu, ec, latents, guidance_scale, int(t),
                                                     self.scheduler.prev_timestep(int(t)))

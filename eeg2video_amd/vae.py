@@ -7,6 +7,8 @@ with ``.sample()`` / ``.mean`` (``train_finetune_videodiffusion.py:264``, ``gene
 """
 from __future__ import annotations
 
+import json
+import os
 from typing import Optional
 
 import torch
@@ -97,6 +99,44 @@ class AutoencoderKL:
 
     def init_synthetic(self, seed: int = 43, mode: str = "reference_init"):
         return self.load_state_dict(synth_state_dict(self.state_dict_spec(), seed=seed, mode=mode))
+
+    @staticmethod
+    def config_from_dir(path: str) -> VAEConfig:
+        """``config.json`` of a diffusers ``AutoencoderKL`` -> ``VAEConfig`` (0.11.1 configs carry no ``scaling_factor``: 0.18215)."""
+        cfg_file = os.path.join(path, "config.json")
+        if not os.path.isfile(cfg_file):
+            raise RuntimeError(f"{cfg_file} does not exist")
+        with open(cfg_file) as f:
+            cj = json.load(f)
+        if cj.get("down_block_types") and any(t != "DownEncoderBlock2D" for t in cj["down_block_types"]):
+            raise NotImplementedError(f"VAE block types {cj['down_block_types']} are not the Stable-Diffusion ones")
+        return VAEConfig(in_channels=cj.get("in_channels", 3), out_channels=cj.get("out_channels", 3),
+                         latent_channels=cj.get("latent_channels", 4),
+                         block_out_channels=tuple(cj.get("block_out_channels", (128, 256, 512, 512))),
+                         layers_per_block=cj.get("layers_per_block", 2), norm_num_groups=cj.get("norm_num_groups", 32),
+                         scaling_factor=cj.get("scaling_factor", 0.18215))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path: str, subfolder: Optional[str] = None, torch_dtype=None, *,
+                        engine: Optional[Engine] = None, unet_config: Optional[UNetConfig] = None, device: int = 0):
+        """Local directory only (what ``DiffusionPipeline.from_pretrained`` does for the ``vae`` component of
+        ``inference_eeg2video.py:70``): ``config.json`` (diffusers ``AutoencoderKL`` config) + ``diffusion_pytorch_model.bin``
+        (or ``.safetensors``).  ``torch_dtype`` is accepted for drop-in use; fp16 / bf16 checkpoints are widened to fp32 at load."""
+        path = os.path.join(pretrained_model_path, subfolder) if subfolder else pretrained_model_path
+        config = cls.config_from_dir(path)
+        if engine is not None and engine.vae_cfg != config:
+            raise RuntimeError(f"the engine was created for a VAE of {engine.vae_cfg}, the checkpoint holds {config}: create the UNet "
+                               "with vae_config=AutoencoderKL.config_from_dir(<dir>/vae)")
+        model = cls(config, engine=engine, unet_config=unet_config, device=device)
+        bin_file, st_file = os.path.join(path, "diffusion_pytorch_model.bin"), os.path.join(path, "diffusion_pytorch_model.safetensors")
+        if os.path.isfile(bin_file):
+            sd = torch.load(bin_file, map_location="cpu")
+        elif os.path.isfile(st_file):
+            from safetensors.torch import load_file
+            sd = load_file(st_file)
+        else:
+            raise RuntimeError(f"{bin_file} does not exist")
+        return model.load_state_dict(sd)
 
     def decode(self, z: torch.Tensor, return_dict: bool = True):
         out = self.engine.vae_decode(z, postprocess=False)

@@ -27,4 +27,5 @@ from .unet3d import unet3d_forward  # noqa: F401
 from .vae import vae_decode, vae_encode  # noqa: F401
 from .pipeline import generate  # noqa: F401
 from .pndm import PNDMOracle  # noqa: F401
+from .schedulers import DPMSolverPPOracle, EulerAncestralOracle, EulerOracle, LMSOracle, lms_coefficient_exact  # noqa: F401
 from .extras import dana_noise, frames_to_uint8, semantic_predictor  # noqa: F401

@@ -38,7 +38,9 @@ class DDIMOracle:
     def scale_model_input(self, x, t):
         return x
 
-    def step(self, eps: torch.Tensor, t: int, x: torch.Tensor, eta: float = 0.0) -> torch.Tensor:
+    def step(self, eps: torch.Tensor, t: int, x: torch.Tensor, eta: float = 0.0, noise=None) -> torch.Tensor:
+        """``eta > 0`` (formulas (12), (16) of the DDIM paper): ``noise`` is the N(0, 1) draw the dependency makes with
+        ``torch.randn(model_output.shape, generator=...)`` (call site pipeline_tuneeeg2video.py:306,325)."""
         t = int(t)
         prev = t - self.num_train_timesteps // self.num_inference_steps
         a_t = self.alphas_cumprod[t]
@@ -48,7 +50,10 @@ class DDIMOracle:
         var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
         std = eta * var ** 0.5
         direction = (1 - a_p - std ** 2) ** 0.5 * eps
-        return a_p ** 0.5 * x0 + direction
+        prev = a_p ** 0.5 * x0 + direction
+        if eta > 0:
+            prev = prev + std * noise
+        return prev
 
 
 # ---- DDIM inversion: EEG2Video_New/Generation/tuneavideo/util.py:56-101 (reference-owned; PINNED by

@@ -29,11 +29,12 @@ def decode_latents(vae_sd, vae_cfg, latents: torch.Tensor) -> torch.Tensor:
 def generate(unet_sd, unet_cfg, vae_sd, vae_cfg, latents: torch.Tensor, cond: torch.Tensor,
              uncond: torch.Tensor, num_inference_steps: int = 50, guidance_scale: float = 7.5,
              eta: float = 0.0, trace: Optional[Dict[str, List[torch.Tensor]]] = None,
-             decode: bool = True, scheduler=None) -> torch.Tensor:
+             decode: bool = True, scheduler=None, noises: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
     """latents ``[B,4,F,h,w]``, cond ``[B,77,D]``, uncond ``[1 or B,77,D]`` -> videos ``[B,3,F,8h,8w]``.
 
     ``trace`` (optional) collects per-step ``eps`` (after guidance) and ``latents`` for the
-    teacher-forced per-step parity tests."""
+    teacher-forced per-step parity tests.  ``noises`` (optional): the per-step N(0, 1) draws of a stochastic scheduler
+    (DDIM with ``eta > 0``, Euler-ancestral), passed in so that a test can hand the device path the same numbers."""
     sched = scheduler if scheduler is not None else DDIMOracle()      # any oracle scheduler (DDIMOracle, PNDMOracle)
     b = latents.shape[0]
     do_cfg = guidance_scale > 1.0                                                    # :281
@@ -43,14 +44,15 @@ def generate(unet_sd, unet_cfg, vae_sd, vae_cfg, latents: torch.Tensor, cond: to
         emb = cond
     timesteps = sched.set_timesteps(num_inference_steps)                             # :287-288
     x = latents * sched.init_noise_sigma                                             # :244
-    for t in timesteps:                                                              # :311
+    for i, t in enumerate(timesteps):                                                # :311
+        t = int(t) if float(t).is_integer() else float(t)         # sigma-space schedulers step through fractional timesteps
         x_in = torch.cat([x] * 2) if do_cfg else x                                   # :313
         x_in = sched.scale_model_input(x_in, t)                                      # :314
-        eps = unet3d_forward(unet_sd, unet_cfg, x_in, int(t), emb)                   # :317
+        eps = unet3d_forward(unet_sd, unet_cfg, x_in, t, emb)                        # :317
         if do_cfg:                                                                   # :320-322
             eps_u, eps_c = eps.chunk(2)
             eps = eps_u + guidance_scale * (eps_c - eps_u)
-        x = sched.step(eps, int(t), x, eta=eta)                                      # :325
+        x = sched.step(eps, t, x, eta=eta, noise=noises[i] if noises is not None else None)   # :325
         if trace is not None:
             trace.setdefault("eps", []).append(eps.clone())
             trace.setdefault("latents", []).append(x.clone())

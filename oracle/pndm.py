@@ -42,7 +42,7 @@ class PNDMOracle:
         model_output_denom_coeff = alpha_prod_t * beta_prod_t_prev ** 0.5 + (alpha_prod_t * beta_prod_t * alpha_prod_t_prev) ** 0.5
         return sample_coeff * sample - (alpha_prod_t_prev - alpha_prod_t) * model_output / model_output_denom_coeff
 
-    def step(self, model_output: torch.Tensor, timestep: int, sample: torch.Tensor, eta: float = 0.0) -> torch.Tensor:
+    def step(self, model_output: torch.Tensor, timestep: int, sample: torch.Tensor, eta: float = 0.0, noise=None) -> torch.Tensor:
         timestep = int(timestep)
         ratio = self.num_train_timesteps // self.num_inference_steps
         prev_timestep = timestep - ratio

@@ -174,8 +174,8 @@ def unet3d_forward(sd: SD, cfg, sample: torch.Tensor, timestep, encoder_hidden_s
     forward_upsample_size = any(s % (2 ** n_up) != 0 for s in sample.shape[-2:])                # :304-312
 
     t = timestep                                                                                # :324-337
-    if not torch.is_tensor(t):
-        t = torch.tensor([t], dtype=torch.int64)
+    if not torch.is_tensor(t):                       # :329-333: float timestep -> float64 tensor, int -> int64; the sinusoid takes .float()
+        t = torch.tensor([t], dtype=torch.float64 if isinstance(t, float) else torch.int64)
     elif t.dim() == 0:
         t = t[None]
     t = t.expand(sample.shape[0])

@@ -378,3 +378,71 @@ def test_pndm_scheduler_vs_oracle_and_pipeline(tiny):
     finally:
         pipe.scheduler = old
     assert out.shape == ref.shape and (out - ref).abs().max().item() < 1e-3
+
+
+def _save_sd_dir(root, usd, vsd, scheduler_cfg, half=True):
+    """A local Stable-Diffusion directory as diffusers lays it out (model_index.json, unet/, vae/, scheduler/), tiny configs,
+    weights saved as fp16 like the reference's checkpoints."""
+    import json
+    import dataclasses
+    cast = (lambda v: v.half()) if half else (lambda v: v)
+    os.makedirs(os.path.join(root, "unet")); os.makedirs(os.path.join(root, "vae")); os.makedirs(os.path.join(root, "scheduler"))
+    ucfg = {"_class_name": "UNet3DConditionModel", "_diffusers_version": "0.11.1", "sample_size": TINY_UNET.sample_size,
+            "in_channels": 4, "out_channels": 4, "block_out_channels": list(TINY_UNET.block_out_channels), "layers_per_block": 2,
+            "cross_attention_dim": TINY_UNET.cross_attention_dim, "attention_head_dim": TINY_UNET.attention_head_dim,
+            "norm_num_groups": 32, "norm_eps": 1e-5, "act_fn": "silu", "flip_sin_to_cos": True, "freq_shift": 0,
+            "down_block_types": ["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"], "up_block_types": ["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3}
+    json.dump(ucfg, open(os.path.join(root, "unet", "config.json"), "w"))
+    torch.save({k: cast(v) for k, v in usd.items()}, os.path.join(root, "unet", "diffusion_pytorch_model.bin"))
+    vcfg = {"_class_name": "AutoencoderKL", "_diffusers_version": "0.11.1", "in_channels": 3, "out_channels": 3, "latent_channels": 4,
+            "block_out_channels": list(TINY_VAE.block_out_channels), "layers_per_block": TINY_VAE.layers_per_block,
+            "norm_num_groups": TINY_VAE.norm_num_groups, "act_fn": "silu", "sample_size": 64,
+            "down_block_types": ["DownEncoderBlock2D"] * 4, "up_block_types": ["UpDecoderBlock2D"] * 4}
+    json.dump(vcfg, open(os.path.join(root, "vae", "config.json"), "w"))
+    torch.save({k: cast(v) for k, v in vsd.items()}, os.path.join(root, "vae", "diffusion_pytorch_model.bin"))
+    json.dump(scheduler_cfg, open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    json.dump({"_class_name": "StableDiffusionPipeline", "_diffusers_version": "0.11.1", "scheduler": ["diffusers", scheduler_cfg["_class_name"]],
+               "unet": ["diffusers", "UNet2DConditionModel"], "vae": ["diffusers", "AutoencoderKL"]}, open(os.path.join(root, "model_index.json"), "w"))
+
+
+@pytest.mark.parametrize("sched", ["DDIMScheduler", "PNDMScheduler"])
+def test_from_pretrained_local_dir_fp16_as_the_reference_script_does(tiny, tmp_path, sched):
+    """inference_eeg2video.py:69-72,90-98 with only the imports changed: UNet3DConditionModel.from_pretrained(dir,
+    subfolder='unet', torch_dtype=float16).to('cuda'), TuneAVideoPipeline.from_pretrained(dir, unet=unet, torch_dtype=float16)
+    .to('cuda'), enable_xformers / enable_vae_slicing, half latents; fp16 checkpoints and inputs are widened at the edge and the
+    result equals the oracle's on the fp16-rounded weights.  The stock SD-v1-4 directory carries a PNDM scheduler config with the
+    outdated steps_offset the constructor patches (pipeline_tuneeeg2video.py:59-71)."""
+    from eeg2video_amd.pipeline import TuneAVideoPipeline
+    from eeg2video_amd.unet import UNet3DConditionModel
+    from eeg2video_amd.vae import AutoencoderKL
+    from oracle import DDIMOracle, PNDMOracle, generate
+    _, usd, vsd = tiny
+    scfg = {"_class_name": sched, "_diffusers_version": "0.11.1", "beta_start": 0.00085, "beta_end": 0.012,
+            "beta_schedule": "scaled_linear", "num_train_timesteps": 1000, "set_alpha_to_one": False, "trained_betas": None,
+            "steps_offset": 0 if sched == "PNDMScheduler" else 1}
+    scfg.update({"clip_sample": False} if sched == "DDIMScheduler" else {"skip_prk_steps": True})
+    root = str(tmp_path / "sd")
+    _save_sd_dir(root, usd, vsd, scfg)
+    unet = UNet3DConditionModel.from_pretrained(root, subfolder="unet", torch_dtype=torch.float16,
+                                                vae_config=AutoencoderKL.config_from_dir(os.path.join(root, "vae"))).to("cuda")
+    pipe = TuneAVideoPipeline.from_pretrained(root, unet=unet, torch_dtype=torch.float16).to("cuda")
+    pipe.enable_xformers_memory_efficient_attention()
+    pipe.enable_vae_slicing()
+    pipe.set_progress_bar_config(disable=True)
+    assert type(pipe.scheduler).__name__ == sched and pipe.scheduler.config.steps_offset == 1 and pipe.vae.engine is unet.engine
+    b, f, tok, d = 1, 3, 77, TINY_UNET.cross_attention_dim
+    lat = _t(counter_normal(70, "lat", (b, 4, f, 4, 6))).half()
+    eeg = _t(counter_normal(71, "eeg", (b, tok * d))).half()
+    neg = _t(counter_normal(72, "neg", (1, tok, d)))
+    out = pipe(None, eeg.cuda(), latents=lat, video_length=f, height=32, width=48, num_inference_steps=3, guidance_scale=12.5,
+               negative_prompt=neg).videos
+    h = lambda sd: {k: v.half().float() for k, v in sd.items()}
+    ref = generate(h(usd), TINY_UNET, h(vsd), TINY_VAE, lat.float(), eeg.float().reshape(b, tok, d), neg, 3, 12.5,
+                   scheduler=DDIMOracle() if sched == "DDIMScheduler" else PNDMOracle())
+    assert out.dtype == torch.float32 and (out - ref).abs().max().item() < 1e-3
+    # a whole pipeline from the directory alone (no unet= given): same result
+    pipe2 = TuneAVideoPipeline.from_pretrained(root)
+    pipe2.set_progress_bar_config(disable=True)
+    out2 = pipe2(None, eeg.cuda(), latents=lat, video_length=f, height=32, width=48, num_inference_steps=3, guidance_scale=12.5,
+                 negative_prompt=neg).videos
+    assert torch.equal(out2, out)
