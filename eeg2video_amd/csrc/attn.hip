@@ -1142,18 +1142,39 @@ __global__ __launch_bounds__(128) void temporal_attn_lds_kernel(const T* __restr
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [F][PB][q | k | v][CS]
     const int smp = blockIdx.x / npg, p0 = (blockIdx.x - smp * npg) * PB;
     const int c_base = blockIdx.y * CS;
-    const int CQ = CS / 4;
-    const int total = F * PB * 3 * CQ;
-    for (int idx = threadIdx.x; idx < total; idx += 128) {
-        const int c4 = idx % CQ;
-        int r = idx / CQ;
-        const int part = r % 3; r /= 3;
-        const int pp = r % PB;
-        const int f = r / PB;
-        const int pix = p0 + pp;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pix < HW) v = ld4(qkv + ((size_t)(smp * F + f) * HW + pix) * ld + part * C + c_base + c4 * 4);
-        *reinterpret_cast<f32x4*>(sm + (size_t)idx * 4) = v;
+    if constexpr (std::is_same<T, __bf16>::value) {       // bf16 rows: 16-byte (8-channel) pieces, widened on their way into LDS
+        const int CO = CS / 8;
+        const int total = F * PB * 3 * CO;
+        for (int idx = threadIdx.x; idx < total; idx += 128) {
+            const int c8 = idx % CO;
+            int r = idx / CO;
+            const int part = r % 3; r /= 3;
+            const int pp = r % PB;
+            const int f = r / PB;
+            const int pix = p0 + pp;
+            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+            if (pix < HW) {
+                const abf16x8 v = *reinterpret_cast<const abf16x8*>(qkv + ((size_t)(smp * F + f) * HW + pix) * ld + part * C + c_base + c8 * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[e] = (float)v[e]; hi[e] = (float)v[4 + e]; }
+            }
+            *reinterpret_cast<f32x4*>(sm + (size_t)idx * 8) = lo;
+            *reinterpret_cast<f32x4*>(sm + (size_t)idx * 8 + 4) = hi;
+        }
+    } else {
+        const int CQ = CS / 4;
+        const int total = F * PB * 3 * CQ;
+        for (int idx = threadIdx.x; idx < total; idx += 128) {
+            const int c4 = idx % CQ;
+            int r = idx / CQ;
+            const int part = r % 3; r /= 3;
+            const int pp = r % PB;
+            const int f = r / PB;
+            const int pix = p0 + pp;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pix < HW) v = ld4(qkv + ((size_t)(smp * F + f) * HW + pix) * ld + part * C + c_base + c4 * 4);
+            *reinterpret_cast<f32x4*>(sm + (size_t)idx * 4) = v;
+        }
     }
     __syncthreads();
     const int hs = CS / D;
@@ -1196,15 +1217,32 @@ __global__ __launch_bounds__(128) void temporal_attn_lds_kernel(const T* __restr
             }
         const float inv = 1.0f / l;
         T* op = out + ((size_t)(smp * F + i) * HW + pix) * ldo + c_base + hh * D;
-        for (int c = 0; c < D; c += 4) {
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (std::is_same<T, __bf16>::value) {
+            for (int c = 0; c < D; c += 8) {                    // D % 8 == 0: one 16-byte store per 8 channels
+                f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
-            for (int jf = 0; jf < FMAX; ++jf)
-                if (jf < F) {
-                    const f32x4 vv = *reinterpret_cast<const f32x4*>(v + jf * fs + c);
-                    o += vv * (s[jf] * inv);
-                }
-            st4(op + c, o);
+                for (int jf = 0; jf < FMAX; ++jf)
+                    if (jf < F) {
+                        const float pw = s[jf] * inv;
+                        o0 += *reinterpret_cast<const f32x4*>(v + jf * fs + c) * pw;
+                        o1 += *reinterpret_cast<const f32x4*>(v + jf * fs + c + 4) * pw;
+                    }
+                abf16x8 ob;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ob[e] = (__bf16)o0[e]; ob[4 + e] = (__bf16)o1[e]; }
+                *reinterpret_cast<abf16x8*>(op + c) = ob;
+            }
+        } else {
+            for (int c = 0; c < D; c += 4) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jf = 0; jf < FMAX; ++jf)
+                    if (jf < F) {
+                        const f32x4 vv = *reinterpret_cast<const f32x4*>(v + jf * fs + c);
+                        o += vv * (s[jf] * inv);
+                    }
+                st4(op + c, o);
+            }
         }
     }
 }
