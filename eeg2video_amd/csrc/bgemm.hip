@@ -15,11 +15,12 @@
 #include "igemm_epi.h"
 #include "prof.h"
 
+#include <cstdlib>
 #include <string>
 
 namespace e2v {
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int STAGE = 128 * 128 * 2>      // STAGE: stage stride, sized for the largest tile of the launch
 __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, const int n0, char* smem) {
     constexpr int BKE = 64;                         // bf16 elements per stage
     constexpr int ROWB = 128;                       // bytes per LDS tile row
@@ -27,7 +28,6 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
-    constexpr int STAGE = 128 * ROWB * 2;           // stage stride: sized for the largest tile of the launch (128 x 128)
     constexpr int APW = BM / 8 / NW, BPW = BN / 8 / NW;   // 1-KB DMA pieces (8 rows) per wave and stage
     static_assert(APW >= 1 && BPW >= 1 && A_BYTES + B_BYTES <= STAGE, "tile does not fit the stage");
     const int z = p.batch > 1 ? rbg / p.nbm_per : 0;
@@ -235,6 +235,26 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const IgemmArgs p) {
     }
 }
 
+// Launches whose tiles are all 128 x 64 (N <= 64, grids below one round, and -- E2V_BGEMM_N64_MAXK -- short-K layers): 24 KB
+// stages, 53 KB of LDS per workgroup, so THREE workgroups share a CU.  A short-K tile (K = 320: five stages) spends most of its
+// life waiting for its first HBM bytes; a third resident workgroup is one more tile's worth of loads in flight per CU.
+__global__ __launch_bounds__(256) void bgemm_n64_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bg64[];
+    const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
+    const int nrb = rb_hi - rb_lo;
+    if (loc >= nrb * p.s2) return;
+    const int r = loc / p.s2;
+    bgemm_tile<128, 64, 2, 2, (128 + 64) * 128>(p, rb_lo + r, (loc - r * p.s2) * 64, smem_bg64);
+}
+
+bool bgemm_all_n64(const IgemmArgs& a) {
+    static const int maxk = [] { const char* e = std::getenv("E2V_BGEMM_N64_MAXK"); return e ? std::atoi(e) : 0; }();
+    static const int conv = [] { const char* e = std::getenv("E2V_BGEMM_N64_CONV"); return e ? std::atoi(e) : 0; }();
+    if (a.taps != 1) return conv != 0;
+    return (a.c0 + a.c1) <= maxk && !a.geglu;
+}
+
 void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
     constexpr size_t smem = (size_t)2 * 128 * 128 * 2 + 9 * 128 * sizeof(unsigned);     // two stages of (128 + 128) rows + gather table
     static bool configured = false;
@@ -252,6 +272,21 @@ void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
     const double out_b = a.out_f32 ? 4.0 : 2.0;
     ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
                  a.batch * (2.0 * rows_in * (a.c0 + a.c1) + 2.0 * a.N * K + out_b * a.M * (a.geglu ? a.N / 2 : a.N)), s);
+    if (a.rb1 == 0 && !a.geglu) {          // every row block is cut into 128 x 64 tiles only
+        constexpr size_t smem64 = (size_t)2 * (128 + 64) * 128 + 9 * 128 * sizeof(unsigned);
+        static bool cfg64 = false;
+        if (!cfg64) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_n64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64);
+            cfg64 = true;
+        }
+        int nt = 0;
+        for (int x = 0; x < 8; ++x) {
+            const int nrb = (int)(((long)(x + 1) * a.nbm) >> 3) - (int)(((long)x * a.nbm) >> 3);
+            nt = nrb * a.s2 > nt ? nrb * a.s2 : nt;
+        }
+        hipLaunchKernelGGL(bgemm_n64_kernel, dim3(nt * 8, 1, 1), dim3(256), smem64, s, a);
+        return;
+    }
     hipLaunchKernelGGL(bgemm_kernel, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
 }
 

@@ -926,6 +926,7 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
             if (tail > 0 && tail * per_rb <= 0.5 * xslots) a.rb1 = nbm - 8 * tail < 0 ? 0 : nbm - 8 * tail;
         }
     }
+    if (a.a_bf16 && bgemm_all_n64(a)) a.rb1 = 0;
     a.nbm = nbm;
     a.tail_rb = (nbm - a.rb1 + 7) / 8;                       // per XCD chunk (rb1 == 0: every row block is "tail")
     if (a.rb1 == 0) a.tail_rb = nbm;

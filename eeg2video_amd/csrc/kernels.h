@@ -51,7 +51,8 @@ struct IgemmArgs {
     int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, nbm_per = 0, tail_rb = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
 };
 void igemm(const IgemmArgs& a, hipStream_t s);
-void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s);      // bgemm.hip: the a_bf16 kernels (schedule already in `a`)
+void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s);
+bool bgemm_all_n64(const IgemmArgs& a);                                  // schedule hint: cut this launch into 128 x 64 tiles only      // bgemm.hip: the a_bf16 kernels (schedule already in `a`)
 
 // weight re-layout helpers (one-off, at finalize)
 // [O][I][3][3] -> [O][ceil(I/bke)][9][bke] (bke = 32 for the fp32 kernel, 64 for the bf16 one); row length below

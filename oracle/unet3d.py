@@ -180,6 +180,7 @@ def unet3d_forward(sd: SD, cfg, sample: torch.Tensor, timestep, encoder_hidden_s
         t = t[None]
     t = t.expand(sample.shape[0])
     t_emb = timestep_sinusoid(t, boc[0], cfg.flip_sin_to_cos, cfg.freq_shift)                   # :339
+    t_emb = t_emb.to(dtype=sample.dtype)                                                        # :343 (the model's dtype)
     emb = F.linear(t_emb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])   # :345
     emb = F.linear(F.silu(emb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
     if taps is not None:

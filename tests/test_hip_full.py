@@ -170,3 +170,35 @@ def test_full_vae_encode_vs_oracle(full):
     e_m, e_lv = rel_err(post.mean, mean_ref), rel_err(post.logvar, logvar_ref)
     print(f"full-size VAE encode: mean {e_m:.3e} logvar {e_lv:.3e} (max-abs / max-ref)")
     assert post.mean.shape == (1, 4, 36, 64) and e_m < 1e-3 and e_lv < 1e-3
+
+
+def test_config0_bf16_mode_vs_the_bf16_run_of_the_oracle(full, config0):
+    """BASELINE configs[2] parity at full size: the bf16-activation mode (bf16 tensors in HBM, bf16 MFMA, fp32 accumulation /
+    norm statistics / softmax) on configs[0]'s inputs.  No oracle can reproduce bf16 rounding decision for decision (one
+    flipped rounding is 2^-8 of a value, and every stored tensor is rounded), so the criterion is the one the reference's own
+    reduced-precision run would be held to: the oracle is ALSO run in torch.bfloat16 (the analogue of the reference's
+    `.half()` inference, inference_eeg2video.py:69-70,76 -- every op output rounded, fp32 inside the ops), and the HIP
+    path must sit as close to the fp32 oracle as that run does (factor 1.5), within absolute bounds: frames (in [0,1]) 0.1,
+    latents 5e-2 of their scale.  The three distances are printed."""
+    from oracle import generate
+    pipe, usd, vsd = full
+    eng = pipe.unet.engine
+    lat, cond, unc, ref, trace = config0
+    b16 = lambda sd: {k: _t(v).bfloat16() for k, v in sd.items()}
+    tr16 = {}
+    with torch.no_grad():
+        ref16 = generate(b16(usd), UNetConfig(), b16(vsd), VAEConfig(), lat.bfloat16(), cond.bfloat16(), unc.bfloat16(),
+                         num_inference_steps=4, guidance_scale=12.5, trace=tr16).float()
+    lat16 = tr16["latents"][-1].float()
+    try:
+        eng.set_compute_dtype("bf16")
+        vid, lat_out = eng.generate(lat.cuda(), cond.cuda(), unc.cuda(), 4, 12.5, 0.0, decode=True, return_latents=True)
+    finally:
+        eng.set_compute_dtype("fp32")
+    f_gpu, f_cpu, f_x = ((a.cpu() - b).abs().max().item() for a, b in ((vid, ref), (ref16, ref), (vid, ref16)))
+    l_gpu, l_cpu, l_x = rel_err(lat_out, trace["latents"][-1]), rel_err(lat16, trace["latents"][-1]), rel_err(lat_out, lat16)
+    print(f"bf16 configs[0]: frames max-abs  HIP-bf16 vs fp32 oracle {f_gpu:.3e} | torch-bf16 oracle vs fp32 oracle {f_cpu:.3e} | HIP-bf16 vs torch-bf16 {f_x:.3e}")
+    print(f"                 latents /max-ref HIP-bf16 vs fp32 oracle {l_gpu:.3e} | torch-bf16 oracle vs fp32 oracle {l_cpu:.3e} | HIP-bf16 vs torch-bf16 {l_x:.3e}")
+    assert torch.isfinite(vid).all() and vid.shape == ref.shape
+    assert f_gpu < 0.1 and l_gpu < 5e-2
+    assert f_gpu <= 1.5 * f_cpu + 1e-3 and l_gpu <= 1.5 * l_cpu + 1e-3
