@@ -101,9 +101,11 @@ def save_videos_grid(videos: torch.Tensor, path: str, rescale: bool = False, n_r
     frames = videos.permute(2, 0, 1, 3, 4)                                   # "b c t h w -> t b c h w"
     grids = torch.stack([make_grid(x, nrow=n_rows) for x in frames])         # [T, C, Hg, Wg]
     grids = grids.permute(0, 2, 3, 1)                                        # x.transpose(0, 1).transpose(1, 2)
-    if rescale:
+    if rescale and grids.dtype != torch.uint8:
         grids = (grids + 1.0) / 2.0
-    if grids.is_cuda:
+    if grids.dtype == torch.uint8:          # frames already converted on the device (Engine.frames_to_uint8): laid out only
+        out = grids.cpu().numpy()
+    elif grids.is_cuda:
         from .engine import Engine
         eng = getattr(save_videos_grid, "engine", None)
         if isinstance(eng, Engine):

@@ -30,4 +30,7 @@ def test_save_videos_grid_gif_and_npy(tmp_path):
     im = Image.open(tmp_path / "clip.gif")
     assert im.n_frames == 6 and im.size == (54, 20) and im.info["duration"] == 330      # GIF delays are centiseconds: 1000 / 3 ms -> 33 cs
     r = save_videos_grid(v * 2 - 1, str(tmp_path / "r.npy"), rescale=True)
-    assert np.abs(r.astype(int) - out.astype(int)).max() <= 1
+    assert np.abs(r[:, 2:18, 2:26].astype(int) - out[:, 2:18, 2:26].astype(int)).max() <= 1      # image cells agree ...
+    assert int(r[0, 0, 0, 0]) == 127                                   # ... and the zero padding is rescaled with them, as the reference does
+    u8 = torch.from_numpy(want)                                        # frames already uint8 (Engine.frames_to_uint8): laid out as they are
+    assert np.array_equal(save_videos_grid(u8, str(tmp_path / "u8.npy")), out)

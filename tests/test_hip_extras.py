@@ -102,3 +102,24 @@ def test_end_to_end_example_runs_on_the_tiny_configuration(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["inference_eeg2video.py", "--tiny", "--steps", "3", "--clips", "2"])
     video = mod.main()
     assert tuple(video.shape) == (2, 3, 3, 32, 48)
+
+
+def test_configs4_sweep_driver_on_the_tiny_configuration(tmp_path, capsys):
+    """examples/run_sweep.py (BASELINE configs[4]): GLMNet + Seq2Seq host models -> semantic predictor -> DANA -> e2v_generate ->
+    uint8 -> GIF writer over concepts x clips, batched with a ragged last batch; the same clips in one batch and in batches of 3
+    are bit-identical (clips never mix), in fp32 and in the bf16-activation mode it merely runs."""
+    import importlib.util, json, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "run_sweep.py")
+    spec = importlib.util.spec_from_file_location("e2v_sweep", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    a = mod.main(["--tiny", "--concepts", "2", "--per-concept", "2", "--batch", "3", "--steps", "2", "--out", str(tmp_path), "--npy"])
+    rec = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rec["clips"] == 4 and rec["clips_per_s"] > 0 and 0 <= rec["host_model_share"] < 1
+    assert tuple(a.shape) == (4, 3, 3, 32, 48) and a.dtype == torch.uint8
+    assert sorted(os.listdir(tmp_path)) == ["00_0.npy", "00_1.npy", "01_0.npy", "01_1.npy"]
+    assert np.array_equal(np.load(tmp_path / "01_0.npy")[:, :, :, :], a[2].permute(1, 2, 3, 0).numpy())
+    b = mod.main(["--tiny", "--concepts", "2", "--per-concept", "2", "--batch", "4", "--steps", "2"])
+    assert torch.equal(a, b)
+    c = mod.main(["--tiny", "--concepts", "1", "--per-concept", "2", "--batch", "2", "--steps", "2", "--dtype", "bf16"])
+    assert tuple(c.shape) == (2, 3, 3, 32, 48)
