@@ -20,7 +20,11 @@
 
 namespace e2v {
 
-template <int BM, int BN, int WGM, int WGN, int STAGE = 128 * 128 * 2>      // STAGE: stage stride, sized for the largest tile of the launch
+// LIN: taps == 1 (linear / 1x1 conv).  Rows are their own pixels, so there is no gather table, a lane's source offsets never
+// change, and a k-step is: eight LDS-DMA instructions whose k position rides in the scalar offset, one scalar add -- the
+// general (3x3) path spends ~130 scalar + vector instructions per k-step on the gather, which an in-order wave pays in issue
+// slots next to its 16 MFMAs.
+template <int BM, int BN, int WGM, int WGN, int STAGE = 128 * 128 * 2, bool LIN = false>      // STAGE: stage stride, sized for the largest tile of the launch
 __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, const int n0, char* smem) {
     constexpr int BKE = 64;                         // bf16 elements per stage
     constexpr int ROWB = 128;                       // bytes per LDS tile row
@@ -50,7 +54,7 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
     const int hw_out = p.Ho * p.Wo, hw_in = p.Hs * p.Ws;
     const int img0 = p.taps == 1 ? 0 : (bm * BM) / hw_out;
     const size_t row_base = p.taps == 1 ? (size_t)bm * BM : (size_t)img0 * hw_in;
-    for (int e = tid; e < p.taps * BM; e += NT) {
+    for (int e = tid; !LIN && e < p.taps * BM; e += NT) {
         const int tap = e / BM, row = e - tap * BM;
         const int m = bm * BM + row;
         unsigned pix = ~0u;
@@ -104,17 +108,53 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
         b_kc[j] = (unsigned)(pp ^ ((r >> 1) & 7));
         b_off[j] = (n0 + r < p.N) ? (unsigned)(r * p.ldw * 2) + b_kc[j] * 16u : OOB;
     }
-    __syncthreads();
+    unsigned a_voff0[APW], a_voff1[APW];            // LIN: the lane's fixed source offsets into the two sources
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const bool in = bm * BM + a_row[i] < p.M;
+        a_voff0[i] = in ? (unsigned)(a_row[i] * p.lda0 * 2) + a_kc[i] * 16u : OOB;
+        a_voff1[i] = in ? (unsigned)(a_row[i] * p.lda1 * 2) + a_kc[i] * 16u : OOB;
+    }
+    if constexpr (!LIN) __syncthreads();
 
     int k_src = 0, k_cb = 0, k_tap = 0, cseg = p.c0, ldb = p.lda0 * 2;
     bool done = false;
     unsigned pixn[APW];
+    if constexpr (!LIN) {
 #pragma unroll
-    for (int i = 0; i < APW; ++i) pixn[i] = tab[a_row[i]];
+        for (int i = 0; i < APW; ++i) pixn[i] = tab[a_row[i]];
+    }
     typedef __attribute__((address_space(3))) void* lds_ptr;
+    const __amdgpu_buffer_rsrc_t rsa0 = rsrc_of(a0b), rsa1 = rsrc_of(a1b);
     auto issue = [&](const int buf) {
         char* Ab = smem + buf * STAGE;
         char* Bb = Ab + A_BYTES;
+        if constexpr (LIN) {
+            if (!done) {                                        // wave-uniform
+                const unsigned so = (unsigned)k_cb * 2u;
+                const unsigned sob = (unsigned)((k_src ? p.c0 : 0) + k_cb) * 2u;
+                const bool whole = k_cb + BKE <= cseg;          // the stage lies inside the segment: no channel masks
+                auto dma_a = [&](const __amdgpu_buffer_rsrc_t& rs, const unsigned (&vo)[APW]) {
+#pragma unroll
+                    for (int i = 0; i < APW; ++i) {
+                        const unsigned off = (whole || k_cb + (int)a_kc[i] * 8 < cseg) ? vo[i] : OOB;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(Ab + (wave * APW + i) * 1024), 16, off, so, 0, 0);
+                    }
+                };
+                if (k_src) dma_a(rsa1, a_voff1); else dma_a(rsa0, a_voff0);
+#pragma unroll
+                for (int j = 0; j < BPW; ++j) {
+                    const unsigned off = (whole || k_cb + (int)b_kc[j] * 8 < cseg) ? b_off[j] : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(Bb + (wave * BPW + j) * 1024), 16, off, sob, 0, 0);
+                }
+                k_cb += BKE;
+                if (k_cb >= cseg) {
+                    if (k_src == 0 && p.c1 > 0) { k_src = 1; k_cb = 0; cseg = p.c1; }
+                    else done = true;
+                }
+            }
+            return;
+        }
         if (!done) {                                            // wave-uniform
             const __amdgpu_buffer_rsrc_t rsa = rsrc_of(k_src ? a1b : a0b);
             const unsigned colb = (unsigned)k_cb * 2u;
@@ -215,6 +255,7 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
     }
 }
 
+template <bool LIN>
 __global__ __launch_bounds__(256) void bgemm_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_bg[];
     const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
@@ -225,19 +266,20 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const IgemmArgs p) {
     const int n1 = (nrb - tail) * per1;
     if (loc < n1) {
         const int r = loc / per1, j = loc - r * per1;
-        if (j < p.w1) bgemm_tile<128, 128, 2, 2>(p, rb_lo + r, j * 128, smem_bg);
-        else bgemm_tile<128, 64, 2, 2>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_bg);
+        if (j < p.w1) bgemm_tile<128, 128, 2, 2, 128 * 128 * 2, LIN>(p, rb_lo + r, j * 128, smem_bg);
+        else bgemm_tile<128, 64, 2, 2, 128 * 128 * 2, LIN>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_bg);
     } else {
         const int t = loc - n1;
         if (t >= tail * p.s2) return;
         const int r = t / p.s2;
-        bgemm_tile<128, 64, 2, 2>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_bg);
+        bgemm_tile<128, 64, 2, 2, 128 * 128 * 2, LIN>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_bg);
     }
 }
 
 // Launches whose tiles are all 128 x 64 (N <= 64, grids below one round, and -- E2V_BGEMM_N64_MAXK -- short-K layers): 24 KB
 // stages, 53 KB of LDS per workgroup, so THREE workgroups share a CU.  A short-K tile (K = 320: five stages) spends most of its
 // life waiting for its first HBM bytes; a third resident workgroup is one more tile's worth of loads in flight per CU.
+template <bool LIN>
 __global__ __launch_bounds__(256) void bgemm_n64_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_bg64[];
     const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
@@ -245,7 +287,7 @@ __global__ __launch_bounds__(256) void bgemm_n64_kernel(const IgemmArgs p) {
     const int nrb = rb_hi - rb_lo;
     if (loc >= nrb * p.s2) return;
     const int r = loc / p.s2;
-    bgemm_tile<128, 64, 2, 2, (128 + 64) * 128>(p, rb_lo + r, (loc - r * p.s2) * 64, smem_bg64);
+    bgemm_tile<128, 64, 2, 2, (128 + 64) * 128, LIN>(p, rb_lo + r, (loc - r * p.s2) * 64, smem_bg64);
 }
 
 bool bgemm_all_n64(const IgemmArgs& a) {
@@ -259,9 +301,12 @@ void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
     constexpr size_t smem = (size_t)2 * 128 * 128 * 2 + 9 * 128 * sizeof(unsigned);     // two stages of (128 + 128) rows + gather table
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         configured = true;
     }
+    static const int lean = [] { const char* e = std::getenv("E2V_BGEMM_LIN"); return e ? std::atoi(e) : 1; }();   // 0: linears through the gather path
+    const bool lin = a.taps == 1 && lean;
     const double K = (double)a.taps * (a.c0 + a.c1);
     const double rows_in = a.taps == 1 ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
     std::string pname = "igemm_bf16";
@@ -276,7 +321,8 @@ void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
         constexpr size_t smem64 = (size_t)2 * (128 + 64) * 128 + 9 * 128 * sizeof(unsigned);
         static bool cfg64 = false;
         if (!cfg64) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_n64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_n64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_n64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64);
             cfg64 = true;
         }
         int nt = 0;
@@ -284,10 +330,12 @@ void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
             const int nrb = (int)(((long)(x + 1) * a.nbm) >> 3) - (int)(((long)x * a.nbm) >> 3);
             nt = nrb * a.s2 > nt ? nrb * a.s2 : nt;
         }
-        hipLaunchKernelGGL(bgemm_n64_kernel, dim3(nt * 8, 1, 1), dim3(256), smem64, s, a);
+        if (lin) hipLaunchKernelGGL(bgemm_n64_kernel<true>, dim3(nt * 8, 1, 1), dim3(256), smem64, s, a);
+        else hipLaunchKernelGGL(bgemm_n64_kernel<false>, dim3(nt * 8, 1, 1), dim3(256), smem64, s, a);
         return;
     }
-    hipLaunchKernelGGL(bgemm_kernel, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
+    if (lin) hipLaunchKernelGGL(bgemm_kernel<true>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
+    else hipLaunchKernelGGL(bgemm_kernel<false>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
 }
 
 }  // namespace e2v
