@@ -125,7 +125,6 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
         for (int i = 0; i < APW; ++i) pixn[i] = tab[a_row[i]];
     }
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    const __amdgpu_buffer_rsrc_t rsa0 = rsrc_of(a0b), rsa1 = rsrc_of(a1b);
     auto issue = [&](const int buf) {
         char* Ab = smem + buf * STAGE;
         char* Bb = Ab + A_BYTES;
@@ -134,14 +133,13 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
                 const unsigned so = (unsigned)k_cb * 2u;
                 const unsigned sob = (unsigned)((k_src ? p.c0 : 0) + k_cb) * 2u;
                 const bool whole = k_cb + BKE <= cseg;          // the stage lies inside the segment: no channel masks
-                auto dma_a = [&](const __amdgpu_buffer_rsrc_t& rs, const unsigned (&vo)[APW]) {
+                const __amdgpu_buffer_rsrc_t rsa = rsrc_of(k_src ? a1b : a0b);
 #pragma unroll
-                    for (int i = 0; i < APW; ++i) {
-                        const unsigned off = (whole || k_cb + (int)a_kc[i] * 8 < cseg) ? vo[i] : OOB;
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(Ab + (wave * APW + i) * 1024), 16, off, so, 0, 0);
-                    }
-                };
-                if (k_src) dma_a(rsa1, a_voff1); else dma_a(rsa0, a_voff0);
+                for (int i = 0; i < APW; ++i) {
+                    const unsigned vo = k_src ? a_voff1[i] : a_voff0[i];
+                    const unsigned off = (whole || k_cb + (int)a_kc[i] * 8 < cseg) ? vo : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(Ab + (wave * APW + i) * 1024), 16, off, so, 0, 0);
+                }
 #pragma unroll
                 for (int j = 0; j < BPW; ++j) {
                     const unsigned off = (whole || k_cb + (int)b_kc[j] * 8 < cseg) ? b_off[j] : OOB;
@@ -255,6 +253,161 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
     }
 }
 
+// ---- taps == 1, four-stage ring (E2V_BGEMM_RING) --------------------------------------------------------------------------
+// The two-stage tile above hands its loads one k-step of cover; a linear layer streams its activations straight from HBM
+// (K = 320: five stages in all), and PMC counters put the waves of such a launch 56 % of their life in s_waitcnt / s_barrier.
+// Here a stage is 32 channels (64-byte tile rows: a DMA piece is 16 rows, chunk swizzle (row >> 2) & 3), four stages ring
+// through 64 KB, and the loads of stage j + 3 are issued as soon as stage j - 1 has been consumed: three stages are always in
+// flight per workgroup, the consumer waits with a COUNTED vmcnt (the two youngest stages stay outstanding) and a raw
+// s_barrier -- no drain in the loop.
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void bgemm_ring_tile(const IgemmArgs& p, const int rbg, const int n0, char* smem) {
+    constexpr int BKE = 32, ROWB = 64, NS = 4, PF = 3;
+    constexpr int NW = WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = 128 * ROWB * 2;
+    constexpr int APW = BM / 16 / NW, BPW = BN / 16 / NW;     // 1-KB DMA pieces (16 rows) per wave and stage
+    constexpr int PIECES = APW + BPW;
+    static_assert(APW >= 1 && BPW >= 1, "tile too small for the DMA split");
+    const int z = p.batch > 1 ? rbg / p.nbm_per : 0;
+    const int bm = rbg - z * p.nbm_per;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const __bf16* __restrict__ a0 = reinterpret_cast<const __bf16*>(p.a0) + (size_t)z * p.sa0;
+    const __bf16* __restrict__ a1 = reinterpret_cast<const __bf16*>(p.a1);
+    const char* __restrict__ w = reinterpret_cast<const char*>(p.w16) + ((size_t)z * p.sw + (size_t)n0 * p.ldw) * 2;
+    const int nk = (p.c0 + BKE - 1) / BKE + (p.c1 + BKE - 1) / BKE;
+    constexpr unsigned OOB = 0x80000000u;
+    const size_t row_base = (size_t)bm * BM;
+    const __bf16* const a0b = a0 + row_base * p.lda0;
+    const __bf16* const a1b = p.c1 > 0 ? a1 + row_base * p.lda1 : a0b;
+    auto rsrc_of = [](const void* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, 0x7FFFFFF0,
+                                                 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rw = rsrc_of(w);
+    const int r16 = lane >> 2, pp = lane & 3;
+    unsigned a_voff0[APW], a_voff1[APW], a_kc[APW], b_off[BPW], b_kc[BPW];
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const int r = 16 * (wave * APW + i) + r16;
+        a_kc[i] = (unsigned)(pp ^ ((r >> 2) & 3));
+        const bool in = bm * BM + r < p.M;
+        a_voff0[i] = in ? (unsigned)(r * p.lda0 * 2) + a_kc[i] * 16u : OOB;
+        a_voff1[i] = in ? (unsigned)(r * p.lda1 * 2) + a_kc[i] * 16u : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+        const int r = 16 * (wave * BPW + j) + r16;
+        b_kc[j] = (unsigned)(pp ^ ((r >> 2) & 3));
+        b_off[j] = (n0 + r < p.N) ? (unsigned)(r * p.ldw * 2) + b_kc[j] * 16u : OOB;
+    }
+    int k_src = 0, k_cb = 0, cseg = p.c0;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto issue = [&](const int buf) {                       // one stage; never called past the last one
+        char* Ab = smem + buf * STAGE;
+        char* Bb = Ab + A_BYTES;
+        const unsigned so = (unsigned)k_cb * 2u;
+        const unsigned sob = (unsigned)((k_src ? p.c0 : 0) + k_cb) * 2u;
+        const bool whole = k_cb + BKE <= cseg;
+        // the descriptor is rebuilt from a pointer forced into SGPRs: a select between two ready-made descriptors is not provably
+        // wave-uniform to hipcc, which then parks them in scratch and wraps every load in a waterfall loop (with a vmcnt(0))
+        const __amdgpu_buffer_rsrc_t rsa = rsrc_of(k_src ? a1b : a0b);
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const unsigned vo = k_src ? a_voff1[i] : a_voff0[i];
+            const unsigned off = (whole || k_cb + (int)a_kc[i] * 8 < cseg) ? vo : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(Ab + (wave * APW + i) * 1024), 16, off, so, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const unsigned off = (whole || k_cb + (int)b_kc[j] * 8 < cseg) ? b_off[j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(Bb + (wave * BPW + j) * 1024), 16, off, sob, 0, 0);
+        }
+        k_cb += BKE;
+        if (k_cb >= cseg && k_src == 0 && p.c1 > 0) { k_src = 1; k_cb = 0; cseg = p.c1; }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int fs = (fr >> 2) & 3;
+    const unsigned foff0 = (unsigned)(((0 + fh) ^ fs) * 16), foff1 = (unsigned)(((2 + fh) ^ fs) * 16);
+    const char* Afr = smem + (wm * WM + fr) * ROWB;
+    const char* Bfr = smem + A_BYTES + (wn * WN + fr) * ROWB;
+
+    int issued = 0;
+    for (; issued < PF && issued < nk; ++issued) issue(issued);
+    for (int j = 0; j < nk; ++j) {
+        const int left = nk - j - 1;                            // stages behind this one: min(left, PF - 1) of them are in flight
+        if (left >= PF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * PIECES) : "memory");
+        else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // stage j landed for every wave; stage j - 1 is consumed
+        __builtin_amdgcn_sched_barrier(0);
+        if (issued < nk) { issue(issued & (NS - 1)); ++issued; }
+        const int bo = (j & (NS - 1)) * STAGE;
+        bf16x8 af0[TM], bf0[TN], af1[TM], bf1[TN];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) af0[mi] = *reinterpret_cast<const bf16x8*>(Afr + bo + mi * 32 * ROWB + foff0);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf0[ni] = *reinterpret_cast<const bf16x8*>(Bfr + bo + ni * 32 * ROWB + foff0);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) af1[mi] = *reinterpret_cast<const bf16x8*>(Afr + bo + mi * 32 * ROWB + foff1);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf1[ni] = *reinterpret_cast<const bf16x8*>(Bfr + bo + ni * 32 * ROWB + foff1);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf0[ni], af0[mi], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf1[ni], af1[mi], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();                                            // the ring becomes the epilogue's staging area
+    if (p.out_f32) {
+        float* __restrict__ out = p.out + (size_t)z * p.sout;
+        igemm_epilogue<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane, reinterpret_cast<float*>(smem));
+    } else {
+        __bf16* __restrict__ out = reinterpret_cast<__bf16*>(p.out) + (size_t)z * p.sout;
+        bgemm_epilogue_bf16<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane, reinterpret_cast<float*>(smem));
+    }
+}
+
+__global__ __launch_bounds__(256) void bgemm_ring_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_ring[];
+    const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
+    const int nrb = rb_hi - rb_lo;
+    const int tail = min(nrb, p.tail_rb);
+    const int per1 = p.w1 + p.s1;
+    const int n1 = (nrb - tail) * per1;
+    if (loc < n1) {
+        const int r = loc / per1, j = loc - r * per1;
+        if (j < p.w1) bgemm_ring_tile<128, 128, 2, 2>(p, rb_lo + r, j * 128, smem_ring);
+        else bgemm_ring_tile<128, 64, 2, 2>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_ring);
+    } else {
+        const int t = loc - n1;
+        if (t >= tail * p.s2) return;
+        const int r = t / p.s2;
+        bgemm_ring_tile<128, 64, 2, 2>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_ring);
+    }
+}
+
 template <bool LIN>
 __global__ __launch_bounds__(256) void bgemm_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_bg[];
@@ -307,6 +460,24 @@ void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
     }
     static const int lean = [] { const char* e = std::getenv("E2V_BGEMM_LIN"); return e ? std::atoi(e) : 1; }();   // 0: linears through the gather path
     const bool lin = a.taps == 1 && lean;
+    static const int ring = [] { const char* e = std::getenv("E2V_BGEMM_RING"); return e ? std::atoi(e) : 0; }();
+    if (ring && a.taps == 1) {
+        constexpr size_t smem_r = (size_t)4 * 128 * 64 * 2;                               // four stages of (128 + 128) rows x 64 bytes
+        static bool cfgr = false;
+        if (!cfgr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_r);
+            cfgr = true;
+        }
+        const double Kr = (double)(a.c0 + a.c1);
+        std::string rn = "igemm_bf16";
+        if (profiler().on && profiler().detail)
+            rn += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)Kr) + " t1" + (a.c1 ? " cat" : "") +
+                  (a.geglu ? " geglu" : "") + (a.batch > 1 ? " b" + std::to_string(a.batch) : "");
+        ProfScope psr(rn.c_str(), 2.0 * a.M * a.N * Kr * a.batch,
+                      a.batch * (2.0 * a.M * Kr + 2.0 * a.N * Kr + (a.out_f32 ? 4.0 : 2.0) * a.M * (a.geglu ? a.N / 2 : a.N)), s);
+        hipLaunchKernelGGL(bgemm_ring_kernel, dim3(ntiles, 1, 1), dim3(256), smem_r, s, a);
+        return;
+    }
     const double K = (double)a.taps * (a.c0 + a.c1);
     const double rows_in = a.taps == 1 ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
     std::string pname = "igemm_bf16";

