@@ -223,6 +223,15 @@ def main() -> int:
     host_frames = torch.empty((world * B, 3, 6, 288, 512), dtype=torch.float32).pin_memory() if rank == 0 else None
     if rank == 0:
         log(f"setup {time.perf_counter() - t_setup:.1f} s; device memory held {eng.device_bytes() / 2**30:.2f} GiB")
+        if os.environ.get("E2V_LOG_MAPS"):       # profiling aid: where the runtime / tool libraries sit, so that a native backtrace can be attributed
+            seen = set()
+            for line in open("/proc/self/maps"):
+                f = line.split()
+                if len(f) >= 6 and "x" in f[1] and any(k in f[5] for k in ("libamdhip64", "libhsa-runtime", "rocprofiler", "libeeg2video_hip", "libroctracer", "librocprofiler")):
+                    key = os.path.basename(f[5])
+                    if key not in seen:
+                        seen.add(key)
+                        log(f"map {f[0]} {f[5]}")
 
     def step():
         frames = eng.generate(lat, cond, unc, args.ddim_steps, args.guidance, 0.0, decode=True)

@@ -263,209 +263,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs p) {
     }
 }
 
-// ---- bf16-MFMA variant (BASELINE configs[2]) ------------------------------------------------------------------
-// Same decomposition (one wave = 32 queries, S^T = K Q^T, O^T = V^T P^T, online softmax in fp32) on
-// v_mfma_f32_32x32x16_bf16: Q, K, V and P are rounded to bf16 on their way into registers / LDS, accumulation and the
-// softmax stay fp32.  A 32x32 fp32 accumulator tile is directly the B operand of the next MFMA once its registers
-// 8s..8s+7 are packed to bf16 (k-slot j of lane half h = key 16s + 8(j>>2) + 4h + (j&3)); V is staged TRANSPOSED
-// ([value column][key]) so that the matching A fragment is two 8-byte reads.  7 MFMAs of 32 cycles per key tile at
-// d = 40 (fp32 path: 36 of 64), so this kernel is bound by the softmax VALU work, not the matrix pipe.
 typedef __bf16 abf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
-
-template <int D>
-__global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const AttnArgs p) {
-    constexpr int DP = (D + 15) / 16 * 16;      // head dim padded to the 16-deep MFMA step
-    constexpr int KS = DP / 16;
-    constexpr int KROW = DP * 2 + 16;           // bytes per K row (padded: conflict-free b128 reads)
-    constexpr int T = (D + 31) / 32;            // 32-row tiles of O^T
-    constexpr int VROW = 72;                    // bytes per V^T row: 32 keys x 2 B + 8 (conflict-free b64 reads)
-    constexpr int KBYTES = 32 * KROW, VBYTES = T * 32 * VROW;
-    constexpr int STAGE = (KBYTES + VBYTES + 15) / 16 * 16;
-    constexpr int DQ = D / 4;
-    constexpr int NF4 = 32 * DQ;
-    constexpr int LPT = (NF4 + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) char smem_b[];      // [2][K rows | V^T rows]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int sf = blockIdx.z;
-    const int smp = sf / p.F, f = sf - smp * p.F;
-    const int head = blockIdx.y;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
-    const bool active = q0 < p.Nq;
-
-    int nseg = 1;
-    size_t kvbase[2];
-    if (p.mode == 0) {
-        kvbase[0] = (size_t)(smp * p.F) * p.Nk;
-        kvbase[1] = (size_t)(smp * p.F + (f > 0 ? f - 1 : 0)) * p.Nk;
-        nseg = f >= 2 ? 2 : 1;
-    } else {
-        kvbase[0] = kvbase[1] = (size_t)smp * p.Nk;
-    }
-    const int tps = (p.Nk + 31) / 32;
-    const int ntiles = nseg * tps;
-
-    for (int i = tid * 16; i < 2 * STAGE; i += 256 * 16)                // pad columns / rows are never rewritten
-        *reinterpret_cast<f32x4*>(smem_b + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    abf16x8 qf[KS];
-    {
-        const int qrow = min(q0 + j, p.Nq - 1);
-        const float* qp = p.q + ((size_t)sf * p.Nq + qrow) * p.ldq + head * D;
-        const float c = p.scale * 1.44269504088896340736f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int k0 = 16 * s + 8 * h;
-            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-            if (k0 < D) {
-                a = *reinterpret_cast<const f32x4*>(qp + k0) * c;
-                b = *reinterpret_cast<const f32x4*>(qp + k0 + 4) * c;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                qf[s][e] = (__bf16)a[e];
-                qf[s][4 + e] = (__bf16)b[e];
-            }
-        }
-    }
-    __syncthreads();
-
-    f32x4 kreg[LPT], vreg[LPT];
-    auto load_tile = [&](int tt) {
-        const int seg = tt / tps;
-        const int key0 = (tt - seg * tps) * 32;
-#pragma unroll
-        for (int e = 0; e < LPT; ++e) {
-            const int idx = tid + 256 * e;
-            f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (idx < NF4) {
-                const int row = idx / DQ, c4 = idx - row * DQ;
-                const int key = key0 + row;
-                if (key < p.Nk) {
-                    const size_t off = (kvbase[seg] + key) * p.ldkv + head * D + c4 * 4;
-                    kk = *reinterpret_cast<const f32x4*>(p.k + off);
-                    vv = *reinterpret_cast<const f32x4*>(p.v + off);
-                }
-            }
-            kreg[e] = kk;
-            vreg[e] = vv;
-        }
-    };
-    auto store_tile = [&](int buf) {
-        char* Kl = smem_b + buf * STAGE;
-        char* Vl = Kl + KBYTES;
-#pragma unroll
-        for (int e = 0; e < LPT; ++e) {
-            const int idx = tid + 256 * e;
-            if (idx < NF4) {
-                const int row = idx / DQ, c4 = idx - row * DQ;
-                *reinterpret_cast<abf16x4*>(Kl + row * KROW + c4 * 8) = __builtin_convertvector(kreg[e], abf16x4);
-#pragma unroll
-                for (int x = 0; x < 4; ++x)                              // transpose: [value column][key]
-                    *reinterpret_cast<__bf16*>(Vl + (c4 * 4 + x) * VROW + row * 2) = (__bf16)vreg[e][x];
-            }
-        }
-    };
-
-    f32x16 acc[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float m_i = -INFINITY, l_i = 0.f;
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int tt = 0; tt < ntiles; ++tt) {
-        const int buf = tt & 1;
-        if (tt + 1 < ntiles) load_tile(tt + 1);
-        const int seg_c = tt / tps;
-        const int key0 = (tt - seg_c * tps) * 32;
-        if (active) {
-            const char* Kl = smem_b + buf * STAGE;
-            const char* Vl = Kl + KBYTES;
-            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            f32x16 st;
-            const char* kp = Kl + j * KROW + h * 16;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const abf16x8 kf = *reinterpret_cast<const abf16x8*>(kp + s * 32);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? zero16 : st, 0, 0, 0);
-            }
-            if (key0 + 32 > p.Nk) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key >= p.Nk) st[r] = -INFINITY;
-                }
-            }
-            float mt = st[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mt = __builtin_fmaxf(mt, st[r]);
-            mt = __builtin_fmaxf(mt, __shfl_xor(mt, 32));
-            const float m_new = __builtin_fmaxf(m_i, mt);
-            const bool moved = __any(m_new > m_i);
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                st[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
-                ps += st[r];
-            }
-            float alpha = 1.0f;
-            if (moved) {
-                alpha = __builtin_amdgcn_exp2f(m_i - m_new);
-                l_i *= alpha;
-            }
-            l_i += ps;
-            m_i = m_new;
-            abf16x8 pf[2];                       // P^T fragments: registers 8s..8s+7 are k-step s as they stand
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pf[s][e] = (__bf16)st[8 * s + e];
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                if (moved) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
-                }
-                const char* vrow = Vl + min(t * 32 + j, D - 1) * VROW + h * 8;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const abf16x4 lo = *reinterpret_cast<const abf16x4*>(vrow + s * 32);        // keys 16s + 4h + 0..3
-                    const abf16x4 hi = *reinterpret_cast<const abf16x4*>(vrow + s * 32 + 16);   // keys 16s + 8 + 4h + 0..3
-                    const abf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], acc[t], 0, 0, 0);
-                }
-            }
-        }
-        if (tt + 1 < ntiles) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-
-    const float l_tot = l_i + __shfl_xor(l_i, 32);
-    if (active && q0 + j < p.Nq) {
-        const float inv = 1.0f / l_tot;
-        float* op = p.o + ((size_t)sf * p.Nq + q0 + j) * p.ldo + head * D;
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int dv = t * 32 + 8 * rg + 4 * h;
-                if (dv < D) {
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = acc[t][rg * 4 + e] * inv;
-                    *reinterpret_cast<f32x4*>(op + dv) = o;
-                }
-            }
-    }
-}
 
 // ---- bf16 in HBM (bf16-activation mode, AttnArgs::io_bf16) ----------------------------------------------------
 // Q, K, V arrive as bf16 rows and O leaves as bf16: nothing is converted on the way in.  K and V tiles go to LDS as they
@@ -979,25 +778,6 @@ static void launch_flash_x3(const AttnArgs& a, hipStream_t s) {
 }
 
 template <int D>
-static void launch_flash_bf16(const AttnArgs& a, hipStream_t s) {
-    static bool configured = false;
-    constexpr int DP = (D + 15) / 16 * 16;
-    constexpr size_t stage = ((size_t)32 * (DP * 2 + 16) + (size_t)((D + 31) / 32) * 32 * 72 + 15) / 16 * 16;
-    constexpr size_t smem = 2 * stage;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_bf16_kernel<D>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        configured = true;
-    }
-    dim3 grid((a.Nq + 127) / 128, a.heads, a.n * a.F);
-    const double nk = a.mode == 0 ? 2.0 * a.Nk : (double)a.Nk;
-    const double probs = (double)a.n * a.F * a.heads;
-    ProfScope ps(a.mode == 0 ? "flash_attn_bf16_sparse_causal" : "flash_attn_bf16_cross", 4.0 * probs * a.Nq * nk * D,
-                 4.0 * probs * D * (2.0 * a.Nq + 2.0 * (a.mode == 0 ? a.Nk : (double)a.Nk / a.F)), s);
-    hipLaunchKernelGGL((flash_attn_bf16_kernel<D>), grid, dim3(256), smem, s, a);
-}
-
-template <int D>
 static void launch_flash(const AttnArgs& a, hipStream_t s) {
     static bool configured = false;
     constexpr size_t smem = (size_t)2 * 2 * 32 * (D + 4) * sizeof(float);
@@ -1038,7 +818,7 @@ void flash_attention(const AttnArgs& a, hipStream_t s) {
             default: launch_flash_b16io<160>(a, s); return;
         }
     }
-    if (a.x3 && !a.bf16) {
+    if (a.x3) {
         switch (a.D) {
             case 8: launch_flash_x3<8>(a, s); return;
             case 16: launch_flash_x3<16>(a, s); return;
@@ -1048,18 +828,6 @@ void flash_attention(const AttnArgs& a, hipStream_t s) {
             case 80: launch_flash_x3<80>(a, s); return;
             default: launch_flash_x3<160>(a, s); return;
         }
-    }
-    if (a.bf16) {
-        switch (a.D) {
-            case 8: launch_flash_bf16<8>(a, s); break;
-            case 16: launch_flash_bf16<16>(a, s); break;
-            case 32: launch_flash_bf16<32>(a, s); break;
-            case 40: launch_flash_bf16<40>(a, s); break;
-            case 64: launch_flash_bf16<64>(a, s); break;
-            case 80: launch_flash_bf16<80>(a, s); break;
-            default: launch_flash_bf16<160>(a, s); break;
-        }
-        return;
     }
     switch (a.D) {
         case 8: launch_flash<8>(a, s); break;

@@ -266,7 +266,7 @@ __device__ __forceinline__ void bgemm_ring_tile(const IgemmArgs& p, const int rb
     constexpr int NW = WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = 128 * ROWB * 2;
+    constexpr int A_BYTES = BM * ROWB, STAGE = 128 * ROWB * 2;
     constexpr int APW = BM / 16 / NW, BPW = BN / 16 / NW;     // 1-KB DMA pieces (16 rows) per wave and stage
     constexpr int PIECES = APW + BPW;
     static_assert(APW >= 1 && BPW >= 1, "tile too small for the DMA split");
@@ -429,6 +429,38 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const IgemmArgs p) {
     }
 }
 
+// 256-row tiles: 8 waves (4 x 2, the same 64 x 64 wave tile), 256 x 128 and 256 x 64, 48 KB stages, one workgroup per CU.
+template <bool LIN>
+__global__ __launch_bounds__(512) void bgemm256_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bg256[];
+    constexpr int ST = (256 + 128) * 128;
+    const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
+    const int nrb = rb_hi - rb_lo;
+    const int tail = min(nrb, p.tail_rb);
+    const int per1 = p.w1 + p.s1;
+    const int n1 = (nrb - tail) * per1;
+    if (loc < n1) {
+        const int r = loc / per1, j = loc - r * per1;
+        if (j < p.w1) bgemm_tile<256, 128, 4, 2, ST, LIN>(p, rb_lo + r, j * 128, smem_bg256);
+        else bgemm_tile<256, 64, 4, 2, ST, LIN>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_bg256);
+    } else {
+        const int t = loc - n1;
+        if (t >= tail * p.s2) return;
+        const int r = t / p.s2;
+        bgemm_tile<256, 64, 4, 2, ST, LIN>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_bg256);
+    }
+}
+
+bool bgemm_use_256(const IgemmArgs& a) {
+    static const int mode = [] { const char* e = std::getenv("E2V_BGEMM_256"); return e ? std::atoi(e) : 1; }();   // 0: never, 2: always
+    if (mode == 0) return false;
+    if (mode == 2) return true;
+    // at least four rounds of 256 resident tiles, else the finer 128-row grid wastes less on its last round
+    const double tiles = (double)((a.M + 255) / 256) * a.batch * ((a.N + 127) / 128);
+    return tiles >= 4.0 * 256;
+}
+
 // Launches whose tiles are all 128 x 64 (N <= 64, grids below one round, and -- E2V_BGEMM_N64_MAXK -- short-K layers): 24 KB
 // stages, 53 KB of LDS per workgroup, so THREE workgroups share a CU.  A short-K tile (K = 320: five stages) spends most of its
 // life waiting for its first HBM bytes; a third resident workgroup is one more tile's worth of loads in flight per CU.
@@ -461,7 +493,7 @@ void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
     static const int lean = [] { const char* e = std::getenv("E2V_BGEMM_LIN"); return e ? std::atoi(e) : 1; }();   // 0: linears through the gather path
     const bool lin = a.taps == 1 && lean;
     static const int ring = [] { const char* e = std::getenv("E2V_BGEMM_RING"); return e ? std::atoi(e) : 0; }();
-    if (ring && a.taps == 1) {
+    if (ring && a.taps == 1 && !a.bm256) {
         constexpr size_t smem_r = (size_t)4 * 128 * 64 * 2;                               // four stages of (128 + 128) rows x 64 bytes
         static bool cfgr = false;
         if (!cfgr) {
@@ -488,6 +520,18 @@ void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
     const double out_b = a.out_f32 ? 4.0 : 2.0;
     ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
                  a.batch * (2.0 * rows_in * (a.c0 + a.c1) + 2.0 * a.N * K + out_b * a.M * (a.geglu ? a.N / 2 : a.N)), s);
+    if (a.bm256) {
+        constexpr size_t smem256 = (size_t)2 * (256 + 128) * 128 + 9 * 256 * sizeof(unsigned);
+        static bool cfg256 = false;
+        if (!cfg256) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem256);
+            cfg256 = true;
+        }
+        if (lin) hipLaunchKernelGGL(bgemm256_kernel<true>, dim3(ntiles, 1, 1), dim3(512), smem256, s, a);
+        else hipLaunchKernelGGL(bgemm256_kernel<false>, dim3(ntiles, 1, 1), dim3(512), smem256, s, a);
+        return;
+    }
     if (a.rb1 == 0 && !a.geglu) {          // every row block is cut into 128 x 64 tiles only
         constexpr size_t smem64 = (size_t)2 * (128 + 64) * 128 + 9 * 128 * sizeof(unsigned);
         static bool cfg64 = false;

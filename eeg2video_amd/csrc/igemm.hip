@@ -23,13 +23,11 @@ namespace e2v {
 static constexpr int BK = 32;
 static constexpr int LDS_LD = 36;
 
-// BF = false: fp32 operands, v_mfma_f32_32x32x2_f32, 32 k per stage (the parity configuration).
-// BF = true : bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation over fp32 activations in HBM: the A tile is
-//             rounded to bf16 on its way into LDS, weights are pre-converted (p.w16), 64 k per stage.  LDS rows are
-//             144 bytes in both modes and a lane's fragment is the same 16 bytes (4 fp32 / 8 bf16), so the fragment
-//             reads, the schedule and the epilogue are shared.
-template <int BM, int BN, int WGM, int WGN, int ABL, int NBUF, bool BF = false>
+// fp32 operands, v_mfma_f32_32x32x2_f32, 32 k per stage (the parity configuration).  (The bf16-activation mode has its own
+// kernels: bgemm.hip.)
+template <int BM, int BN, int WGM, int WGN, int ABL, int NBUF>
 __device__ __forceinline__ void igemm_tile(const IgemmArgs& p, const int rbg, const int n0, float* smem) {
+    constexpr bool BF = false;
     // rbg counts row blocks over all batch entries (batch-major): entry z, row block bm within it
     const int z = p.batch > 1 ? rbg / p.nbm_per : 0;
     const int bm = rbg - z * p.nbm_per;
@@ -666,161 +664,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
-template <int BM, int BN, int WGM, int WGN>
-__device__ __forceinline__ void igemm_tile_k32bf(const IgemmArgs& p, const int rbg, const int n0, float* smem) {
-    const int z = p.batch > 1 ? rbg / p.nbm_per : 0;
-    const int bm = rbg - z * p.nbm_per;
-    constexpr int BKE = 32, LD = 20;                // 32 bf16 (64 bytes) + 16 pad per LDS row = 20 floats: conflict-free b128 reads
-    constexpr int NT = 64 * WGM * WGN;
-    constexpr int WM = BM / WGM, WN = BN / WGN;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int RPA = NT / 8, AR = BM / RPA;      // activations: 8 lanes per 128-byte fp32 row piece
-    constexpr int RPP = NT / 4;                     // weights: 4 lanes per 64-byte bf16 row piece
-    constexpr int BR = (BN + RPP - 1) / RPP;
-    float* As = smem;                               // [2][BM][LD]
-    float* Bs = smem + 2 * BM * LD;                 // [2][BN][LD]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const float* __restrict__ a0 = p.a0 + (size_t)z * p.sa0;
-    const char* __restrict__ w = reinterpret_cast<const char*>(p.w16) + ((size_t)z * p.sw + (size_t)n0 * p.ldw) * 2;
-    float* __restrict__ out = p.out + (size_t)z * p.sout;
-    const int nk = (p.c0 + BKE - 1) / BKE + (p.c1 + BKE - 1) / BKE;
-    const int q = tid & 3, r0 = tid >> 2;           // weight loader
-    const int aq = tid & 7, ar0 = tid >> 3;         // activation loader
-    constexpr unsigned OOB = 0x80000000u;
-    const size_t row_base = (size_t)bm * BM;
-    const float* const a0b = a0 + row_base * p.lda0;
-    const float* const a1b = p.c1 > 0 ? p.a1 + row_base * p.lda1 : a0b;
-    auto rsrc_of = [](const void* ptr) {
-        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, 0x7FFFFFF0,
-                                                 0x00020000);
-    };
-    const __amdgpu_buffer_rsrc_t rw = rsrc_of(w);
-    unsigned a_row[AR], b_off[BR];
-#pragma unroll
-    for (int i = 0; i < AR; ++i) a_row[i] = (bm * BM + ar0 + RPA * i < p.M) ? (unsigned)(ar0 + RPA * i) : ~0u;
-#pragma unroll
-    for (int j = 0; j < BR; ++j) {
-        const int r = r0 + RPP * j;
-        b_off[j] = (r < BN && n0 + r < p.N) ? (unsigned)(r * p.ldw * 2 + q * 16) : OOB;
-    }
-    int k_src = 0, k_cb = 0, cseg = p.c0, ldb = p.lda0 * 4;
-    bool done = false;
-    f32x4 rga[2][AR], rgb[2][BR];
-    auto issue_loads = [&](f32x4 (&ra)[AR], f32x4 (&rb)[BR]) {
-        const unsigned colb = (unsigned)(k_cb + aq * 4) * 4u;
-        const __amdgpu_buffer_rsrc_t rsa = rsrc_of(k_src ? a1b : a0b);
-        const bool cok = (!done) & (k_cb + aq * 4 < cseg);
-        const bool cokb = (!done) & (k_cb + q * 8 < cseg);
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const unsigned rowb = __umul24(a_row[i], (unsigned)ldb) + colb;
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, ((a_row[i] != ~0u) & cok) ? rowb : OOB, 0, 0));
-        }
-        const int koffb = ((k_src ? p.c0 : 0) + k_cb) * 2;
-#pragma unroll
-        for (int j = 0; j < BR; ++j)
-            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, cokb ? b_off[j] : OOB, koffb, 0));
-        const int cb2 = k_cb + BKE;
-        const bool wrap = cb2 >= cseg;
-        k_cb = wrap ? 0 : cb2;
-        const bool more = k_src == 0 && p.c1 > 0;
-        done = done || (wrap && !more);
-        k_src = (wrap && more) ? 1 : k_src;
-        cseg = k_src ? p.c1 : p.c0;
-        ldb = (k_src ? p.lda1 : p.lda0) * 4;
-    };
-    auto store_tile = [&](int buf, const f32x4 (&ra)[AR], const f32x4 (&rb)[BR]) {
-#pragma unroll
-        for (int i = 0; i < AR; ++i)                   // 4 fp32 -> 4 bf16 (v_cvt_pk_bf16_f32), 8 bytes at k = 4 aq
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(As + buf * BM * LD + (ar0 + RPA * i) * LD) + aq * 8) =
-                __builtin_convertvector(ra[i], bf16x4);
-#pragma unroll
-        for (int j = 0; j < BR; ++j)
-            if (r0 + RPP * j < BN) *reinterpret_cast<f32x4*>(Bs + buf * BN * LD + (r0 + RPP * j) * LD + q * 4) = rb[j];
-    };
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    issue_loads(rga[0], rgb[0]);
-    issue_loads(rga[1], rgb[1]);
-    store_tile(0, rga[0], rgb[0]);
-    __syncthreads();
-    const int frag_off = (lane & 31) * LD + (lane >> 5) * 4;
-    const float* Afr = As + wm * WM * LD + frag_off;
-    const float* Bfr = Bs + wn * WN * LD + frag_off;
-    f32x4 af[2][TM], bf[2][TN];
-    auto read_frags = [&](int set, int buf, int g) {
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) af[set][mi] = *reinterpret_cast<const f32x4*>(Afr + buf * BM * LD + mi * 32 * LD + g * 8);
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) bf[set][ni] = *reinterpret_cast<const f32x4*>(Bfr + buf * BN * LD + ni * 32 * LD + g * 8);
-    };
-    auto mma = [&](int set) {
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[set][ni]),
-                                                                      __builtin_bit_cast(bf16x8, af[set][mi]), acc[mi][ni], 0, 0, 0);
-    };
-    read_frags(0, 0, 0);
-    auto kstep = [&](auto Pc) {
-        constexpr int P = decltype(Pc)::value;
-        issue_loads(rga[P], rgb[P]);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(1, P, 1);
-        mma(0);
-        store_tile(P ^ 1, rga[P ^ 1], rgb[P ^ 1]);
-        __syncthreads();
-        read_frags(0, P ^ 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1);
-    };
-    int ks = 0;
-    for (; ks + 1 < nk; ks += 2) {
-        kstep(std::integral_constant<int, 0>{});
-        kstep(std::integral_constant<int, 1>{});
-    }
-    if (ks < nk) kstep(std::integral_constant<int, 0>{});
-    igemm_epilogue<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane, smem);
-}
-
-// bf16 counterpart of the 16-k tile: 32-k stages (64 bytes of bf16 per row), the same 40 KB of LDS and three workgroups per CU.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void igemm_k32bf_kernel(const IgemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float smem_k32[];
-    const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
-    const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
-    const int nrb = rb_hi - rb_lo;
-    const int tail = min(nrb, p.tail_rb);
-    const int per1 = p.w1 + p.s1;
-    const int n1 = (nrb - tail) * per1;
-    if (loc < n1) {
-        const int r = loc / per1, j = loc - r * per1;
-        if (j < p.w1) igemm_tile_k32bf<128, 128, 2, 2>(p, rb_lo + r, j * 128, smem_k32);
-        else igemm_tile_k32bf<128, 64, 2, 2>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_k32);
-    } else {
-        const int t = loc - n1;
-        if (t >= tail * p.s2) return;
-        const int r = t / p.s2;
-        igemm_tile_k32bf<128, 64, 2, 2>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_k32);
-    }
-}
-
 // One launch runs a MIX of tile shapes (IgemmArgs::rb1/w1/s1/s2): row blocks [0, rb1) are cut into w1 tiles of
 // 128x128 followed by s1 tiles of 128x64 (N = 320 -> 2 + 1, no wasted columns); row blocks [rb1, nbm) are cut into s2
 // tiles of 128x64 only.  The launcher sizes rb1 so that the 128x128 part fills whole rounds of the 512 resident
 // tiles and the ragged last round runs as half-size tiles (L1: 5 rounds -> 4.5, L2: 3 -> 2.5).
 // XCD-aware order: the 8 XCDs are dealt blocks round-robin; each XCD gets a contiguous run of tiles (columns
 // fastest), so the column tiles that share one gathered A tile hit the same L2.
-template <int ABL, bool BF>
+template <int ABL>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // XCD x = blockIdx % 8 owns the contiguous row blocks [x*nbm/8, (x+1)*nbm/8); the last `tail` of them are cut
@@ -835,23 +685,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     if (loc < n1) {
         const int r = loc / per1, j = loc - r * per1;
         if (j < p.w1)
-            igemm_tile<128, 128, 2, 2, ABL, 2, BF>(p, rb_lo + r, j * 128, smem);
+            igemm_tile<128, 128, 2, 2, ABL, 2>(p, rb_lo + r, j * 128, smem);
         else
-            igemm_tile<128, 64, 2, 2, ABL, 2, BF>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem);
+            igemm_tile<128, 64, 2, 2, ABL, 2>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem);
     } else {
         const int t = loc - n1;
         if (t >= tail * p.s2) return;                     // padding block of the 8 x max-chunk grid
         const int r = t / p.s2;
-        igemm_tile<128, 64, 2, 2, ABL, 2, BF>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem);
+        igemm_tile<128, 64, 2, 2, ABL, 2>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem);
     }
 }
 
-template <int ABL, bool BF = false>
+template <int ABL>
 static void launch_igemm(const IgemmArgs& a, int ntiles, const char* cls, hipStream_t s) {
     static bool configured = false;
     constexpr size_t smem = (size_t)2 * (128 + 128) * LDS_LD * sizeof(float) + 9 * 128 * sizeof(unsigned);   // tiles + gather table
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<ABL, BF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<ABL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         configured = true;
     }
@@ -866,7 +716,7 @@ static void launch_igemm(const IgemmArgs& a, int ntiles, const char* cls, hipStr
                  std::to_string(a.rb1) + " w" + std::to_string(a.w1) + " s" + std::to_string(a.s1);
     ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
                  4.0 * a.batch * (rows_in * (a.c0 + a.c1) + (double)a.N * K + (double)a.M * (a.geglu ? a.N / 2 : a.N)), s);
-    hipLaunchKernelGGL((igemm_kernel<ABL, BF>), grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL((igemm_kernel<ABL>), grid, dim3(256), smem, s, a);
 }
 
 void igemm(const IgemmArgs& a_in, hipStream_t s) {
@@ -880,21 +730,25 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
     // ---- tile schedule ----------------------------------------------------------------------------------
     static const int abl = [] { const char* e = std::getenv("E2V_IGEMM_ABLATE"); return e ? std::atoi(e) : 0; }();
     static const int sched = [] { const char* e = std::getenv("E2V_IGEMM_SCHED"); return e ? std::atoi(e) : 1; }();   // 0: no half-size tails
-    a.nbm_per = (a.M + 127) / 128;
+    // bf16-activation launches with enough row blocks run 256-row tiles (bgemm256_kernel: 8 waves, one workgroup per CU): the
+    // fill rate of a CU's LDS (~35 B/clk through L1) bounds a 128 x 128 x 64 bf16 tile at ~55 % of the matrix pipe; a 256 x 128
+    // tile moves 0.75x the bytes per flop.  The schedule below is the same with 256-row blocks and 256 resident tiles.
+    const int BMrows = (a.a_bf16 && bgemm_use_256(a)) ? 256 : 128;
+    a.bm256 = BMrows == 256 ? 1 : 0;
+    a.nbm_per = (a.M + BMrows - 1) / BMrows;
     const int nbm = a.nbm_per * a.batch;                     // batch entries are just more row blocks (dealt to the XCDs together)
     static const int k16 = [] { const char* e = std::getenv("E2V_IGEMM_K16"); return e ? std::atoi(e) : 1; }();   // 0: the 32-k tile for everything
     // The tail heuristics below size rounds of 512 tiles (2 workgroups per CU).  The 16-k tile runs 3 per CU, but sizing its
     // rounds at 768 measured worse (level-2 linears 129 -> 116 TFLOP/s, UNet step 272.9 -> 278.9 ms): the third workgroup is
     // better spent overlapping than being planned for.
-    const int slots = 512;
+    const int slots = BMrows == 256 ? 256 : 512;
     a.s2 = (a.N + 63) / 64;
     a.w1 = a.N / 128;                                        // full 128-wide column tiles
     const int rem = a.N - a.w1 * 128;
     a.s1 = rem == 0 ? 0 : (rem <= 64 ? 1 : 0);
     if (rem > 64) a.w1 += 1;                                 // 65..127 leftover columns: one more (masked) wide tile
     a.rb1 = nbm;
-    const bool use_bf16 = a.bf16 && a.w16 && a.c0 % 8 == 0 && a.c1 % 8 == 0 && a.ldw16 % 8 == 0 &&
-                          (a.c1 == 0 || a.c0 % 64 == 0 || a.taps == 1);
+    constexpr bool use_bf16 = false;
     // split-bf16 fp32 (see igemm_tile_x3): linears / Winograd GEMMs whose K is a multiple of 8 and whose weights were split
     const bool use_x3 = !use_bf16 && a.x3 && a.w3 && a.taps == 1 && !a.relu && a.c0 % 8 == 0 && a.c1 % 8 == 0 && a.ldw % 8 == 0 &&
                         abl == 0;
@@ -904,8 +758,7 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
             throw Error(E2V_ESHAPE, "bf16 GEMM: channel counts / row strides must be multiples of 8 (concat seam of a 3x3 conv: 64) and rows 16-byte aligned");
         a.ldw = a.ldw16;
     }
-    if (use_bf16) a.ldw = a.ldw16;
-    const char* cls = use_bf16 ? "igemm_bf16" : "igemm_f32";
+    const char* cls = "igemm_f32";
     if (a.geglu) {                                           // the GEGLU epilogue pairs the two 32-column halves of a wave
         a.w1 = (a.N + 127) / 128; a.s1 = 0;
     } else if (a.w1 == 0) {                                  // N <= 64
@@ -940,20 +793,6 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
     ntiles *= 8;
     if (a.a_bf16) { bgemm_launch(a, ntiles, s); return; }
     if (use_x3) { launch_igemm_x3(a, ntiles, s); return; }
-    static const int k32bf = [] { const char* e = std::getenv("E2V_IGEMM_K32BF"); return e ? std::atoi(e) : 1; }();   // 0: the 64-k tile
-    if (k32bf && use_bf16 && a.taps == 1 && abl == 0) {
-        constexpr size_t smem32 = (size_t)2 * (128 + 128) * 20 * sizeof(float);
-        static bool cfgd32 = false;
-        if (!cfgd32) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_k32bf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem32);
-            cfgd32 = true;
-        }
-        const double K = (double)(a.c0 + a.c1);
-        ProfScope ps(cls, 2.0 * a.M * a.N * K * a.batch,
-                     4.0 * a.batch * ((double)a.M * K + 0.5 * a.N * K + (double)a.M * (a.geglu ? a.N / 2 : a.N)), s);
-        hipLaunchKernelGGL(igemm_k32bf_kernel, dim3(ntiles, 1, 1), dim3(256), smem32, s, a);
-        return;
-    }
     if (k16 && !use_bf16 && a.taps == 1 && abl == 0) {
         constexpr size_t smem16 = (size_t)2 * (128 + 128) * 20 * sizeof(float);   // 40 KB (epilogue staging: 4 x 32 x 68 floats = 34 KB)
         static bool cfgd = false;
@@ -971,7 +810,6 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
         hipLaunchKernelGGL(igemm_k16_kernel, dim3(ntiles, 1, 1), dim3(256), smem16, s, a);
         return;
     }
-    if (use_bf16 && abl == 0) { launch_igemm<0, true>(a, ntiles, cls, s); return; }
     if (abl == 1) launch_igemm<1>(a, ntiles, cls, s);
     else if (abl == 2) launch_igemm<2>(a, ntiles, cls, s);
     else launch_igemm<0>(a, ntiles, cls, s);

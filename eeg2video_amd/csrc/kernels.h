@@ -39,8 +39,7 @@ struct IgemmArgs {
     int geglu = 0;                 // W rows packed [32 value | 32 gate] per 64: out[m][n/2] = v * gelu(g)
     int batch = 1;                 // blockIdx.z; strides in floats
     long long sa0 = 0, sw = 0, sout = 0;
-    int bf16 = 0;                  // 1: multiply in bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate); needs w16
-    const void* w16 = nullptr;     // the same packed weights rounded to bf16
+    const void* w16 = nullptr;     // the same packed weights rounded to bf16 (a_bf16 mode)
     int x3 = 0;                    // 1: fp32 products from three bf16 pieces per operand on the bf16 MFMA (igemm_tile_x3); needs w3
     const void* w3 = nullptr;      // three bf16 planes of w ([N][K] each, w3_plane elements apart; batch entries sw apart)
     long long w3_plane = 0;
@@ -48,11 +47,13 @@ struct IgemmArgs {
     // are w16, the product is v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  out is bf16 unless out_f32; resid is bf16 iff
     // resid_bf16 (it is an activation) -- bias and rowbias stay fp32.
     int a_bf16 = 0, out_f32 = 0, resid_bf16 = 0;
+    int bm256 = 0;                 // filled by the launcher: 256-row tiles (bgemm256_kernel)
     int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, nbm_per = 0, tail_rb = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
 };
 void igemm(const IgemmArgs& a, hipStream_t s);
 void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s);
-bool bgemm_all_n64(const IgemmArgs& a);                                  // schedule hint: cut this launch into 128 x 64 tiles only      // bgemm.hip: the a_bf16 kernels (schedule already in `a`)
+bool bgemm_all_n64(const IgemmArgs& a);
+bool bgemm_use_256(const IgemmArgs& a);                                  // schedule hint: 256-row tiles pay for this launch                                  // schedule hint: cut this launch into 128 x 64 tiles only      // bgemm.hip: the a_bf16 kernels (schedule already in `a`)
 
 // weight re-layout helpers (one-off, at finalize)
 // [O][I][3][3] -> [O][ceil(I/bke)][9][bke] (bke = 32 for the fp32 kernel, 64 for the bf16 one); row length below
@@ -123,7 +124,6 @@ struct AttnArgs {
     int mode = 0;      // 0: sparse-causal self-attention, keys = [frame 0 ; frame max(f-1,0)] (attention.py:292-301)
                        // 1: keys shared by all frames of a sample (cross-attention to the 77 cond tokens)
     float scale = 1.f;
-    int bf16 = 0;      // 1: bf16 MFMA for QK^T and PV (fp32 softmax / accumulate)
     int x3 = 0;        // 1: fp32-equivalent QK^T and PV from exactly split bf16 pieces (six MFMAs per product, f32x3 mode)
     int io_bf16 = 0;   // 1: q / k / v / o are bf16 rows (strides in elements, multiples of 8); implies the bf16 MFMA
 };

@@ -157,6 +157,59 @@ void e2v_ctx::free_part(int part) {
     owned_part[part].clear();
 }
 
+bool e2v_ctx::conv_has_wino(const ConvW& w, int m) const {
+    if (!w.stride1 || conv_algo == 1) return false;
+    const int cmin = std::min(w.cin, w.cout);
+    if (m == 2) return conv_algo == 2 || (conv_algo == 0 && cmin >= wino_min_c);
+    return conv_algo == 3 || (conv_algo == 0 && wino_f4 && cmin >= wino4_min_c);
+}
+
+// First use of a layout: allocate it under the owning finalize() group (freed when that part is finalized again) and derive
+// it from the torch-layout weight on the calling stream -- ordered before the launch that asked for it.
+void e2v_ctx::conv_form(const ConvW& w, ConvForm f, hipStream_t s) {
+    const int saved = alloc_part;
+    struct Restore { e2v_ctx* c; int v; ~Restore() { c->alloc_part = v; } } restore{this, saved};
+    alloc_part = w.part;
+    auto split3 = [&](const float* u, size_t n) -> const void* {
+        float* d = dev_alloc((3 * n + 1) / 2);
+        split_bf16x3(u, d, n, n, s);
+        return d;
+    };
+    switch (f) {
+        case FORM_DIRECT32:
+            if (!w.w) {
+                float* d = dev_alloc((size_t)w.cout * w.ldw);
+                pack_conv3x3(w.raw, d, w.cout, w.cin, 32, s);
+                w.w = d;
+            }
+            break;
+        case FORM_BF16:
+            if (!w.w16) {
+                const size_t n = (size_t)w.cout * w.ldw16;
+                Act tmp(pool, (int64_t)((n + 1023) / 1024), 1024);            // fp32 staging of the 64-channel-chunk layout
+                pack_conv3x3(w.raw, tmp.p, w.cout, w.cin, 64, s);
+                float* d16 = dev_alloc((n + 1) / 2);
+                to_bf16(tmp.p, d16, n, s);
+                w.w16 = d16;
+            }
+            break;
+        case FORM_WINO2:
+        case FORM_WINO4: {
+            const int m = f == FORM_WINO4 ? 4 : 2;
+            const size_t n = (size_t)(m + 2) * (m + 2) * w.cout * w.cin;
+            const float*& u = m == 4 ? w.wino4 : w.wino;
+            const void*& u3 = m == 4 ? w.wino4_x3 : w.wino_x3;
+            if (!u) {
+                float* d = dev_alloc(n);
+                wino_pack_weights(w.raw, d, w.cout, w.cin, m, s);
+                u = d;
+            }
+            if (x3_compute && !u3) u3 = split3(u, n);
+            break;
+        }
+    }
+}
+
 void e2v_ctx::enter_stream(hipStream_t s) {
     if (has_last_stream && s != last_stream) {
         if (!stream_ev) E2V_HIP(hipEventCreateWithFlags(&stream_ev, hipEventDisableTiming));
@@ -215,41 +268,16 @@ struct Packer {
         const WTensor& w = t(n + ".weight");
         return mk_lin(w.d, bias ? t(n + ".bias").d : nullptr, (int)w.shape[1], (int)w.shape[0]);
     }
-    // [O][I][3][3] -> [O][chunk][tap][32] (+ a bf16 copy in chunks of 64) (+ Winograd-domain weights for stride-1 convs)
+    // 3x3 conv: the torch-layout weight stays; kernel layouts are built on first use (e2v_ctx::conv_form)
     ConvW conv3(const std::string& n, bool stride1 = true) {
         const WTensor& w = t(n + ".weight");
-        const int co = (int)w.shape[0], ci = (int)w.shape[1];
-        const int cp = (ci + 3) / 4 * 4;
-        const int ld32 = conv3x3_packed_ld(ci, 32), ld64 = conv3x3_packed_ld(ci, 64);
-        float* d = c->dev_alloc((size_t)co * ld32);
-        pack_conv3x3(w.d, d, co, ci, 32, s);
-        float* tmp = nullptr;
-        E2V_HIP(hipMalloc((void**)&tmp, (size_t)co * ld64 * sizeof(float)));
-        pack_conv3x3(w.d, tmp, co, ci, 64, s);
-        float* d16 = c->dev_alloc(((size_t)co * ld64 + 1) / 2);
-        to_bf16(tmp, d16, (size_t)co * ld64, s);
-        E2V_HIP(hipStreamSynchronize(s));
-        (void)hipFree(tmp);
-        const float* wino = nullptr;
-        const float* wino4 = nullptr;
-        const void* wino_x3 = nullptr; const void* wino4_x3 = nullptr;
-        if (stride1 && ci % 4 == 0 && co % 4 == 0 && c->conv_algo != 1) {
-            const int cmin = std::min(ci, co);
-            if (c->conv_algo == 2 || (c->conv_algo == 0 && cmin >= c->wino_min_c)) {
-                float* u = c->dev_alloc((size_t)16 * co * ci);
-                wino_pack_weights(w.d, u, co, ci, 2, s);
-                wino = u;
-                wino_x3 = split3(u, (size_t)16 * co * ci);
-            }
-            if (c->conv_algo == 3 || (c->conv_algo == 0 && c->wino_f4 && cmin >= c->wino4_min_c)) {
-                float* u4 = c->dev_alloc((size_t)36 * co * ci);
-                wino_pack_weights(w.d, u4, co, ci, 4, s);
-                wino4 = u4;
-                wino4_x3 = split3(u4, (size_t)36 * co * ci);
-            }
-        }
-        ConvW cw{d, t(n + ".bias").d, ci, cp, co, d16, ld32, ld64, wino, wino4, wino_x3, wino4_x3};
-        cw.cin_pad16 = (ci + 7) / 8 * 8;
+        ConvW cw;
+        cw.raw = w.d; cw.b = t(n + ".bias").d;
+        cw.cout = (int)w.shape[0]; cw.cin = (int)w.shape[1];
+        cw.cin_pad = (cw.cin + 3) / 4 * 4; cw.cin_pad16 = (cw.cin + 7) / 8 * 8;
+        cw.ldw = conv3x3_packed_ld(cw.cin, 32); cw.ldw16 = conv3x3_packed_ld(cw.cin, 64);
+        cw.stride1 = stride1 && cw.cin % 4 == 0 && cw.cout % 4 == 0;
+        cw.part = c->alloc_part >= 0 ? c->alloc_part : 0;
         return cw;
     }
     LinW fuse_rows(const std::vector<std::string>& names, bool bias) {   // stack Linear weights along `out`
@@ -433,7 +461,8 @@ void e2v_ctx::finalize(int which) {
                            k.find(".query.") != std::string::npos || k.find(".key.") != std::string::npos ||
                            k.find(".value.") != std::string::npos;
         const bool keep_q = k.find(".attn2.to_q.") != std::string::npos;
-        if ((conv3 || fused) && !keep_q) drop(k);
+        (void)conv3;                            // 3x3 conv weights stay: their kernel layouts are derived from them on first use
+        if (fused && !keep_q) drop(k);
     }
     if (which & 1) unet_ready = true;
     if (which & 2) vae_ready = true;
@@ -515,11 +544,11 @@ struct Runner {
     // transforms would dominate and rounding the transformed inputs costs accuracy.
     int winograd(const ConvW& w, int stride, int pad, int Hi, int Wi, int Ho, int Wo) const {
         if (c->conv_algo == 1 || c->bf16_compute || stride != 1 || pad != 1 || Hi != Ho || Wi != Wo) return 0;
-        if (c->conv_algo == 2) return w.wino ? 2 : 0;
-        if (c->conv_algo == 3) return w.wino4 ? 4 : 0;
+        if (c->conv_algo == 2) return c->conv_has_wino(w, 2) ? 2 : 0;
+        if (c->conv_algo == 3) return c->conv_has_wino(w, 4) ? 4 : 0;
         const double padded = (double)((Ho + 3) / 4 * 4) * ((Wo + 3) / 4 * 4);
-        if (w.wino4 && padded <= c->wino_f4_pad * Ho * Wo) return 4;
-        return w.wino ? 2 : 0;
+        if (c->conv_has_wino(w, 4) && padded <= c->wino_f4_pad * Ho * Wo) return 4;
+        return c->conv_has_wino(w, 2) ? 2 : 0;
     }
 
     Act ln(const NormW& w, const Act& x) {
@@ -571,6 +600,7 @@ struct Runner {
                 a.ups_w = (float)geo.W / (float)Wi;
             }
             if (gn_P > 0) { a.gn_scsh = c->gn_scale; a.gn_P = gn_P; a.gn_silu = 1; }
+            c->conv_form(w, wm == 4 ? e2v_ctx::FORM_WINO4 : e2v_ctx::FORM_WINO2, s);
             a.U = wm == 4 ? w.wino4 : w.wino; a.N = w.cout; a.out = out.p; a.ldc = w.cout; a.bias = w.b;
             if (c->x3_compute) a.U3 = wm == 4 ? w.wino4_x3 : w.wino_x3;
             a.rowbias = rowbias; a.rb_ld = rb_ld; a.rows_per_sample = rows_per_sample; a.resid = resid; a.ldr = w.cout;
@@ -584,6 +614,7 @@ struct Runner {
         IgemmArgs g;
         g.a0 = x0; g.c0 = c0; g.lda0 = c0; g.a1 = x1; g.c1 = c1; g.lda1 = c1;
         E2V_REQUIRE(c1 == 0 || c0 % 32 == 0, E2V_ESHAPE, "conv: the concat seam must be a multiple of 32 channels");
+        c->conv_form(w, bf() ? e2v_ctx::FORM_BF16 : e2v_ctx::FORM_DIRECT32, s);
         g.w = w.w; g.ldw = w.ldw; g.ldw16 = w.ldw16; g.out = out.p; g.ldc = w.cout; g.bias = w.b;
         g.rowbias = rowbias; g.rb_ld = rb_ld; g.rows_per_sample = rows_per_sample;
         g.resid = resid; g.ldr = w.cout;

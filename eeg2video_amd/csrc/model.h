@@ -16,11 +16,23 @@ struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
 struct LinW { const float* w = nullptr; const float* b = nullptr; int in = 0, out = 0; const void* w16 = nullptr;
               const void* w3 = nullptr;         // three bf16 planes of w (out*in elements apart) for the f32x3 mode
               int in16 = 0; };                  // row length of w16: `in` rounded up to 8 (zero columns; 16-byte DMA pieces)
-struct ConvW { const float* w = nullptr; const float* b = nullptr; int cin = 0, cin_pad = 0, cout = 0; const void* w16 = nullptr; int ldw = 0, ldw16 = 0;
-               const float* wino = nullptr;      // [16][cout][cin] Winograd F(2x2,3x3)-domain weights (stride-1 convs wide enough to profit)
-               const float* wino4 = nullptr;     // [36][cout][cin] F(4x4,3x3)-domain weights (only when that form is enabled)
-               const void* wino_x3 = nullptr; const void* wino4_x3 = nullptr;     // their three-plane bf16 splits (f32x3 mode)
-               int cin_pad16 = 0; };             // channels of the bf16 input: cin rounded up to 8
+// A 3x3 conv keeps its torch-layout weight and builds the kernel layouts ON FIRST USE (e2v_ctx::conv_form): which of them a
+// layer ever needs depends on the arithmetic mode and on the map size it is called with -- fp32 direct-packed, F(2x2) / F(4x4)
+// Winograd-domain (x2.25 / x4 the raw size), bf16 direct-packed -- and building all of them cost 18 GiB where one mode uses 4-9.
+struct ConvW {
+    const float* raw = nullptr;                  // [O][I][3][3] fp32, as uploaded
+    const float* b = nullptr;
+    int cin = 0, cin_pad = 0, cout = 0;
+    int ldw = 0, ldw16 = 0;                      // row lengths of the fp32 (32-channel chunks) / bf16 (64-channel chunks) packed forms
+    int cin_pad16 = 0;                           // channels of the bf16 input: cin rounded up to 8
+    bool stride1 = true;                         // a Winograd form exists (stride-1 conv, channel counts multiples of 4)
+    int part = 0;                                // 0 UNet, 1 VAE: which finalize() group owns the lazily built forms
+    mutable const float* w = nullptr;            // [O][chunk32][tap][32]
+    mutable const void* w16 = nullptr;           // [O][chunk64][tap][64] bf16
+    mutable const float* wino = nullptr;         // [16][O][I]
+    mutable const float* wino4 = nullptr;        // [36][O][I]
+    mutable const void* wino_x3 = nullptr; mutable const void* wino4_x3 = nullptr;   // three-plane bf16 splits (f32x3 mode)
+};
 
 struct ResW {
     NormW n1, n2;
@@ -118,6 +130,9 @@ struct e2v_ctx {
     void free_part(int part);
 
     float* dev_alloc(size_t floats);
+    enum ConvForm { FORM_DIRECT32, FORM_BF16, FORM_WINO2, FORM_WINO4 };
+    void conv_form(const e2v::ConvW& w, ConvForm f, hipStream_t s);     // build the layout if this is its first use
+    bool conv_has_wino(const e2v::ConvW& w, int m) const;               // would the policy allow the F(m x m) form for this layer?
     void expected_keys();
     void finalize(int which);
     // graphs (channel-last in/out); see model.cpp
