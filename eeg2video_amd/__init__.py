@@ -5,7 +5,10 @@ Layout (only what the path needs):
 * ``csrc/``      hand-written gfx950 kernels + the C-ABI library ``lib/libeeg2video_hip.so``
 * ``_lib`` / ``engine``   ctypes binding and the one-ctx-per-GPU wrapper
 * ``unet`` / ``vae`` / ``scheduler`` / ``pipeline``   mirrors of the reference's interfaces
-  (``UNet3DConditionModel.forward``, ``AutoencoderKL``, ``DDIMScheduler``, ``TuneAVideoPipeline.__call__``)
+  (``UNet3DConditionModel.forward`` / ``.from_pretrained``, ``AutoencoderKL``, the six scheduler types the pipeline's
+  constructor accepts, ``TuneAVideoPipeline.__call__`` / ``.from_pretrained``)
+* ``semantic`` / ``util``   the steps either side of the path: Semantic Predictor, DDIM inversion, ``save_videos_grid``
+* ``host_models``   GLMNet / Seq2Seq as plain host-side torch modules (BASELINE configs[4] driver: ``examples/run_sweep.py``)
 * ``weights``    state-dict key scheme + counter-RNG synthetic weights
 * ``dist``       sharding of clips over ranks and the all-gather of decoded frames
 
@@ -14,7 +17,8 @@ The compute path has no CPU fallback: without the built library or without a GPU
 from .weights import TINY_SEMANTIC, TINY_UNET, TINY_VAE, SemanticConfig, UNetConfig, VAEConfig  # noqa: F401
 
 __all__ = ["UNetConfig", "VAEConfig", "TINY_UNET", "TINY_VAE", "Engine", "UNet3DConditionModel", "AutoencoderKL",
-           "DDIMScheduler", "PNDMScheduler", "TuneAVideoPipeline", "build_pipeline"]
+           "DDIMScheduler", "PNDMScheduler", "LMSDiscreteScheduler", "EulerDiscreteScheduler", "EulerAncestralDiscreteScheduler",
+           "DPMSolverMultistepScheduler", "TuneAVideoPipeline", "build_pipeline", "save_videos_grid"]
 
 
 def __getattr__(name):          # lazy: importing the package must not need torch.cuda or the .so
@@ -27,12 +31,13 @@ def __getattr__(name):          # lazy: importing the package must not need torc
     if name == "AutoencoderKL":
         from .vae import AutoencoderKL
         return AutoencoderKL
-    if name == "DDIMScheduler":
-        from .scheduler import DDIMScheduler
-        return DDIMScheduler
-    if name == "PNDMScheduler":
-        from .scheduler import PNDMScheduler
-        return PNDMScheduler
+    if name in ("DDIMScheduler", "PNDMScheduler", "LMSDiscreteScheduler", "EulerDiscreteScheduler",
+                "EulerAncestralDiscreteScheduler", "DPMSolverMultistepScheduler"):
+        from . import scheduler
+        return getattr(scheduler, name)
+    if name == "save_videos_grid":
+        from .util import save_videos_grid
+        return save_videos_grid
     if name in ("TuneAVideoPipeline", "build_pipeline"):
         from . import pipeline
         return getattr(pipeline, name)

@@ -1,5 +1,6 @@
 // extern "C" surface of libeeg2video_hip.so (include/eeg2video_hip.h, include/eeg2video_hip_ops.h).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -231,6 +232,23 @@ e2v_status e2v_semantic_predict(e2v_ctx* c, const float* eeg, int B, float* out,
         E2V_REQUIRE(eeg && out && B > 0, E2V_EINVAL, "bad arguments");
         hipStream_t s = S(c, stream);
         const bool b16 = c->bf16_compute;                        // bf16-activation mode: bf16 rows between the layers, fp32 result
+        static const bool gemv_on = [] { const char* e = std::getenv("E2V_SEM_GEMV"); return !e || std::atoi(e) != 0; }();
+        if (gemv_on && gemv_rows_supported(B, c->cfg.sem_hidden, b16) && gemv_rows_supported(B, c->sem_in_pad, b16)) {
+            // the reference's batch sizes (1 .. a few EEG segments): every layer is a stream over its weight matrix
+            Act x(c->pool, B, c->sem_in_pad);
+            pad_cols(eeg, c->cfg.sem_in_features, x.p, c->sem_in_pad, B, s);
+            for (size_t i = 0; i < c->sem.size(); ++i) {
+                const LinW& w = c->sem[i];
+                const bool last = i + 1 == c->sem.size();
+                Act y;
+                if (!last) y = Act(c->pool, B, w.out);
+                gemv_rows(x.p, x.C, b16 ? w.w16 : (const void*)w.w, b16 ? w.in16 : w.in, b16 ? 1 : 0, w.b, last ? out : y.p, w.out, B, w.out,
+                          b16 ? w.in16 : w.in, last ? 0 : 1, s);
+                if (!last) x = std::move(y);
+            }
+            E2V_HIP(hipGetLastError());
+            return;
+        }
         Act x(c->pool, B, c->sem_in_pad, b16);
         pad_cols(eeg, c->cfg.sem_in_features, x.p, c->sem_in_pad, B, s, b16 ? 1 : 0);
         for (size_t i = 0; i < c->sem.size(); ++i) {              // Linear -> ReLU ... -> Linear (train_semantic_predictor.py:14-28)

@@ -281,6 +281,11 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
     constexpr int VROW = T * 64 + 16;           // bytes per V row (the tr reads of the last tile may run past D: they stay inside the row)
     constexpr int KBYTES = 32 * KROW, VBYTES = 32 * VROW;
     constexpr int STAGE = (KBYTES + VBYTES + 15) / 16 * 16;
+    // Row sums on the matrix pipe: when D is not a multiple of 32 the last 32-row tile of O^T has spare rows, and a value
+    // column of ONES at index D makes row D of O^T the softmax denominator (rescaled with the accumulator, summed over the
+    // same bf16-rounded probabilities as the numerator) -- 16 vector adds per key tile less in a loop that is VALU-bound.
+    constexpr bool SUMV = (D % 32) != 0;
+    constexpr int LROW = D % 32, LREG = 4 * (LROW / 8) + (LROW & 3), LHALF = (LROW >> 2) & 1;
     constexpr int C8 = D / 8;                   // 16-byte pieces per row
     constexpr int NP = 32 * C8;
     constexpr int LPT = (NP + 255) / 256;
@@ -312,6 +317,11 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
 
     for (int i = tid * 16; i < 2 * STAGE; i += 256 * 16)                // pad columns are never rewritten: keep them finite
         *reinterpret_cast<f32x4*>(smem_h + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (SUMV) {
+        __syncthreads();
+        if (tid < 64)                                                       // value column D of every key row, both stages: 1.0
+            *reinterpret_cast<__bf16*>(smem_h + (tid >> 5) * STAGE + KBYTES + (tid & 31) * VROW + D * 2) = (__bf16)1.0f;
+    }
 
     abf16x8 qf[KS];
     {
@@ -348,9 +358,7 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
         ld_off[e] = idx < NP ? (unsigned)(row * p.ldkv + c8 * 8) * 2u : OOB;
     }
     f32x4 kreg[LPT], vreg[LPT];
-    auto load_tile = [&](int tt) {
-        const int seg = tt / tps;
-        const int key0 = (tt - seg * tps) * 32;
+    auto load_tile = [&](const int seg, const int key0) {        // position of the tile, kept incrementally by the caller
         const size_t first = (kvbase[seg] + key0) * p.ldkv + head * D;
         const __amdgpu_buffer_rsrc_t rk = rsrc_of(K + first), rv = rsrc_of(V + first);
         const int left = p.Nk - key0;                           // keys this tile really has (uniform)
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float m_i = -INFINITY, l_i = 0.f;
 
-    load_tile(0);
+    load_tile(0, 0);
     store_tile(0);
     __syncthreads();
 
@@ -391,11 +399,13 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
     const int tr_off = (4 * h + (ti >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (ti & 3)) * 2;
     typedef __attribute__((address_space(3))) abf16x4* lds_b4;
 
+    int key0 = 0;
     for (int tt = 0; tt < ntiles; ++tt) {
         const int buf = tt & 1;
-        if (tt + 1 < ntiles) load_tile(tt + 1);
-        const int seg_c = tt / tps;
-        const int key0 = (tt - seg_c * tps) * 32;
+        if (tt == tps) key0 = 0;                                  // second key segment
+        if (tt + 1 < ntiles) {
+            if (tt + 1 == tps) load_tile(1, 0); else load_tile(tt + 1 > tps ? 1 : 0, key0 + 32);
+        }
         if (active) {
             const char* Kl = smem_h + buf * STAGE;
             const char* Vl = Kl + KBYTES;
@@ -424,14 +434,14 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 st[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc, -m_new));
-                ps += st[r];
+                if constexpr (!SUMV) ps += st[r];
             }
             float alpha = 1.0f;
             if (moved) {
                 alpha = __builtin_amdgcn_exp2f(m_i - m_new);
-                l_i *= alpha;
+                if constexpr (!SUMV) l_i *= alpha;
             }
-            l_i += ps;
+            if constexpr (!SUMV) l_i += ps;
             m_i = m_new;
             abf16x8 pf[2];                       // P^T fragments: registers 8s..8s+7 are k-step s as they stand
 #pragma unroll
@@ -456,9 +466,12 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
         }
         if (tt + 1 < ntiles) store_tile(buf ^ 1);
         __syncthreads();
+        key0 += 32;
     }
 
-    const float l_tot = l_i + __shfl_xor(l_i, 32);
+    float l_tot;
+    if constexpr (SUMV) l_tot = __shfl(acc[T - 1][LREG], j + 32 * LHALF);     // row D of O^T: lane (query j, half LHALF)
+    else l_tot = l_i + __shfl_xor(l_i, 32);
     if (active && q0 + j < p.Nq) {
         const float inv = 1.0f / l_tot;
         __bf16* op = reinterpret_cast<__bf16*>(p.o) + ((size_t)sf * p.Nq + q0 + j) * p.ldo + head * D;

@@ -167,6 +167,12 @@ void dana_noise(const float* x0, const float* eps_div, const float* eps_same, co
 void frames_to_u8(const float* in, unsigned char* out, long long count, hipStream_t s);
 void pad_cols(const float* in, int cols, float* out, int cols_pad, long long rows, hipStream_t s, int out_bf16 = 0);   // fp32 in; out fp32 or bf16
 
+// weight-streaming GEMV (gemv.hip): out[b][n] = act(x[b] . W[n] + bias[n]) for B <= 16 rows, x / out fp32 rows, W [N][ldw] fp32 or
+// bf16 (rows zero-padded to ldw); the Semantic Predictor at the reference's batch sizes
+bool gemv_rows_supported(int B, int K, int w_bf16);
+void gemv_rows(const float* x, int ldx, const void* w, int ldw, int w_bf16, const float* bias, float* out, int ldo, int B, int N, int K,
+               int relu, hipStream_t s);
+
 // strided row copy between storage types (fp32 <-> bf16), zero-filling columns cols .. cols_out-1 of the output
 void cvt_rows(const void* in, int ld_in, int in_bf16, void* out, int ld_out, int out_bf16, long long rows, int cols, int cols_out,
               hipStream_t s);
