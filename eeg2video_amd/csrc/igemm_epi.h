@@ -216,7 +216,7 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
             for (int i = 0; i < 32 / RPI; ++i) {
                 const int row = lane / LPR + RPI * i;
                 const int m = bm * BM + wm * WM + mi * 32 + row;
-                if (m >= p.M || n >= p.N) continue;            // N % 8 == 0: the lane's eight columns are in or out together
+                if (m >= p.M || n >= p.N || (p.ablate & 1)) continue;   // N % 8 == 0: the lane's eight columns are in or out together
                 f32x4 y0 = *reinterpret_cast<const f32x4*>(st + row * SLD + col);
                 f32x4 y1 = *reinterpret_cast<const f32x4*>(st + row * SLD + col + 4);
                 if (p.alpha != 1.0f) { y0 *= p.alpha; y1 *= p.alpha; }

@@ -48,6 +48,7 @@ struct IgemmArgs {
     // resid_bf16 (it is an activation) -- bias and rowbias stay fp32.
     int a_bf16 = 0, out_f32 = 0, resid_bf16 = 0;
     int bm256 = 0;                 // filled by the launcher: 256-row tiles (bgemm256_kernel)
+    int ablate = 0;                // timing experiments only (E2V_BGEMM_ABLATE): 1 = no output stores, 2 = A loads read zeros, 3 = both
     int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, nbm_per = 0, tail_rb = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
 };
 void igemm(const IgemmArgs& a, hipStream_t s);
