@@ -81,6 +81,7 @@ SIGNATURES = {
     "e2v_op_temporal_attention": (_i, [_ctx, _p, _p, _i, _i, _i, _i, _i, _f, _stream]),
     "e2v_op_to_channels_last": (_i, [_ctx, _p, _p, _i, _i, _i, _i, _stream]),
     "e2v_op_from_channels_last": (_i, [_ctx, _p, _i, _p, _i, _i, _i, _stream]),
+    "e2v_op_set_knob": (_i, [C.c_char_p, _i]),
 }
 
 _lib = None

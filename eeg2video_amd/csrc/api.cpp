@@ -829,4 +829,9 @@ e2v_status e2v_op_from_channels_last(e2v_ctx* c, const float* in, int ld, float*
     return guarded(c, [&] { cl_to_ncfhw(in, ld, out, n, C, FHW, 1.f, 0.f, 0, 0.f, 0.f, S(c, stream)); E2V_HIP(hipGetLastError()); });
 }
 
+e2v_status e2v_op_set_knob(const char* name, int value) {
+    if (!name) return E2V_EINVAL;
+    return set_knob(name, value) ? E2V_OK : E2V_EINVAL;
+}
+
 }  // extern "C"

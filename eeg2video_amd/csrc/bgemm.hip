@@ -18,7 +18,37 @@
 #include <cstdlib>
 #include <string>
 
+#include <map>
+#include <mutex>
+
 namespace e2v {
+
+static std::mutex& knob_mutex() { static std::mutex m; return m; }
+static std::map<std::string, int>& knob_table() { static std::map<std::string, int> t; return t; }
+int* knob(const char* name, int dflt) {
+    std::lock_guard<std::mutex> lk(knob_mutex());
+    auto& t = knob_table();
+    auto it = t.find(name);
+    if (it == t.end()) {
+        const char* e = std::getenv(name);
+        it = t.emplace(name, e ? std::atoi(e) : dflt).first;
+    }
+    return &it->second;                          // std::map nodes do not move
+}
+bool set_knob(const char* name, int value) {
+    std::lock_guard<std::mutex> lk(knob_mutex());
+    auto& t = knob_table();
+    auto it = t.find(name);
+    if (it == t.end()) {
+        static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_256", "E2V_BGEMM_LIN", "E2V_BGEMM_ABLATE"};
+        bool ok = false;
+        for (const char* k : known) ok = ok || std::string(k) == name;
+        if (!ok) return false;
+        it = t.emplace(name, value).first;
+    }
+    it->second = value;
+    return true;
+}
 
 // LIN: taps == 1 (linear / 1x1 conv).  Rows are their own pixels, so there is no gather table, a lane's source offsets never
 // change, and a k-step is: eight LDS-DMA instructions whose k position rides in the scalar offset, one scalar add -- the
@@ -254,144 +284,20 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
     }
 }
 
-// ---- taps == 1, four-stage ring (E2V_BGEMM_RING) --------------------------------------------------------------------------
-// The two-stage tile above hands its loads one k-step of cover; a linear layer streams its activations straight from HBM
-// (K = 320: five stages in all), and PMC counters put the waves of such a launch 56 % of their life in s_waitcnt / s_barrier.
-// Here a stage is 32 channels (64-byte tile rows: a DMA piece is 16 rows, chunk swizzle (row >> 2) & 3), four stages ring
-// through 64 KB, and the loads of stage j + 3 are issued as soon as stage j - 1 has been consumed: three stages are always in
-// flight per workgroup, the consumer waits with a COUNTED vmcnt (the two youngest stages stay outstanding) and a raw
-// s_barrier -- no drain in the loop.
-template <int BM, int BN, int WGM, int WGN>
-__device__ __forceinline__ void bgemm_ring_tile(const IgemmArgs& p, const int rbg, const int n0, char* smem) {
-    constexpr int BKE = 32, ROWB = 64, NS = 4, PF = 3;
-    constexpr int NW = WGM * WGN;
-    constexpr int WM = BM / WGM, WN = BN / WGN;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_BYTES = BM * ROWB, STAGE = 128 * ROWB * 2;
-    constexpr int APW = BM / 16 / NW, BPW = BN / 16 / NW;     // 1-KB DMA pieces (16 rows) per wave and stage
-    constexpr int PIECES = APW + BPW;
-    static_assert(APW >= 1 && BPW >= 1, "tile too small for the DMA split");
-    const int z = p.batch > 1 ? rbg / p.nbm_per : 0;
-    const int bm = rbg - z * p.nbm_per;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const __bf16* __restrict__ a0 = reinterpret_cast<const __bf16*>(p.a0) + (size_t)z * p.sa0;
-    const __bf16* __restrict__ a1 = reinterpret_cast<const __bf16*>(p.a1);
-    const char* __restrict__ w = reinterpret_cast<const char*>(p.w16) + ((size_t)z * p.sw + (size_t)n0 * p.ldw) * 2;
-    const int nk = (p.c0 + BKE - 1) / BKE + (p.c1 + BKE - 1) / BKE;
-    constexpr unsigned OOB = 0x80000000u;
-    const size_t row_base = (size_t)bm * BM;
-    const __bf16* const a0b = a0 + row_base * p.lda0;
-    const __bf16* const a1b = p.c1 > 0 ? a1 + row_base * p.lda1 : a0b;
-    auto rsrc_of = [](const void* ptr) {
-        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, 0x7FFFFFF0,
-                                                 0x00020000);
-    };
-    const __amdgpu_buffer_rsrc_t rw = rsrc_of(w);
-    const int r16 = lane >> 2, pp = lane & 3;
-    unsigned a_voff0[APW], a_voff1[APW], a_kc[APW], b_off[BPW], b_kc[BPW];
-#pragma unroll
-    for (int i = 0; i < APW; ++i) {
-        const int r = 16 * (wave * APW + i) + r16;
-        a_kc[i] = (unsigned)(pp ^ ((r >> 2) & 3));
-        const bool in = bm * BM + r < p.M;
-        a_voff0[i] = in ? (unsigned)(r * p.lda0 * 2) + a_kc[i] * 16u : OOB;
-        a_voff1[i] = in ? (unsigned)(r * p.lda1 * 2) + a_kc[i] * 16u : OOB;
-    }
-#pragma unroll
-    for (int j = 0; j < BPW; ++j) {
-        const int r = 16 * (wave * BPW + j) + r16;
-        b_kc[j] = (unsigned)(pp ^ ((r >> 2) & 3));
-        b_off[j] = (n0 + r < p.N) ? (unsigned)(r * p.ldw * 2) + b_kc[j] * 16u : OOB;
-    }
-    int k_src = 0, k_cb = 0, cseg = p.c0;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    auto issue = [&](const int buf) {                       // one stage; never called past the last one
-        char* Ab = smem + buf * STAGE;
-        char* Bb = Ab + A_BYTES;
-        const unsigned so = (unsigned)k_cb * 2u;
-        const unsigned sob = (unsigned)((k_src ? p.c0 : 0) + k_cb) * 2u;
-        const bool whole = k_cb + BKE <= cseg;
-        // the descriptor is rebuilt from a pointer forced into SGPRs: a select between two ready-made descriptors is not provably
-        // wave-uniform to hipcc, which then parks them in scratch and wraps every load in a waterfall loop (with a vmcnt(0))
-        const __amdgpu_buffer_rsrc_t rsa = rsrc_of(k_src ? a1b : a0b);
-#pragma unroll
-        for (int i = 0; i < APW; ++i) {
-            const unsigned vo = k_src ? a_voff1[i] : a_voff0[i];
-            const unsigned off = (whole || k_cb + (int)a_kc[i] * 8 < cseg) ? vo : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(Ab + (wave * APW + i) * 1024), 16, off, so, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < BPW; ++j) {
-            const unsigned off = (whole || k_cb + (int)b_kc[j] * 8 < cseg) ? b_off[j] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(Bb + (wave * BPW + j) * 1024), 16, off, sob, 0, 0);
-        }
-        k_cb += BKE;
-        if (k_cb >= cseg && k_src == 0 && p.c1 > 0) { k_src = 1; k_cb = 0; cseg = p.c1; }
-    };
+// ---- persistent workgroups ---------------------------------------------------------------------------------------------------
+// A tile of the kernels below pays, at full price and alone on its half of the CU: the workgroup launch, the table build, the
+// latency of its first stage (HBM for a linear layer), and at the end the drain of its stores before the next workgroup may
+// start.  Timing with the epilogue's stores dropped (E2V_BGEMM_ABLATE=1) puts that at 17-22 % of a 3x3 conv and 40-50 % of a
+// K = 320 linear.  Here a workgroup stays resident and walks the tile list of its XCD (the same order as the launches above,
+// slot s takes tiles s, s + slots, ...).  The LDS ring never stops: the last k-stage of tile i issues stage 0 of tile i + 1
+// (whose gather table was built while tile i was being multiplied), the epilogue of tile i stages its accumulators through the
+// stage buffer it has just consumed while that DMA is in flight, and its stores are never waited for.
+struct BgTile {
+    int rbg, n0, wide, valid;
+};
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    const int fr = lane & 31, fh = lane >> 5;
-    const int fs = (fr >> 2) & 3;
-    const unsigned foff0 = (unsigned)(((0 + fh) ^ fs) * 16), foff1 = (unsigned)(((2 + fh) ^ fs) * 16);
-    const char* Afr = smem + (wm * WM + fr) * ROWB;
-    const char* Bfr = smem + A_BYTES + (wn * WN + fr) * ROWB;
-
-    int issued = 0;
-    for (; issued < PF && issued < nk; ++issued) issue(issued);
-    for (int j = 0; j < nk; ++j) {
-        const int left = nk - j - 1;                            // stages behind this one: min(left, PF - 1) of them are in flight
-        if (left >= PF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * PIECES) : "memory");
-        else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // stage j landed for every wave; stage j - 1 is consumed
-        __builtin_amdgcn_sched_barrier(0);
-        if (issued < nk) { issue(issued & (NS - 1)); ++issued; }
-        const int bo = (j & (NS - 1)) * STAGE;
-        bf16x8 af0[TM], bf0[TN], af1[TM], bf1[TN];
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) af0[mi] = *reinterpret_cast<const bf16x8*>(Afr + bo + mi * 32 * ROWB + foff0);
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) bf0[ni] = *reinterpret_cast<const bf16x8*>(Bfr + bo + ni * 32 * ROWB + foff0);
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) af1[mi] = *reinterpret_cast<const bf16x8*>(Afr + bo + mi * 32 * ROWB + foff1);
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) bf1[ni] = *reinterpret_cast<const bf16x8*>(Bfr + bo + ni * 32 * ROWB + foff1);
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf0[ni], af0[mi], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf1[ni], af1[mi], acc[mi][ni], 0, 0, 0);
-    }
-    __syncthreads();                                            // the ring becomes the epilogue's staging area
-    if (p.out_f32) {
-        float* __restrict__ out = p.out + (size_t)z * p.sout;
-        igemm_epilogue<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane, reinterpret_cast<float*>(smem));
-    } else {
-        __bf16* __restrict__ out = reinterpret_cast<__bf16*>(p.out) + (size_t)z * p.sout;
-        bgemm_epilogue_bf16<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane, reinterpret_cast<float*>(smem));
-    }
-}
-
-__global__ __launch_bounds__(256) void bgemm_ring_kernel(const IgemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_ring[];
-    const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+__device__ __forceinline__ BgTile bgemm_decode(const IgemmArgs& p, const int x, const int loc) {
+    BgTile t{0, 0, 0, 0};
     const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
     const int nrb = rb_hi - rb_lo;
     const int tail = min(nrb, p.tail_rb);
@@ -399,14 +305,337 @@ __global__ __launch_bounds__(256) void bgemm_ring_kernel(const IgemmArgs p) {
     const int n1 = (nrb - tail) * per1;
     if (loc < n1) {
         const int r = loc / per1, j = loc - r * per1;
-        if (j < p.w1) bgemm_ring_tile<128, 128, 2, 2>(p, rb_lo + r, j * 128, smem_ring);
-        else bgemm_ring_tile<128, 64, 2, 2>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_ring);
+        t.rbg = rb_lo + r;
+        t.wide = j < p.w1;
+        t.n0 = t.wide ? j * 128 : p.w1 * 128 + (j - p.w1) * 64;
+        t.valid = 1;
     } else {
-        const int t = loc - n1;
-        if (t >= tail * p.s2) return;
-        const int r = t / p.s2;
-        bgemm_ring_tile<128, 64, 2, 2>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_ring);
+        const int q = loc - n1;
+        if (q < tail * p.s2) {
+            const int r = q / p.s2;
+            t.rbg = rb_lo + (nrb - tail) + r;
+            t.n0 = (q - r * p.s2) * 64;
+            t.valid = 1;
+        }
     }
+    return t;
+}
+
+template <int BM, int WGM, bool LIN>
+__device__ __forceinline__ void bgemm_pers_body(const IgemmArgs& p, char* smem, const int x, const int slot, const int nslots) {
+    constexpr int BKE = 64, ROWB = 128, WGN = 2;
+    constexpr int NW = WGM * WGN, NT = 64 * NW;
+    constexpr int WM = BM / WGM, TM = WM / 32;
+    constexpr int STAGE = (BM + 128) * ROWB, A_BYTES = BM * ROWB;
+    constexpr int APW = BM / 8 / NW, BPWM = 128 / 8 / NW;     // 1-KB DMA pieces per wave and stage (B: of a 128-wide tile)
+    constexpr int TABN = 9 * BM;
+    static_assert(WM == 64 && APW >= 1 && BPWM >= 2, "wave tile is 64 rows");
+    constexpr unsigned OOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    unsigned* const tabs = reinterpret_cast<unsigned*>(smem + 2 * STAGE);
+    float* const brow = reinterpret_cast<float*>(tabs + 2 * TABN);      // bias, time-embedding rows of two samples: [3][128]
+    const int steps0 = (p.c0 + BKE - 1) / BKE, steps1 = (p.c1 + BKE - 1) / BKE;
+    const int nk = p.taps * (steps0 + steps1);
+    const int hw_out = p.Ho * p.Wo, hw_in = p.Hs * p.Ws;
+    const int a_records = (p.ablate & 2) ? 0 : 0x7FFFFFF0;
+    auto rsrc_of = [](const void* ptr, const int records = 0x7FFFFFF0) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, records,
+                                                 0x00020000);
+    };
+
+    // ---- issue side: the tile whose stages are being fetched ----------------------------------------------------------------
+    // DMA geometry of a lane: piece q covers tile rows 8q .. 8q+7, lane -> (row 8q + (lane >> 3), LDS chunk lane & 7); the chunk
+    // FETCHED for LDS position c of row r is c ^ ((r >> 1) & 7) = kc0 ^ 4 (q & 1): one register and a wave-uniform bit
+    const int r8 = lane >> 3, pp = lane & 7;
+    const unsigned kc0 = (unsigned)(pp ^ (r8 >> 1));
+    auto a_row = [&](const int i) { return 8 * (wave * APW + i) + r8; };
+    auto a_kc = [&](const int i) { return kc0 ^ (unsigned)((((wave * APW + i) & 1)) << 2); };
+    const __bf16* i_a0b = nullptr;
+    const __bf16* i_a1b = nullptr;
+    const char* i_w = nullptr;
+    const unsigned* i_tab = tabs;
+    int i_bpw = BPWM;
+    unsigned a_voff0[APW], b_off[BPWM], pixn[APW];
+    auto b_kc = [&](const int j) { return kc0 ^ (unsigned)((((wave * i_bpw + j) & 1)) << 2); };
+    // LDS piece of this wave's j-th B instruction; the instructions a 64-wide tile does not need (all lanes out of window: they
+    // write zeros) are pointed at the unused upper half of the B area
+    auto b_piece = [&](const int j) { return j < i_bpw ? wave * i_bpw + j : 128 / 16 + wave * (BPWM - i_bpw) + (j - i_bpw); };
+    int k_src = 0, k_cb = 0, k_tap = 0, cseg = p.c0, ldb = p.lda0 * 2;
+    bool i_live = false;                                     // a tile is being fetched and has stages left
+
+    // gather table of tile t into table buffer `which` (3x3: all threads take part; the caller orders it against the first use
+    // with a barrier)
+    auto build_table = [&](const BgTile t, const int which) {
+        if constexpr (!LIN) {
+            const int z = p.batch > 1 ? t.rbg / p.nbm_per : 0;
+            const int bm = t.rbg - z * p.nbm_per;
+            const int img0 = p.taps == 1 ? 0 : (bm * BM) / hw_out;
+            unsigned* tab = tabs + which * TABN;
+            for (int e = tid; e < p.taps * BM; e += NT) {
+                const int tap = e / BM, row = e - tap * BM;
+                const int m = bm * BM + row;
+                unsigned pix = ~0u;
+                if (m < p.M) {
+                    if (p.taps == 1) {
+                        pix = (unsigned)row;
+                    } else {
+                        const int img = m / hw_out;
+                        const int rem = m - img * hw_out;
+                        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;          // tap < 9
+                        const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+                        if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
+                            int sy = iy, sx = ix;
+                            if (p.upsample) {      // torch nearest: src = min(floor(dst * (in/out)), in - 1), fp32 scale
+                                sy = min((int)floorf((float)iy * p.ups_h), p.Hs - 1);
+                                sx = min((int)floorf((float)ix * p.ups_w), p.Ws - 1);
+                            }
+                            pix = (unsigned)(((img - img0) * p.Hs + sy) * p.Ws + sx);
+                        }
+                    }
+                }
+                tab[e] = pix;
+            }
+        }
+    };
+    // point the issue side at tile t, whose table sits in buffer `which`
+    auto aim = [&](const BgTile t, const int which) {
+        const int z = p.batch > 1 ? t.rbg / p.nbm_per : 0;
+        const int bm = t.rbg - z * p.nbm_per;
+        const __bf16* a0 = reinterpret_cast<const __bf16*>(p.a0) + (size_t)z * p.sa0;
+        const __bf16* a1 = reinterpret_cast<const __bf16*>(p.a1);
+        i_w = reinterpret_cast<const char*>(p.w16) + ((size_t)z * p.sw + (size_t)t.n0 * p.ldw) * 2;
+        const int img0 = p.taps == 1 ? 0 : (bm * BM) / hw_out;
+        const size_t row_base = p.taps == 1 ? (size_t)bm * BM : (size_t)img0 * hw_in;
+        i_a0b = a0 + row_base * p.lda0;
+        i_a1b = p.c1 > 0 ? a1 + row_base * p.lda1 : i_a0b;
+        i_bpw = t.wide ? BPWM : BPWM / 2;
+        i_tab = tabs + which * TABN;
+#pragma unroll
+        for (int j = 0; j < BPWM; ++j) {
+            const int r = 8 * (wave * i_bpw + j) + r8;
+            b_off[j] = (j < i_bpw && t.n0 + r < p.N) ? (unsigned)(r * p.ldw * 2) + b_kc(j) * 16u : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < APW; ++i) a_voff0[i] = bm * BM + a_row(i) < p.M ? (unsigned)(a_row(i) * p.lda0 * 2) + a_kc(i) * 16u : OOB;
+        k_src = 0, k_cb = 0, k_tap = 0, cseg = p.c0, ldb = p.lda0 * 2;
+        i_live = true;
+    };
+    auto first_pixels = [&]() {                             // after the table of the aimed tile is visible
+        if constexpr (!LIN) {
+#pragma unroll
+            for (int i = 0; i < APW; ++i) pixn[i] = i_tab[a_row(i)];
+        }
+    };
+    // one stage of the aimed tile into the buffer at byte offset bo; clears i_live behind the tile's last stage
+    auto issue = [&](const int bo) {
+        char* Ab = smem + bo;
+        char* Bb = Ab + A_BYTES;
+        if constexpr (LIN) {
+            const unsigned so = (unsigned)k_cb * 2u;
+            const unsigned sob = (unsigned)((k_src ? p.c0 : 0) + k_cb) * 2u;
+            const bool whole = k_cb + BKE <= cseg;          // the stage lies inside the segment: no channel masks
+            const __amdgpu_buffer_rsrc_t rsa = rsrc_of(k_src ? i_a1b : i_a0b, a_records);
+            const __amdgpu_buffer_rsrc_t rw = rsrc_of(i_w);
+            // every call issues the same APW + BPWM instructions (no tile behind this one: all of them out of window; a 64-wide
+            // tile: the unused B pieces likewise): the compiler's vmcnt bookkeeping then counts the epilogue's waits exactly
+            // instead of draining the queue
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                // second source (concat): same rows, its own row stride
+                const unsigned vo = !k_src ? a_voff0[i] : a_voff0[i] == OOB ? OOB : (unsigned)(a_row(i) * p.lda1 * 2) + a_kc(i) * 16u;
+                const unsigned off = (i_live && (whole || k_cb + (int)a_kc(i) * 8 < cseg)) ? vo : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(Ab + (wave * APW + i) * 1024), 16, off, so, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < BPWM; ++j) {
+                const unsigned off = (i_live && (whole || k_cb + (int)b_kc(j) * 8 < cseg)) ? b_off[j] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(Bb + b_piece(j) * 1024), 16, off, sob, 0, 0);
+            }
+            if (!i_live) return;
+            k_cb += BKE;
+            if (k_cb >= cseg) {
+                if (k_src == 0 && p.c1 > 0) { k_src = 1; k_cb = 0; cseg = p.c1; }
+                else i_live = false;
+            }
+            return;
+        } else {
+            const __amdgpu_buffer_rsrc_t rsa = rsrc_of(k_src ? i_a1b : i_a0b, a_records);
+            const __amdgpu_buffer_rsrc_t rw = rsrc_of(i_w);
+            const unsigned colb = (unsigned)k_cb * 2u;
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                const bool ok = i_live & (pixn[i] != ~0u) & (k_cb + (int)a_kc(i) * 8 < cseg);
+                const unsigned off = ok ? __umul24(pixn[i], (unsigned)ldb) + colb + a_kc(i) * 16u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(Ab + (wave * APW + i) * 1024), 16, off, 0, 0, 0);
+            }
+            const int cbase = (k_src ? p.c0 : 0) + k_cb;                               // channel of this k-step in the concat
+            const int koffb = (p.taps == 1 ? cbase : (cbase / BKE * 9 + k_tap) * BKE) * 2;   // wave-uniform: rides in soffset
+#pragma unroll
+            for (int j = 0; j < BPWM; ++j) {
+                const bool ok = i_live & (k_cb + (int)b_kc(j) * 8 < cseg);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(Bb + b_piece(j) * 1024), 16, ok ? b_off[j] : OOB, koffb, 0, 0);
+            }
+            if (!i_live) return;
+            // advance (tap fastest, then chunk, then source)
+            const int t2 = k_tap + 1;
+            const bool wrap_t = t2 == p.taps;
+            k_tap = wrap_t ? 0 : t2;
+            const int cb2 = wrap_t ? k_cb + BKE : k_cb;
+            const bool wrap = cb2 >= cseg;
+            k_cb = wrap ? 0 : cb2;
+            const bool more = k_src == 0 && p.c1 > 0;
+            if (wrap && !more) i_live = false;
+            k_src = (wrap && more) ? 1 : k_src;
+            cseg = k_src ? p.c1 : p.c0;
+            ldb = (k_src ? p.lda1 : p.lda0) * 2;
+            if (i_live) {
+#pragma unroll
+                for (int i = 0; i < APW; ++i) pixn[i] = i_tab[k_tap * BM + a_row(i)];
+            }
+        }
+    };
+
+    // ---- compute side ---------------------------------------------------------------------------------------------------------
+    const int fr = lane & 31, fh = lane >> 5;
+    const int fs = (fr >> 1) & 7;
+    unsigned foff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) foff[g] = (unsigned)(((2 * g + fh) ^ fs) * 16);
+    const char* const Afr = smem + (wm * WM + fr) * ROWB;
+
+    int loc = slot;
+    BgTile cur = bgemm_decode(p, x, loc);
+    if (!cur.valid) return;
+    build_table(cur, 0);
+    aim(cur, 0);
+    if constexpr (!LIN) __syncthreads();
+    first_pixels();
+    int bo = 0;                                             // byte offset of the buffer holding the stage being multiplied
+    issue(0);
+    int tabsel = 0;
+    __syncthreads();                                        // stage 0 of the first tile has landed
+
+    for (;;) {
+        loc += nslots;
+        const BgTile nxt = bgemm_decode(p, x, loc);
+        if constexpr (!LIN) {
+            // the next tile's table, now: the k-loop's barriers (or the one here, for a single-stage tile) put it in front of
+            // its first use at this tile's last stage
+            if (nxt.valid) build_table(nxt, tabsel ^ 1);
+            if (nk < 2) __syncthreads();
+        }
+        // bias (+ the time-embedding row of the two samples the tile's rows can belong to) for the tile's columns: loaded now,
+        // parked in LDS at the tile's last stage (by then the k-loop's barriers have waited for it anyway)
+        const int c_z = p.batch > 1 ? cur.rbg / p.nbm_per : 0;
+        const int c_bm = cur.rbg - c_z * p.nbm_per;
+        const int s_lo = p.rowbias ? (c_bm * BM) / p.rows_per_sample : 0;
+        // (unconditional buffer loads, a null pointer as a zero-record descriptor: a load under a branch would leave the compiler's
+        // vmcnt bookkeeping with a "maybe pending" register at the loop head and a queue drain there)
+        float brv, brr;
+        {
+            const int n = cur.n0 + (tid & 127), sr = s_lo + ((tid >> 7) & 1);
+            const bool rok = n < p.N && (long)sr * p.rows_per_sample < (long)p.M;
+            brv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_of(p.bias, p.bias ? 0x7FFFFFF0 : 0),
+                                                                                  n < p.N ? (unsigned)n * 4u : OOB, 0, 0));
+            brr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_of(p.rowbias, p.rowbias ? 0x7FFFFFF0 : 0),
+                                                                                  rok ? (unsigned)(sr * p.rb_ld + n) * 4u : OOB, 0, 0));
+        }
+        auto run = [&](auto TNc) {
+            constexpr int TN = decltype(TNc)::value;
+            constexpr int WN = 32 * TN;
+            const char* const Bfr = smem + A_BYTES + (wn * WN + fr) * ROWB;
+            f32x16 acc[TM][TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            bf16x8 af[2][TM], bfr[2][TN];
+            auto read_frags = [&](const int set, const int off, const int g) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) af[set][mi] = *reinterpret_cast<const bf16x8*>(Afr + off + mi * 32 * ROWB + foff[g]);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) bfr[set][ni] = *reinterpret_cast<const bf16x8*>(Bfr + off + ni * 32 * ROWB + foff[g]);
+            };
+            auto mma = [&](const int set) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[set][ni], af[set][mi], acc[mi][ni], 0, 0, 0);
+            };
+            const int z = c_z, bm = c_bm;
+            read_frags(0, bo, 0);
+            for (int ks = 0; ks + 1 < nk; ++ks) {
+                const int bn = STAGE - bo;                  // the other buffer
+                issue(bn);                                  // stage ks + 1 of this tile
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(1, bo, 1);
+                mma(0);
+                read_frags(0, bo, 2);
+                mma(1);
+                read_frags(1, bo, 3);
+                mma(0);
+                __syncthreads();                            // stage ks+1 has landed; every wave is done reading stage ks
+                read_frags(0, bn, 0);                       // first fragments of stage ks+1 ...
+                __builtin_amdgcn_sched_barrier(0);
+                mma(1);                                     // ... land while the last k-group of stage ks is multiplied
+                bo = bn;
+            }
+            // the tile's last stage
+            const int bn = STAGE - bo;
+            brow[tid & 127] = brv;                          // read behind the barrier below
+            brow[128 + (tid & 255)] = brr;
+            read_frags(1, bo, 1);
+            mma(0);
+            read_frags(0, bo, 2);
+            mma(1);
+            read_frags(1, bo, 3);
+            mma(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // every wave is done reading the stage: it becomes the staging area
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1);
+            BgEpilogue<BM, TM, TN, WM, WN> epi;
+            epi.prefetch(p, bm, cur.n0, wm, wn, lane);      // bias / residual loads: older than the DMA below in the vmcnt queue
+            __builtin_amdgcn_sched_barrier(0);
+            if (nxt.valid) {                                // the ring runs on into the next tile while this one is written out
+                aim(nxt, tabsel ^ 1);
+                first_pixels();
+                tabsel ^= 1;
+            }
+            issue(bn);
+            __builtin_amdgcn_sched_barrier(0);
+            __bf16* __restrict__ out = reinterpret_cast<__bf16*>(p.out) + (size_t)z * p.sout;
+            epi.finish(p, acc, out, bm, cur.n0, wm, wn, lane, reinterpret_cast<float*>(smem + bo) + wave * 32 * WN, brow, s_lo);
+            // finish() ends on a counted vmcnt: this wave's part of the next tile's stage 0 has landed, its stores have not
+            // been waited for
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // staging reads done; stage 0 of the next tile is in LDS
+            __builtin_amdgcn_sched_barrier(0);
+            bo = bn;
+        };
+        if (cur.wide) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 1>{});
+        if (!nxt.valid) break;
+        cur = nxt;
+    }
+}
+
+template <bool LIN>
+__global__ __launch_bounds__(256, 2) void bgemm_pers_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bp[];
+    bgemm_pers_body<128, 2, LIN>(p, smem_bp, blockIdx.x & 7, blockIdx.x >> 3, gridDim.x >> 3);
 }
 
 template <bool LIN>
@@ -454,7 +683,8 @@ __global__ __launch_bounds__(512) void bgemm256_kernel(const IgemmArgs p) {
 }
 
 bool bgemm_use_256(const IgemmArgs& a) {
-    static const int mode = [] { const char* e = std::getenv("E2V_BGEMM_256"); return e ? std::atoi(e) : 1; }();   // 0: never, 2: always
+    static const int* const modep = knob("E2V_BGEMM_256", 1);      // 0: never, 2: always
+    const int mode = *modep;
     if (mode == 0) return false;
     if (mode == 2) return true;
     // 3x3 convs only: their long k-loop (K >= 2880) is bound by the LDS fill rate, which the bigger tile relieves (+5-10 %);
@@ -494,26 +724,8 @@ void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         configured = true;
     }
-    static const int lean = [] { const char* e = std::getenv("E2V_BGEMM_LIN"); return e ? std::atoi(e) : 1; }();   // 0: linears through the gather path
-    const bool lin = a.taps == 1 && lean;
-    static const int ring = [] { const char* e = std::getenv("E2V_BGEMM_RING"); return e ? std::atoi(e) : 0; }();
-    if (ring && a.taps == 1 && !a.bm256) {
-        constexpr size_t smem_r = (size_t)4 * 128 * 64 * 2;                               // four stages of (128 + 128) rows x 64 bytes
-        static bool cfgr = false;
-        if (!cfgr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_r);
-            cfgr = true;
-        }
-        const double Kr = (double)(a.c0 + a.c1);
-        std::string rn = "igemm_bf16";
-        if (profiler().on && profiler().detail)
-            rn += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)Kr) + " t1" + (a.c1 ? " cat" : "") +
-                  (a.geglu ? " geglu" : "") + (a.batch > 1 ? " b" + std::to_string(a.batch) : "");
-        ProfScope psr(rn.c_str(), 2.0 * a.M * a.N * Kr * a.batch,
-                      a.batch * (2.0 * a.M * Kr + 2.0 * a.N * Kr + (a.out_f32 ? 4.0 : 2.0) * a.M * (a.geglu ? a.N / 2 : a.N)), s);
-        hipLaunchKernelGGL(bgemm_ring_kernel, dim3(ntiles, 1, 1), dim3(256), smem_r, s, a);
-        return;
-    }
+    static const int* const lean = knob("E2V_BGEMM_LIN", 1);        // 0: linears through the gather path
+    const bool lin = a.taps == 1 && *lean;
     const double K = (double)a.taps * (a.c0 + a.c1);
     const double rows_in = a.taps == 1 ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
     std::string pname = "igemm_bf16";
@@ -521,11 +733,27 @@ void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
         pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t" + std::to_string(a.taps) +
                  (a.stride > 1 ? " s2" : "") + (a.upsample ? " up" : "") + (a.c1 ? " cat" : "") + (a.geglu ? " geglu" : "") +
                  (a.batch > 1 ? " b" + std::to_string(a.batch) : "");
-    static const int ablate = [] { const char* e = std::getenv("E2V_BGEMM_ABLATE"); return e ? std::atoi(e) : 0; }();
-    const_cast<IgemmArgs&>(a).ablate = ablate;
+    static const int* const ablate = knob("E2V_BGEMM_ABLATE", 0);
+    const_cast<IgemmArgs&>(a).ablate = *ablate;
     const double out_b = a.out_f32 ? 4.0 : 2.0;
     ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
                  a.batch * (2.0 * rows_in * (a.c0 + a.c1) + 2.0 * a.N * K + out_b * a.M * (a.geglu ? a.N / 2 : a.N)), s);
+    static const int* const persp = knob("E2V_BGEMM_PERS", 1);
+    const int pers = *persp;
+    // (an fp32 residual, or time-embedding rows of more than two samples under one tile -- toy sizes -- take the kernels below)
+    if (pers && !a.out_f32 && !a.bm256 && !(a.resid && !a.resid_bf16) && !(a.rowbias && a.rows_per_sample < 128)) {
+        constexpr size_t smem_p = (size_t)2 * 128 * 128 * 2 + 2 * 9 * 128 * sizeof(unsigned) + 3 * 128 * sizeof(float);   // stages, tables, bias rows
+        static bool cfgp = false;
+        if (!cfgp) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_pers_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_pers_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
+            cfgp = true;
+        }
+        const int grid = ntiles < 512 ? ntiles : 512;                                             // two workgroups per CU
+        if (lin) hipLaunchKernelGGL(bgemm_pers_kernel<true>, dim3(grid, 1, 1), dim3(256), smem_p, s, a);
+        else hipLaunchKernelGGL(bgemm_pers_kernel<false>, dim3(grid, 1, 1), dim3(256), smem_p, s, a);
+        return;
+    }
     if (a.bm256) {
         constexpr size_t smem256 = (size_t)2 * (256 + 128) * 128 + 9 * 256 * sizeof(unsigned);
         static bool cfg256 = false;

@@ -28,6 +28,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Epilogue shared by the fp32, bf16 and split-bf16 tiles (all use 32x32 MFMA results with the WEIGHT fragment as the A
 // operand): in each 32x32 result a lane holds pixel m = lane & 31 and output channels n = 8 g + 4 (lane >> 5) + e in register
@@ -146,7 +147,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
 // bf16 OUTPUT (bf16-activation mode): same staging through LDS, but a lane finishes 8 consecutive columns -- two 16-byte
 // reads of the fp32 staging row, bias / time-embedding row in fp32, the residual as 8 bf16 (16 bytes), one rounding to bf16 at
 // the very end, a 16-byte store.  `out` / `p.resid` are bf16 (p.resid_bf16) or the residual is fp32 (latents never are).
-template <int BM, int TM, int TN, int WM, int WN>
+// SWZ (the persistent kernel): the staging area is the stage buffer the tile has just consumed and no byte more -- 32 rows x WN
+// floats per wave, UNPADDED, the 16-byte chunk of a row XOR-swizzled with the row (256-byte rows: row & 15; 128-byte rows:
+// (row >> 1) & 7) so that the column-major writes and the row-major reads both cover all 64 banks once per 16 lanes.
+template <int BM, int TM, int TN, int WM, int WN, bool SWZ = false>
 __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (&acc)[TM][TN], __bf16* __restrict__ out, const int bm,
                                                     const int n0, const int wm, const int wn, const int lane, float* stage) {
     const int mrow = lane & 31;
@@ -190,11 +194,13 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
     }
     const bool vec = ((p.N | p.ldc | p.ldr) & 7) == 0 && (p.rb_ld & 3) == 0;
     if (vec) {
-        constexpr int SLD = WN + 4;
+        constexpr int SLD = SWZ ? WN : WN + 4;
         constexpr int LPR = WN / 8;                            // lanes per staged row (8 columns each)
         constexpr int RPI = 64 / LPR;                          // rows per access instruction
         float* st = stage + (size_t)(threadIdx.x >> 6) * 32 * SLD;
         const int col = (lane % LPR) * 8;
+        auto swz = [](const int row) { return !SWZ ? 0 : (WN == 64 ? (row & 15) : ((row >> 1) & 7)); };
+        const int wsw = swz(mrow);
         const int n = n0 + wn * WN + col;
         f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
         if (p.bias && n < p.N) {
@@ -210,15 +216,16 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
                     f32x4 y;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y[e] = acc[mi][ni][4 * g + e];
-                    *reinterpret_cast<f32x4*>(st + mrow * SLD + ni * 32 + 8 * g + nq) = y;
+                    *reinterpret_cast<f32x4*>(st + mrow * SLD + (((ni * 8 + 2 * g + (lane >> 5)) ^ wsw) << 2)) = y;
                 }
 #pragma unroll
             for (int i = 0; i < 32 / RPI; ++i) {
                 const int row = lane / LPR + RPI * i;
                 const int m = bm * BM + wm * WM + mi * 32 + row;
                 if (m >= p.M || n >= p.N || (p.ablate & 1)) continue;   // N % 8 == 0: the lane's eight columns are in or out together
-                f32x4 y0 = *reinterpret_cast<const f32x4*>(st + row * SLD + col);
-                f32x4 y1 = *reinterpret_cast<const f32x4*>(st + row * SLD + col + 4);
+                const int rsw = swz(row);
+                f32x4 y0 = *reinterpret_cast<const f32x4*>(st + row * SLD + ((((col >> 2)) ^ rsw) << 2));
+                f32x4 y1 = *reinterpret_cast<const f32x4*>(st + row * SLD + ((((col >> 2) + 1) ^ rsw) << 2));
                 if (p.alpha != 1.0f) { y0 *= p.alpha; y1 *= p.alpha; }
                 y0 += b0; y1 += b1;
                 if (p.rowbias) {
@@ -273,5 +280,179 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
             }
     }
 }
+
+// The same epilogue cut in two for the persistent kernel (bgemm.hip).  `prefetch` issues the only global loads the epilogue
+// has left -- the bf16 residual -- BEFORE the caller starts the next tile's first stage, so that they are older than that DMA
+// in the wave's in-order vmcnt queue and waiting for them never waits for it.  Bias and time-embedding rows do not come from
+// global memory here: the caller has put them into LDS for the tile's 128 columns -- `brow[0][128]` = bias, `brow[1 + j][128]` =
+// rowbias of sample s_lo + j, j = 0, 1 (a tile's rows belong to at most two samples; sample of row m = m / rows_per_sample).  `finish` stages the
+// accumulators through `st` (this wave's 32 x WN floats, unpadded and chunk-swizzled as above), adds, rounds once and stores.
+// Residuals are bf16 (the launcher sends an fp32 residual to the non-persistent kernels).
+template <int BM, int TM, int TN, int WM, int WN>
+struct BgEpilogue {
+    static constexpr int LPR = WN / 8, RPI = 64 / LPR, NI = 32 / RPI;
+    bf16x8 res[TM][NI];
+    bool vec;
+
+    __device__ __forceinline__ void prefetch(const IgemmArgs& p, const int bm, const int n0, const int wm, const int wn, const int lane) {
+        vec = ((p.N | p.ldc | p.ldr) & 7) == 0;
+        if (p.geglu || !vec || !p.resid) return;
+        // branch-free (a load under a branch cannot be counted by the compiler's vmcnt bookkeeping, which then drains the queue
+        // -- the next tile's DMA included -- at the first use): buffer loads against a descriptor based at the tile's first
+        // residual row, rows / columns outside the matrix as out-of-window offsets
+        const int n = n0 + wn * WN + (lane % LPR) * 8;
+        const unsigned long long base = reinterpret_cast<unsigned long long>(reinterpret_cast<const __bf16*>(p.resid) + (size_t)bm * BM * p.ldr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0,
+                                                                            0x7FFFFFF0, 0x00020000);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = wm * WM + mi * 32 + lane / LPR + RPI * i;
+                const bool ok = bm * BM + row < p.M && n < p.N;
+                const unsigned off = ok ? (unsigned)((row * p.ldr + n) * 2) : 0x80000000u;
+                const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+                res[mi][i] = __builtin_bit_cast(bf16x8, r);
+            }
+    }
+
+    __device__ __forceinline__ void finish(const IgemmArgs& p, f32x16 (&acc)[TM][TN], __bf16* __restrict__ out, const int bm, const int n0,
+                                           const int wm, const int wn, const int lane, float* st, const float* brow, const int s_lo) {
+        const int mrow = lane & 31;
+        const int nq = (lane >> 5) * 4;
+        // stores: buffer stores against a descriptor based at the tile's first output row, masked elements as out-of-window
+        // offsets (dropped by the buffer unit) -- issued unconditionally, so that the number of stores behind the next tile's
+        // DMA is a compile-time constant and the wait in front of the barrier can be COUNTED (vmcnt(stores)): the DMA has
+        // landed, the stores are left in flight
+        const unsigned long long obase = reinterpret_cast<unsigned long long>(out + (size_t)bm * BM * p.ldc);
+        const unsigned olo = __builtin_amdgcn_readfirstlane((unsigned)obase);
+        const unsigned ohi = __builtin_amdgcn_readfirstlane((unsigned)(obase >> 32));
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)ohi << 32) | olo), (short)0,
+                                                                             0x7FFFFFF0, 0x00020000);
+        const bool drop = (p.ablate & 1) != 0;
+        if (p.geglu) {
+            if constexpr (TN == 2) {
+                const int nb = n0 + wn * WN;
+                if (nb + 64 > p.N) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    return;
+                }
+                const int col = (lane & 3) * 8;                    // 4 lanes x 8 bf16 = one 64-byte output row segment
+                const int wsw = (mrow >> 1) & 7;                   // 32-float staging rows
+                f32x4 gv[4], gg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    gv[g] = *reinterpret_cast<const f32x4*>(brow + wn * WN + 8 * g + nq);
+                    gg[g] = *reinterpret_cast<const f32x4*>(brow + wn * WN + 32 + 8 * g + nq);
+                }
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 y;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + gv[g][e]) * gelu_erf(acc[mi][1][4 * g + e] * p.alpha + gg[g][e]);
+                        *reinterpret_cast<f32x4*>(st + mrow * 32 + (((2 * g + (lane >> 5)) ^ wsw) << 2)) = y;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = (lane >> 2) + 16 * i;
+                        const int m = bm * BM + wm * WM + mi * 32 + row;
+                        const int rsw = (row >> 1) & 7;
+                        const f32x4 y0 = *reinterpret_cast<const f32x4*>(st + row * 32 + (((col >> 2) ^ rsw) << 2));
+                        const f32x4 y1 = *reinterpret_cast<const f32x4*>(st + row * 32 + ((((col >> 2) + 1) ^ rsw) << 2));
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y0[e]; o[4 + e] = (__bf16)y1[e]; }
+                        const unsigned off = (m < p.M && !drop) ? (unsigned)(((wm * WM + mi * 32 + row) * p.ldc + nb / 2 + col) * 2) : 0x80000000u;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ors, off, 0, 0);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM * 2) : "memory");
+                return;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+        if (!vec) {                                            // N or a stride not a multiple of 8: element-wise, no staging
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const int m = bm * BM + wm * WM + mi * 32 + mrow;
+                if (m >= p.M) continue;
+                const float* bb = brow + wn * WN;
+                const float* br = brow + 128 + (p.rowbias ? (m / p.rows_per_sample - s_lo) * 128 : 0) + wn * WN;
+                __bf16* orow = out + (size_t)m * p.ldc;
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = ni * 32 + 8 * g + nq;
+                        const int n = n0 + wn * WN + c;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e >= p.N) break;
+                            float v = acc[mi][ni][4 * g + e] * p.alpha + bb[c + e];
+                            if (p.rowbias) v += br[c + e];
+                            if (p.resid) v += (float)reinterpret_cast<const __bf16*>(p.resid)[(size_t)m * p.ldr + n + e];
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            orow[n + e] = (__bf16)v;
+                        }
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+        auto swz = [](const int row) { return WN == 64 ? (row & 15) : ((row >> 1) & 7); };
+        const int wsw = swz(mrow);
+        const int col = (lane % LPR) * 8;
+        const int n = n0 + wn * WN + col;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = acc[mi][ni][4 * g + e];
+                    *reinterpret_cast<f32x4*>(st + mrow * WN + (((ni * 8 + 2 * g + (lane >> 5)) ^ wsw) << 2)) = y;
+                }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = lane / LPR + RPI * i;
+                const int m = bm * BM + wm * WM + mi * 32 + row;
+                const int rsw = swz(row);
+                f32x4 y0 = *reinterpret_cast<const f32x4*>(st + row * WN + (((col >> 2) ^ rsw) << 2));
+                f32x4 y1 = *reinterpret_cast<const f32x4*>(st + row * WN + ((((col >> 2) + 1) ^ rsw) << 2));
+                const float* bb = brow + wn * WN + col;
+                if (p.alpha != 1.0f) { y0 *= p.alpha; y1 *= p.alpha; }
+                y0 += *reinterpret_cast<const f32x4*>(bb);
+                y1 += *reinterpret_cast<const f32x4*>(bb + 4);
+                if (p.rowbias) {                                   // separately, in the order of the tile kernels: bit-identical results
+                    const float* br = bb + 128 + (m < p.M ? (m / p.rows_per_sample - s_lo) * 128 : 0);
+                    y0 += *reinterpret_cast<const f32x4*>(br);
+                    y1 += *reinterpret_cast<const f32x4*>(br + 4);
+                }
+                if (p.resid) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { y0[e] += (float)res[mi][i][e]; y1[e] += (float)res[mi][i][4 + e]; }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { y0[e] = fmaxf(y0[e], 0.f); y1[e] = fmaxf(y1[e], 0.f); }
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y0[e]; o[4 + e] = (__bf16)y1[e]; }
+                const unsigned off = (m < p.M && n < p.N && !drop) ? (unsigned)(((wm * WM + mi * 32 + row) * p.ldc + n) * 2) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ors, off, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM * NI) : "memory");
+    }
+};
 
 }  // namespace e2v

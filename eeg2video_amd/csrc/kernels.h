@@ -52,9 +52,13 @@ struct IgemmArgs {
     int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, nbm_per = 0, tail_rb = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
 };
 void igemm(const IgemmArgs& a, hipStream_t s);
+// Run-time switches: an int per name, initialised from the environment variable of that name on first use
+// and settable through e2v_op_set_knob for A/B comparisons inside one process.  The returned pointer stays valid.
+int* knob(const char* name, int dflt);
+bool set_knob(const char* name, int value);      // false: no kernel has asked for a knob of that name yet and it is not a known one
 void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s);
 bool bgemm_all_n64(const IgemmArgs& a);
-bool bgemm_use_256(const IgemmArgs& a);                                  // schedule hint: 256-row tiles pay for this launch                                  // schedule hint: cut this launch into 128 x 64 tiles only      // bgemm.hip: the a_bf16 kernels (schedule already in `a`)
+bool bgemm_use_256(const IgemmArgs& a);                                  // schedule hint: 256-row tiles pay for this launch
 
 // weight re-layout helpers (one-off, at finalize)
 // [O][I][3][3] -> [O][ceil(I/bke)][9][bke] (bke = 32 for the fp32 kernel, 64 for the bf16 one); row length below

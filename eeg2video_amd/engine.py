@@ -123,6 +123,11 @@ class Engine:
         code = {"auto": 0, "direct": 1, "winograd": 2, "winograd4": 3}[algo]
         self._check(self.lib.e2v_set_conv_algo(self.ctx, code))
 
+    def set_knob(self, name: str, value: int) -> None:
+        """Run-time switch of DESIGN section 10 (tests / profiling: same-process A/B of kernel variants)."""
+        if self.lib.e2v_op_set_knob(name.encode(), int(value)) != 0:
+            raise ValueError(f"unknown switch {name!r}")
+
     def device_bytes(self) -> int:
         return int(self.lib.e2v_device_bytes(self.ctx))
 

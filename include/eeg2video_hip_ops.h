@@ -59,6 +59,11 @@ e2v_status e2v_op_to_channels_last(e2v_ctx* ctx, const float* in, float* out, in
 e2v_status e2v_op_from_channels_last(e2v_ctx* ctx, const float* in, int ld, float* out, int n, int C, int FHW,
                                      e2v_stream stream);
 
+/* Test / profiling aid: set one of the run-time switches of DESIGN.md section 10 (the integer an environment variable of the
+ * same name would give it at first use), for same-process A/B comparisons of kernel variants -- e.g. "E2V_BGEMM_PERS" 0/1.
+ * Process-wide; E2V_EINVAL for an unknown name.  No reference counterpart. */
+e2v_status e2v_op_set_knob(const char* name, int value);
+
 #ifdef __cplusplus
 }
 #endif
