@@ -40,7 +40,7 @@ bool set_knob(const char* name, int value) {
     auto& t = knob_table();
     auto it = t.find(name);
     if (it == t.end()) {
-        static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_256", "E2V_BGEMM_LIN", "E2V_BGEMM_ABLATE"};
+        static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_PERS256", "E2V_BGEMM_256", "E2V_BGEMM_LIN", "E2V_BGEMM_ABLATE"};
         bool ok = false;
         for (const char* k : known) ok = ok || std::string(k) == name;
         if (!ok) return false;
@@ -324,6 +324,7 @@ __device__ __forceinline__ BgTile bgemm_decode(const IgemmArgs& p, const int x, 
 template <int BM, int WGM, bool LIN>
 __device__ __forceinline__ void bgemm_pers_body(const IgemmArgs& p, char* smem, const int x, const int slot, const int nslots) {
     constexpr int BKE = 64, ROWB = 128, WGN = 2;
+    constexpr bool PREFETCH = BM == 128;                      // next tile's first stage in flight under the epilogue
     constexpr int NW = WGM * WGN, NT = 64 * NW;
     constexpr int WM = BM / WGM, TM = WM / 32;
     constexpr int STAGE = (BM + 128) * ROWB, A_BYTES = BM * ROWB;
@@ -546,8 +547,9 @@ __device__ __forceinline__ void bgemm_pers_body(const IgemmArgs& p, char* smem, 
             const bool rok = n < p.N && (long)sr * p.rows_per_sample < (long)p.M;
             brv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_of(p.bias, p.bias ? 0x7FFFFFF0 : 0),
                                                                                   n < p.N ? (unsigned)n * 4u : OOB, 0, 0));
-            brr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_of(p.rowbias, p.rowbias ? 0x7FFFFFF0 : 0),
-                                                                                  rok ? (unsigned)(sr * p.rb_ld + n) * 4u : OOB, 0, 0));
+            brr = LIN ? 0.f                                 // (time-embedding rows belong to the resnets' 3x3 convs)
+                      : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_of(p.rowbias, p.rowbias ? 0x7FFFFFF0 : 0),
+                                                                                        rok ? (unsigned)(sr * p.rb_ld + n) * 4u : OOB, 0, 0));
         }
         auto run = [&](auto TNc) {
             constexpr int TN = decltype(TNc)::value;
@@ -606,23 +608,41 @@ __device__ __forceinline__ void bgemm_pers_body(const IgemmArgs& p, char* smem, 
             __builtin_amdgcn_s_barrier();                   // every wave is done reading the stage: it becomes the staging area
             __builtin_amdgcn_sched_barrier(0);
             mma(1);
-            BgEpilogue<BM, TM, TN, WM, WN> epi;
+            BgEpilogue<BM, TM, TN, WM, WN, !LIN> epi;
             epi.prefetch(p, bm, cur.n0, wm, wn, lane);      // bias / residual loads: older than the DMA below in the vmcnt queue
             __builtin_amdgcn_sched_barrier(0);
-            if (nxt.valid) {                                // the ring runs on into the next tile while this one is written out
-                aim(nxt, tabsel ^ 1);
-                first_pixels();
-                tabsel ^= 1;
+            if constexpr (PREFETCH) {
+                if (nxt.valid) {                            // the ring runs on into the next tile while this one is written out
+                    aim(nxt, tabsel ^ 1);
+                    first_pixels();
+                    tabsel ^= 1;
+                }
+                issue(bn);
+                __builtin_amdgcn_sched_barrier(0);
+                __bf16* __restrict__ out = reinterpret_cast<__bf16*>(p.out) + (size_t)z * p.sout;
+                epi.finish(p, acc, out, bm, cur.n0, wm, wn, lane, reinterpret_cast<float*>(smem + bo) + wave * 32 * WN, brow, s_lo);
+                // finish() ends on a counted vmcnt: this wave's part of the next tile's stage 0 has landed, its stores have not
+                // been waited for
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();               // staging reads done; stage 0 of the next tile is in LDS
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                // 256-row tiles: eight waves stage 64 KB, more than one 48 KB stage buffer -- the staging area is both buffers and
+                // the next tile's first stage is fetched behind the epilogue (one exposed round trip per ~100 us tile); the
+                // workgroup still keeps its place, its next table is built and its stores are not waited for
+                __bf16* __restrict__ out = reinterpret_cast<__bf16*>(p.out) + (size_t)z * p.sout;
+                epi.finish(p, acc, out, bm, cur.n0, wm, wn, lane, reinterpret_cast<float*>(smem) + wave * 32 * WN, brow, s_lo);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();               // staging reads done
+                __builtin_amdgcn_sched_barrier(0);
+                if (nxt.valid) {
+                    aim(nxt, tabsel ^ 1);
+                    first_pixels();
+                    tabsel ^= 1;
+                    issue(bn);
+                    __syncthreads();
+                }
             }
-            issue(bn);
-            __builtin_amdgcn_sched_barrier(0);
-            __bf16* __restrict__ out = reinterpret_cast<__bf16*>(p.out) + (size_t)z * p.sout;
-            epi.finish(p, acc, out, bm, cur.n0, wm, wn, lane, reinterpret_cast<float*>(smem + bo) + wave * 32 * WN, brow, s_lo);
-            // finish() ends on a counted vmcnt: this wave's part of the next tile's stage 0 has landed, its stores have not
-            // been waited for
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                   // staging reads done; stage 0 of the next tile is in LDS
-            __builtin_amdgcn_sched_barrier(0);
             bo = bn;
         };
         if (cur.wide) run(std::integral_constant<int, 2>{});
@@ -636,6 +656,12 @@ template <bool LIN>
 __global__ __launch_bounds__(256, 2) void bgemm_pers_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_bp[];
     bgemm_pers_body<128, 2, LIN>(p, smem_bp, blockIdx.x & 7, blockIdx.x >> 3, gridDim.x >> 3);
+}
+
+template <bool LIN>
+__global__ __launch_bounds__(512, 2) void bgemm_pers256_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bp256[];
+    bgemm_pers_body<256, 4, LIN>(p, smem_bp256, blockIdx.x & 7, blockIdx.x >> 3, gridDim.x >> 3);
 }
 
 template <bool LIN>
@@ -738,10 +764,14 @@ void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
     const double out_b = a.out_f32 ? 4.0 : 2.0;
     ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
                  a.batch * (2.0 * rows_in * (a.c0 + a.c1) + 2.0 * a.N * K + out_b * a.M * (a.geglu ? a.N / 2 : a.N)), s);
+    // E2V_BGEMM_PERS: 0 never, 1 where it measured faster (same-box A/B over every GEMM shape of a B = 32 pass, tools/shape_profile.py:
+    // linears with a residual to read, K <= 2560: -3..-20 %; K = 320 and the K = 640 GEGLU without one: -4..-6 %; the wide
+    // residual-free projections at K >= 640 and the 3x3 convs that are too small for 256-row tiles: +2..+6 %), 2 wherever it applies
     static const int* const persp = knob("E2V_BGEMM_PERS", 1);
-    const int pers = *persp;
+    const int Kc = a.c0 + a.c1;
+    const int pers = *persp == 2 ? 1 : *persp == 0 ? 0 : (a.taps == 1 && (a.resid ? Kc <= 2560 : (Kc <= 320 || (a.geglu && Kc <= 640))));
     // (an fp32 residual, or time-embedding rows of more than two samples under one tile -- toy sizes -- take the kernels below)
-    if (pers && !a.out_f32 && !a.bm256 && !(a.resid && !a.resid_bf16) && !(a.rowbias && a.rows_per_sample < 128)) {
+    if (pers && !a.out_f32 && !a.bm256 && !(a.resid && !a.resid_bf16) && !(a.rowbias && (lin || a.rows_per_sample < 128))) {
         constexpr size_t smem_p = (size_t)2 * 128 * 128 * 2 + 2 * 9 * 128 * sizeof(unsigned) + 3 * 128 * sizeof(float);   // stages, tables, bias rows
         static bool cfgp = false;
         if (!cfgp) {
@@ -752,6 +782,20 @@ void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
         const int grid = ntiles < 512 ? ntiles : 512;                                             // two workgroups per CU
         if (lin) hipLaunchKernelGGL(bgemm_pers_kernel<true>, dim3(grid, 1, 1), dim3(256), smem_p, s, a);
         else hipLaunchKernelGGL(bgemm_pers_kernel<false>, dim3(grid, 1, 1), dim3(256), smem_p, s, a);
+        return;
+    }
+    static const int* const pers256 = knob("E2V_BGEMM_PERS256", 1);
+    if (a.bm256 && *pers256 && !a.out_f32 && !(a.resid && !a.resid_bf16) && !(a.rowbias && (lin || a.rows_per_sample < 256))) {
+        constexpr size_t smem_p256 = (size_t)2 * (256 + 128) * 128 + 2 * 9 * 256 * sizeof(unsigned) + 3 * 128 * sizeof(float);
+        static bool cfgp256 = false;
+        if (!cfgp256) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_pers256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_pers256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p256);
+            cfgp256 = true;
+        }
+        const int grid = ntiles < 256 ? ntiles : 256;                                             // one workgroup per CU
+        if (lin) hipLaunchKernelGGL(bgemm_pers256_kernel<true>, dim3(grid, 1, 1), dim3(512), smem_p256, s, a);
+        else hipLaunchKernelGGL(bgemm_pers256_kernel<false>, dim3(grid, 1, 1), dim3(512), smem_p256, s, a);
         return;
     }
     if (a.bm256) {

@@ -288,7 +288,7 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
 // rowbias of sample s_lo + j, j = 0, 1 (a tile's rows belong to at most two samples; sample of row m = m / rows_per_sample).  `finish` stages the
 // accumulators through `st` (this wave's 32 x WN floats, unpadded and chunk-swizzled as above), adds, rounds once and stores.
 // Residuals are bf16 (the launcher sends an fp32 residual to the non-persistent kernels).
-template <int BM, int TM, int TN, int WM, int WN>
+template <int BM, int TM, int TN, int WM, int WN, bool ROWBIAS = true>      // ROWBIAS false: launches that never carry one (linears)
 struct BgEpilogue {
     static constexpr int LPR = WN / 8, RPI = 64 / LPR, NI = 32 / RPI;
     bf16x8 res[TM][NI];
@@ -306,13 +306,17 @@ struct BgEpilogue {
         const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0,
                                                                             0x7FFFFFF0, 0x00020000);
+        // (the empty asm keeps the per-row offsets from being hoisted out of the caller's tile loop as eight loop-invariant
+        // registers, which the allocator then spills: a scratch reload in the epilogue is a vmcnt wait behind the DMA)
+        unsigned off0 = (unsigned)(((wm * WM + lane / LPR) * p.ldr + n) * 2);
+        asm volatile("" : "+v"(off0));
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int row = wm * WM + mi * 32 + lane / LPR + RPI * i;
                 const bool ok = bm * BM + row < p.M && n < p.N;
-                const unsigned off = ok ? (unsigned)((row * p.ldr + n) * 2) : 0x80000000u;
+                const unsigned off = ok ? off0 + (unsigned)((mi * 32 + RPI * i) * p.ldr * 2) : 0x80000000u;
                 const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
                 res[mi][i] = __builtin_bit_cast(bf16x8, r);
             }
@@ -383,7 +387,7 @@ struct BgEpilogue {
                 const int m = bm * BM + wm * WM + mi * 32 + mrow;
                 if (m >= p.M) continue;
                 const float* bb = brow + wn * WN;
-                const float* br = brow + 128 + (p.rowbias ? (m / p.rows_per_sample - s_lo) * 128 : 0) + wn * WN;
+                const float* br = brow + 128 + ((ROWBIAS && p.rowbias) ? (m / p.rows_per_sample - s_lo) * 128 : 0) + wn * WN;
                 __bf16* orow = out + (size_t)m * p.ldc;
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
@@ -395,7 +399,7 @@ struct BgEpilogue {
                         for (int e = 0; e < 4; ++e) {
                             if (n + e >= p.N) break;
                             float v = acc[mi][ni][4 * g + e] * p.alpha + bb[c + e];
-                            if (p.rowbias) v += br[c + e];
+                            if (ROWBIAS && p.rowbias) v += br[c + e];
                             if (p.resid) v += (float)reinterpret_cast<const __bf16*>(p.resid)[(size_t)m * p.ldr + n + e];
                             if (p.relu) v = fmaxf(v, 0.f);
                             orow[n + e] = (__bf16)v;
@@ -409,6 +413,8 @@ struct BgEpilogue {
         const int wsw = swz(mrow);
         const int col = (lane % LPR) * 8;
         const int n = n0 + wn * WN + col;
+        unsigned ooff0 = (unsigned)(((wm * WM + lane / LPR) * p.ldc + n) * 2);
+        asm volatile("" : "+v"(ooff0));                    // as in prefetch(): recomputed per tile, not eight spilled invariants
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
@@ -431,7 +437,7 @@ struct BgEpilogue {
                 if (p.alpha != 1.0f) { y0 *= p.alpha; y1 *= p.alpha; }
                 y0 += *reinterpret_cast<const f32x4*>(bb);
                 y1 += *reinterpret_cast<const f32x4*>(bb + 4);
-                if (p.rowbias) {                                   // separately, in the order of the tile kernels: bit-identical results
+                if (ROWBIAS && p.rowbias) {                        // separately, in the order of the tile kernels: bit-identical results
                     const float* br = bb + 128 + (m < p.M ? (m / p.rows_per_sample - s_lo) * 128 : 0);
                     y0 += *reinterpret_cast<const f32x4*>(br);
                     y1 += *reinterpret_cast<const f32x4*>(br + 4);
@@ -447,7 +453,7 @@ struct BgEpilogue {
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y0[e]; o[4 + e] = (__bf16)y1[e]; }
-                const unsigned off = (m < p.M && n < p.N && !drop) ? (unsigned)(((wm * WM + mi * 32 + row) * p.ldc + n) * 2) : 0x80000000u;
+                const unsigned off = (m < p.M && n < p.N && !drop) ? ooff0 + (unsigned)((mi * 32 + RPI * i) * p.ldc * 2) : 0x80000000u;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ors, off, 0, 0);
             }
         }
