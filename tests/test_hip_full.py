@@ -206,33 +206,36 @@ def test_config0_bf16_mode_vs_the_bf16_run_of_the_oracle(full, config0):
 
 @pytest.mark.parametrize("B", [1, 3])
 def test_bf16_persistent_gemm_bit_identical_to_the_tile_kernels(full, B):
-    """bf16 mode has two implementations of the implicit GEMM: one workgroup per tile (bgemm_kernel) and persistent
-    workgroups that walk a tile list with the next tile's first stage in flight under the epilogue (bgemm_pers_kernel, the
-    default).  Same k order, same fp32 accumulation, same epilogue order => the whole UNet (every linear / conv shape of the
-    model, ragged row blocks at B = 3, time-embedding rows of two samples under one tile at the lower levels) and the VAE
-    decode must come out BIT-identical under both.  E2V_BGEMM_PERS is flipped through e2v_op_set_knob."""
+    """bf16 mode has several implementations of the implicit GEMM: one workgroup per 128-row tile (bgemm_kernel), per 256-row
+    tile (bgemm256_kernel), and persistent workgroups that walk a tile list with the next tile's first stage in flight under
+    the epilogue (bgemm_pers_kernel, the default where it measured faster).  Same k order, same fp32
+    accumulation, same epilogue order => the whole UNet (every linear / conv shape of the model, ragged row blocks at B = 3,
+    time-embedding rows of two samples under one tile at the lower levels) and a VAE decode must come out BIT-identical under
+    every combination.  The switches are flipped through e2v_op_set_knob."""
     pipe, _, _ = full
     eng = pipe.unet.engine
     lat = torch.stack([_t(counter_normal(4321 + k, "latent", (4, 6, 36, 64))) for k in range(B)]).cuda()
     cond = torch.stack([_t(counter_normal(4400 + k, "cond", (77, 768))) for k in range(B)]).cuda()
     ts = [501]
-    outs = {}
+    # (E2V_BGEMM_PERS, E2V_BGEMM_256): first entry = one workgroup per 128-row tile everywhere; 256 = 2: 256-row tiles for every conv
+    modes = [(0, 0), (2, 1), (1, 1), (0, 2), (2, 2)]
+    outs = []
     try:
         eng.set_compute_dtype("bf16")
-        for pers in (2, 1, 0):                                   # everywhere it applies / where it measured faster / nowhere
+        for pers, m256 in modes:
             eng.set_knob("E2V_BGEMM_PERS", pers)
-            eng.set_knob("E2V_BGEMM_PERS256", 1 if pers else 0)   # the 256-row tiles of the big 3x3 convs likewise
+            eng.set_knob("E2V_BGEMM_256", m256)
             eps = eng.unet_forward(lat, ts, cond)
             frames = eng.vae_decode((lat[:1, :, :2] * 0.5).contiguous())
             torch.cuda.synchronize()
-            outs[pers] = (eps.clone(), frames.clone())
+            outs.append((eps.clone(), frames.clone()))
     finally:
         eng.set_knob("E2V_BGEMM_PERS", 1)
-        eng.set_knob("E2V_BGEMM_PERS256", 1)
+        eng.set_knob("E2V_BGEMM_256", 1)
         eng.set_compute_dtype("fp32")
-    for pers in (2, 1):
-        for a, b, name in zip(outs[pers], outs[0], ("unet", "vae")):
+    for mode, out in zip(modes[1:], outs[1:]):
+        for a, b, name in zip(out, outs[0], ("unet", "vae")):
             assert torch.isfinite(a).all()
             diff = (a - b).abs().max().item()
-            print(f"B={B} {name}: E2V_BGEMM_PERS={pers} vs tile kernels max-abs diff {diff:.3e}")
-            assert torch.equal(a, b), name
+            print(f"B={B} {name}: PERS/256 = {mode} vs 128-row tile kernels max-abs diff {diff:.3e}")
+            assert torch.equal(a, b), (name, mode)
