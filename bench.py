@@ -172,6 +172,12 @@ def main() -> int:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args, argv)
 
+    # stdout carries ONE JSON line and nothing else: libraries below write banners to fd 1 (RCCL prints its version block there
+    # on init), so fd 1 is pointed at stderr for the run and the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -358,7 +364,8 @@ def main() -> int:
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "output_finite": finite,
             "gpu_over_cpu": (value / cpu["value"]) if cpu else None,
         }
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -68,6 +68,9 @@ def main(argv=None):
     neg = t(counter_normal(2, "neg", (1, scfg.tokens, ucfg.cross_attention_dim))).to(dev)
     stage = {"glmnet": 0.0, "seq2seq": 0.0, "semantic": 0.0, "dana": 0.0, "generate": 0.0, "uint8_d2h": 0.0, "write": 0.0}
     mine = []
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=max(1, min(8, len(os.sched_getaffinity(0)) - 2)))
+    pending = []
 
     def tick(name, t0):
         torch.cuda.synchronize()
@@ -113,12 +116,17 @@ def main(argv=None):
         tick("uint8_d2h", t0)
         mine.append(u8)
         if args.out:
-            t0 = time.perf_counter()
+            # the GIF encoder (Pillow's quantiser, ~0.45 s per clip on one core) runs on a worker pool while the GPU generates
+            # the next batch; "write" = the time the main thread spent waiting for it at the end
             for j, k in enumerate(ids):
                 name = f"{k // args.per_concept:02d}_{k % args.per_concept}" + (".npy" if args.npy else ".gif")
-                save_videos_grid(u8[j:j + 1], os.path.join(args.out, name))
-            stage["write"] += time.perf_counter() - t0
+                pending.append(pool.submit(save_videos_grid, u8[j:j + 1], os.path.join(args.out, name)))
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in pending:
+        f.result()
+    stage["write"] += time.perf_counter() - t0
+    pool.shutdown()
     elapsed = time.perf_counter() - t_all
     u8_all = torch.cat(mine) if mine else torch.zeros((0, 3, F, 8 * h, 8 * w), dtype=torch.uint8)
     if world > 1:
