@@ -652,6 +652,14 @@ __device__ __forceinline__ void bgemm_pers_body(const IgemmArgs& p, char* smem, 
     }
 }
 
+// (Two weight-stationary designs for the K <= 640 projections were built, validated and measured against the kernels above on a
+// B = 32 pass, and removed: a weight PANEL resident in LDS -- 80 KB, 256-row blocks of A streamed past it through a two-stage ring,
+// one 512-thread workgroup per CU, half the L2 -> LDS traffic -- ran 8-76 % SLOWER (one stage in flight per CU: 1.4 us per stage);
+// weights in REGISTERS -- 160 VGPRs per wave for K = 320, every wave streaming its own 32 rows through a private four-slot ring
+// with counted vmcnt and no barrier at all, 96 KB in flight per CU -- ran -7 % (GEGLU) .. +5 %: with the latency gone the same
+// 8-10 TB/s of L2 -> LDS traffic remain, because a 64-column wave panel re-reads A as often as 128 x 128 tiles re-read A and B.
+// DESIGN.md 3.5.)
+
 template <bool LIN>
 __global__ __launch_bounds__(256, 2) void bgemm_pers_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_bp[];

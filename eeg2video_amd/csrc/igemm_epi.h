@@ -322,6 +322,10 @@ struct BgEpilogue {
             }
     }
 
+    // WAIT false: no counted vmcnt at the end (the caller runs several finish() calls behind one DMA and waits once, for the sum
+    // of their stores: STORES each, when vec / geglu hold)
+    static constexpr int STORES = TM * NI, STORES_GEGLU = TM * 2;
+    template <bool WAIT = true>
     __device__ __forceinline__ void finish(const IgemmArgs& p, f32x16 (&acc)[TM][TN], __bf16* __restrict__ out, const int bm, const int n0,
                                            const int wm, const int wn, const int lane, float* st, const float* brow, const int s_lo) {
         const int mrow = lane & 31;
@@ -375,7 +379,7 @@ struct BgEpilogue {
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ors, off, 0, 0);
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM * 2) : "memory");
+                if constexpr (WAIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM * 2) : "memory");
                 return;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -457,7 +461,7 @@ struct BgEpilogue {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ors, off, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM * NI) : "memory");
+        if constexpr (WAIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM * NI) : "memory");
     }
 };
 

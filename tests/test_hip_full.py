@@ -208,16 +208,17 @@ def test_config0_bf16_mode_vs_the_bf16_run_of_the_oracle(full, config0):
 def test_bf16_persistent_gemm_bit_identical_to_the_tile_kernels(full, B):
     """bf16 mode has several implementations of the implicit GEMM: one workgroup per 128-row tile (bgemm_kernel), per 256-row
     tile (bgemm256_kernel), and persistent workgroups that walk a tile list with the next tile's first stage in flight under
-    the epilogue (bgemm_pers_kernel, the default where it measured faster).  Same k order, same fp32
-    accumulation, same epilogue order => the whole UNet (every linear / conv shape of the model, ragged row blocks at B = 3,
-    time-embedding rows of two samples under one tile at the lower levels) and a VAE decode must come out BIT-identical under
-    every combination.  The switches are flipped through e2v_op_set_knob."""
+    the epilogue (bgemm_pers_kernel, the default where it measured faster).  Same k order, same fp32 accumulation, same
+    epilogue order => the whole UNet (every linear / conv shape of the model, ragged row blocks at B = 3, time-embedding rows
+    of two samples under one tile at the lower levels) and a VAE decode must come out BIT-identical under every combination.
+    The switches are flipped through e2v_op_set_knob."""
     pipe, _, _ = full
     eng = pipe.unet.engine
     lat = torch.stack([_t(counter_normal(4321 + k, "latent", (4, 6, 36, 64))) for k in range(B)]).cuda()
     cond = torch.stack([_t(counter_normal(4400 + k, "cond", (77, 768))) for k in range(B)]).cuda()
     ts = [501]
-    # (E2V_BGEMM_PERS, E2V_BGEMM_256): first entry = one workgroup per 128-row tile everywhere; 256 = 2: 256-row tiles for every conv
+    # (E2V_BGEMM_PERS, E2V_BGEMM_256): first entry = one workgroup per 128-row tile everywhere; PERS = 2: wherever the kernel
+    # applies; 256 = 2: 256-row tiles for every conv; (1, 1) = the defaults
     modes = [(0, 0), (2, 1), (1, 1), (0, 2), (2, 2)]
     outs = []
     try:
