@@ -40,7 +40,7 @@ bool set_knob(const char* name, int value) {
     auto& t = knob_table();
     auto it = t.find(name);
     if (it == t.end()) {
-        static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_256", "E2V_BGEMM_LIN", "E2V_BGEMM_ABLATE"};
+        static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_S3", "E2V_BGEMM_256LIN", "E2V_BGEMM_256", "E2V_BGEMM_LIN", "E2V_BGEMM_ABLATE"};
         bool ok = false;
         for (const char* k : known) ok = ok || std::string(k) == name;
         if (!ok) return false;
@@ -54,7 +54,14 @@ bool set_knob(const char* name, int value) {
 // change, and a k-step is: eight LDS-DMA instructions whose k position rides in the scalar offset, one scalar add -- the
 // general (3x3) path spends ~130 scalar + vector instructions per k-step on the gather, which an in-order wave pays in issue
 // slots next to its 16 MFMAs.
-template <int BM, int BN, int WGM, int WGN, int STAGE = 128 * 128 * 2, bool LIN = false>      // STAGE: stage stride, sized for the largest tile of the launch
+template <class F, int... T>
+__device__ __forceinline__ void static_for_taps(F&& f, std::integer_sequence<int, T...>) {
+    (f(std::integral_constant<int, T>{}), ...);
+}
+
+// NST: LDS stages.  2: the next stage's DMA is in flight while this one is multiplied.  3 (one 512-thread workgroup per CU: nothing
+// else on the CU covers a wait): TWO stages in flight, the consumer waits with a counted vmcnt that leaves the younger one outstanding.
+template <int BM, int BN, int WGM, int WGN, int STAGE = 128 * 128 * 2, bool LIN = false, int NST = 2>      // STAGE: stage stride, sized for the largest tile of the launch
 __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, const int n0, char* smem) {
     constexpr int BKE = 64;                         // bf16 elements per stage
     constexpr int ROWB = 128;                       // bytes per LDS tile row
@@ -80,7 +87,7 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
     const int nk = p.taps * (steps0 + steps1);
 
     // gather table (see igemm.hip): source pixel of (tap, tile row), block-relative; ~0u = zero padding / row >= M
-    unsigned* tab = reinterpret_cast<unsigned*>(smem + 2 * STAGE);
+    unsigned* tab = reinterpret_cast<unsigned*>(smem + NST * STAGE);
     const int hw_out = p.Ho * p.Wo, hw_in = p.Hs * p.Ws;
     const int img0 = p.taps == 1 ? 0 : (bm * BM) / hw_out;
     const size_t row_base = p.taps == 1 ? (size_t)bm * BM : (size_t)img0 * hw_in;
@@ -250,6 +257,116 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[set][ni], af[set][mi], acc[mi][ni], 0, 0, 0);
     };
 
+    if constexpr (NST == 3 && LIN) {
+        // linears: nothing but the DMA and the fragment reads touches LDS in the loop; buffers rotate at run time
+        constexpr int PIECES = APW + BPW;                   // DMA instructions of one stage and wave
+        issue(0);
+        if (nk > 1) {
+            issue(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                       // stage 0 has landed for every wave
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(0, 0, 0);
+        int cb = 0;                                         // buffer of the stage being multiplied
+        for (int ks = 0; ks < nk; ++ks) {
+            const int nb1 = cb == 2 ? 0 : cb + 1, nb2 = nb1 == 2 ? 0 : nb1 + 1;
+            if (ks + 2 < nk) issue(nb2);                    // into the buffer consumed at step ks - 1 (every wave is past that barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(1, cb, 1);
+            mma(0);
+            read_frags(0, cb, 2);
+            mma(1);
+            read_frags(1, cb, 3);
+            mma(0);
+            if (ks + 1 < nk) {
+                // stage ks+1 has to have landed; stage ks+2 (if there is one) stays in flight
+                if (ks + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(0, nb1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma(1);
+            cb = nb1;
+        }
+        __syncthreads();                                    // the ring becomes the epilogue's staging area
+    } else if constexpr (NST == 3) {
+        // 3x3 convs only (taps == 9, general path): the k-loop is unrolled over the nine taps of a 64-channel chunk, so that the tap,
+        // the ring buffer of every step (9 = 3 x 3) and hence every LDS address are compile-time constants, and the source pixels of
+        // all nine taps sit in registers -- the loop reads no gather table (an LDS read behind an LDS-DMA makes the compiler wait
+        // for that DMA, which would put the two-stages-in-flight ring back to one)
+        static_assert(!LIN, "three-stage ring: 3x3 convs");
+        constexpr int PIECES = APW + BPW;                   // DMA instructions of one stage and wave
+        unsigned pixr[9][APW];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < APW; ++i) pixr[t][i] = tab[t * BM + a_row[i]];
+        auto issue_t = [&](auto Tc, auto Bc) {
+            constexpr int T = decltype(Tc)::value, BUF = decltype(Bc)::value;
+            char* Ab = smem + BUF * STAGE;
+            char* Bb = Ab + A_BYTES;
+            const __amdgpu_buffer_rsrc_t rsa = rsrc_of(k_src ? a1b : a0b);
+            const unsigned colb = (unsigned)k_cb * 2u;
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                const bool ok = (pixr[T][i] != ~0u) & (k_cb + (int)a_kc[i] * 8 < cseg);
+                const unsigned off = ok ? __umul24(pixr[T][i], (unsigned)ldb) + colb + a_kc[i] * 16u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(Ab + (wave * APW + i) * 1024), 16, off, 0, 0, 0);
+            }
+            const int cbase = (k_src ? p.c0 : 0) + k_cb;
+            const int koffb = ((cbase / BKE) * 9 + T) * BKE * 2;
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) {
+                const bool ok = k_cb + (int)b_kc[j] * 8 < cseg;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(Bb + (wave * BPW + j) * 1024), 16, ok ? b_off[j] : OOB, koffb, 0, 0);
+            }
+            if constexpr (T == 8) {                         // next chunk (then next source)
+                k_cb += BKE;
+                if (k_cb >= cseg && k_src == 0 && p.c1 > 0) { k_src = 1; k_cb = 0; cseg = p.c1; ldb = p.lda1 * 2; }
+            }
+        };
+        const int ngroups = steps0 + steps1;                // nk = 9 * ngroups
+        issue_t(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        issue_t(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        __builtin_amdgcn_s_barrier();                       // stage 0 has landed for every wave
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(0, 0, 0);
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const bool lastg = gi + 1 == ngroups;
+            auto step = [&](auto Tc) {
+                constexpr int T = decltype(Tc)::value;
+                constexpr int CB = T % 3, NB1 = (T + 1) % 3, NB2 = (T + 2) % 3;
+                const bool has2 = T + 2 < 9 || !lastg, has1 = T + 1 < 9 || !lastg;
+                // stage ks+2 into the buffer consumed at step ks-1 (every wave is past that step's barrier)
+                if (has2) issue_t(std::integral_constant<int, (T + 2) % 9>{}, std::integral_constant<int, NB2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(1, CB, 1);
+                mma(0);
+                read_frags(0, CB, 2);
+                mma(1);
+                read_frags(1, CB, 3);
+                mma(0);
+                if (has1) {
+                    // stage ks+1 has to have landed; stage ks+2 (if there is one) stays in flight
+                    if (has2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frags(0, NB1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mma(1);
+            };
+            static_for_taps(step, std::make_integer_sequence<int, 9>{});
+        }
+        __syncthreads();                                    // the ring becomes the epilogue's staging area
+    } else {
     issue(0);
     __syncthreads();                            // LDS-DMA is a pending LDS write: the fence waits for it (vmcnt(0))
     read_frags(0, 0, 0);
@@ -274,6 +391,7 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
         kstep(std::integral_constant<int, 1>{});
     }
     if (ks < nk) kstep(std::integral_constant<int, 0>{});
+    }
 
     if (p.out_f32) {
         float* __restrict__ out = p.out + (size_t)z * p.sout;
@@ -714,14 +832,45 @@ __global__ __launch_bounds__(512) void bgemm256_kernel(const IgemmArgs p) {
     }
 }
 
+// the same with a three-stage ring (144 KB of stages + the gather table: all of a CU's LDS)
+template <bool LIN>
+__global__ __launch_bounds__(512) void bgemm256s3_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bg256s3[];
+    constexpr int ST = (256 + 128) * 128;
+    const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
+    const int nrb = rb_hi - rb_lo;
+    const int tail = min(nrb, p.tail_rb);
+    const int per1 = p.w1 + p.s1;
+    const int n1 = (nrb - tail) * per1;
+    if (loc < n1) {
+        const int r = loc / per1, j = loc - r * per1;
+        if (j < p.w1) bgemm_tile<256, 128, 4, 2, ST, LIN, 3>(p, rb_lo + r, j * 128, smem_bg256s3);
+        else bgemm_tile<256, 64, 4, 2, ST, LIN, 3>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_bg256s3);
+    } else {
+        const int t = loc - n1;
+        if (t >= tail * p.s2) return;
+        const int r = t / p.s2;
+        bgemm_tile<256, 64, 4, 2, ST, LIN, 3>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_bg256s3);
+    }
+}
+
 bool bgemm_use_256(const IgemmArgs& a) {
     static const int* const modep = knob("E2V_BGEMM_256", 1);      // 0: never, 2: always
     const int mode = *modep;
     if (mode == 0) return false;
     if (mode == 2) return true;
-    // 3x3 convs only: their long k-loop (K >= 2880) is bound by the LDS fill rate, which the bigger tile relieves (+5-10 %);
-    // the linears' short k-loops lean on a second resident workgroup to cover prologue and epilogue (256-row tiles: -6..-20 %)
-    if (a.taps == 1) return false;
+    // 3x3 convs: one 512-thread workgroup per CU on a three-stage ring (two stages in flight) -- with two stages a workgroup that is
+    // alone on its CU pays an L2 round trip per 64-deep stage (matrix pipe 0.45 busy); 1150-1260 TFLOP/s on the big convs.
+    // Linears (same-box A/B over every shape of a B = 32 pass): the residual-free projections at K >= 640 (QKV, GEGLU, concat
+    // shortcuts) and K > 2560 gain 4-17 % on 256-row tiles; the ones with a residual to read are better off on the persistent
+    // kernel (256-row: +5..+18 %), and K = 320 is five stages deep -- nothing for a ring to do.  E2V_BGEMM_256LIN: that smallest K
+    // (0: no linear takes 256-row tiles)
+    if (a.taps == 1) {
+        static const int* const lin256 = knob("E2V_BGEMM_256LIN", 640);
+        const int Kc = a.c0 + a.c1;
+        if (*lin256 <= 0 || Kc < *lin256 || (a.resid && Kc <= 2560)) return false;
+    }
     // at least four rounds of 256 resident tiles, else the finer 128-row grid wastes less on its last round
     const double tiles = (double)((a.M + 255) / 256) * a.batch * ((a.N + 127) / 128);
     return tiles >= 4.0 * 256;
@@ -788,6 +937,19 @@ void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
         const int grid = ntiles < 512 ? ntiles : 512;                                             // two workgroups per CU
         if (lin) hipLaunchKernelGGL(bgemm_pers_kernel<true>, dim3(grid, 1, 1), dim3(256), smem_p, s, a);
         else hipLaunchKernelGGL(bgemm_pers_kernel<false>, dim3(grid, 1, 1), dim3(256), smem_p, s, a);
+        return;
+    }
+    static const int* const s3p = knob("E2V_BGEMM_S3", 1);          // 256-row tiles on a three-stage ring
+    if (a.bm256 && *s3p && (a.taps == 9 || lin)) {
+        constexpr size_t smem256s3 = (size_t)3 * (256 + 128) * 128 + 9 * 256 * sizeof(unsigned);
+        static bool cfg256s3 = false;
+        if (!cfg256s3) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm256s3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem256s3);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm256s3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem256s3);
+            cfg256s3 = true;
+        }
+        if (lin) hipLaunchKernelGGL(bgemm256s3_kernel<true>, dim3(ntiles, 1, 1), dim3(512), smem256s3, s, a);
+        else hipLaunchKernelGGL(bgemm256s3_kernel<false>, dim3(ntiles, 1, 1), dim3(512), smem256s3, s, a);
         return;
     }
     if (a.bm256) {
