@@ -40,7 +40,7 @@ bool set_knob(const char* name, int value) {
     auto& t = knob_table();
     auto it = t.find(name);
     if (it == t.end()) {
-        static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_S3", "E2V_BGEMM_256LIN", "E2V_BGEMM_256", "E2V_BGEMM_LIN", "E2V_BGEMM_ABLATE"};
+        static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_S3", "E2V_BGEMM_256LIN", "E2V_BGEMM_256_MINROUNDS", "E2V_BGEMM_256", "E2V_BGEMM_LIN", "E2V_BGEMM_ABLATE"};
         bool ok = false;
         for (const char* k : known) ok = ok || std::string(k) == name;
         if (!ok) return false;
@@ -871,9 +871,11 @@ bool bgemm_use_256(const IgemmArgs& a) {
         const int Kc = a.c0 + a.c1;
         if (*lin256 <= 0 || Kc < *lin256 || (a.resid && Kc <= 2560)) return false;
     }
-    // at least four rounds of 256 resident tiles, else the finer 128-row grid wastes less on its last round
+    // enough rounds of 256 resident tiles, else the finer 128-row grid wastes less on its last round
     const double tiles = (double)((a.M + 255) / 256) * a.batch * ((a.N + 127) / 128);
-    return tiles >= 4.0 * 256;
+    // (two rounds: with the three-stage ring the 256-row tile wins from there on -- level-3 convs -11 %; it was four with two stages)
+    static const int* const minr = knob("E2V_BGEMM_256_MINROUNDS", 2);
+    return tiles >= (double)*minr * 256;
 }
 
 // Launches whose tiles are all 128 x 64 (N <= 64, grids below one round, and -- E2V_BGEMM_N64_MAXK -- short-K layers): 24 KB
