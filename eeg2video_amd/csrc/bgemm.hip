@@ -832,6 +832,11 @@ __global__ __launch_bounds__(512) void bgemm256_kernel(const IgemmArgs p) {
     }
 }
 
+// (A variant with one A stage per KERNEL ROW -- the input pixels under output pixels m0-1 .. m0+256 fetched once per ky and read at
+// LDS rows r + kx by the three taps of that row, image-row ends zeroed in registers: activations fetched 3x instead of 9x, L2
+// requests -42 % -- was built, came out bit-identical, and ran at the SAME speed (1.576 ms against 1.577 ms on 640 -> 640 @ 18x32,
+// B = 32): with two stages in flight these kernels are not bound by what they fetch.  Removed)
+
 // the same with a three-stage ring (144 KB of stages + the gather table: all of a CU's LDS)
 template <bool LIN>
 __global__ __launch_bounds__(512) void bgemm256s3_kernel(const IgemmArgs p) {
