@@ -119,6 +119,15 @@ def test_create_rejects_head_dims_without_a_kernel(lib):
     lib.e2v_destroy(ctx)
 
 
+def test_run_time_switches_by_name(lib):
+    """e2v_op_set_knob: the switches of DESIGN section 10 by the name of their environment variable; unknown names are refused."""
+    assert lib.e2v_op_set_knob(b"E2V_BGEMM_PERS", 0) == _lib.E2V_OK
+    assert lib.e2v_op_set_knob(b"E2V_BGEMM_PERS", 1) == _lib.E2V_OK
+    assert lib.e2v_op_set_knob(b"E2V_BGEMM_256", 1) == _lib.E2V_OK
+    assert lib.e2v_op_set_knob(b"E2V_NO_SUCH_SWITCH", 1) == _lib.E2V_EINVAL
+    assert lib.e2v_op_set_knob(None, 1) == _lib.E2V_EINVAL
+
+
 def test_device_entry_points_refuse_host_only_context(lib, host_ctx):
     assert lib.e2v_finalize_weights(host_ctx, 1) == _lib.E2V_ESTATE
     assert b"host-only" in lib.e2v_last_error(host_ctx)
