@@ -160,6 +160,28 @@ def test_benchmark_and_odd_batches_equal_single_clip_calls(full, B):
         assert torch.equal(v1[0], vid[k]), k
 
 
+def test_bf16_mode_batches_equal_single_clip_calls(full):
+    """The same property in the bf16-activation mode, where the batch also decides which GEMM kernel a layer takes (128- or
+    256-row tiles, persistent or not): every kernel accumulates an output element over k in the same order, so a clip of a
+    batch of 5 must still be BIT-identical to the clip generated alone."""
+    pipe = full[0]
+    eng = pipe.unet.engine
+    B = 5
+    lat = torch.stack([_t(counter_normal(1234 + k, "latent", (4, 6, 36, 64))) for k in range(B)]).cuda()
+    cond = torch.stack([_t(counter_normal(1235 + 7919 * k, "cond", (77, 768))) for k in range(B)]).cuda()
+    unc = _t(counter_normal(1236, "uncond", (1, 77, 768))).cuda()
+    try:
+        eng.set_compute_dtype("bf16")
+        vid, lat_out = eng.generate(lat, cond, unc, 2, 12.5, 0.0, decode=True, return_latents=True)
+        assert vid.shape == (B, 3, 6, 288, 512) and torch.isfinite(vid).all()
+        for k in (0, B - 1):
+            v1, l1 = eng.generate(lat[k:k + 1], cond[k:k + 1], unc, 2, 12.5, 0.0, decode=True, return_latents=True)
+            assert torch.equal(l1[0], lat_out[k]), k
+            assert torch.equal(v1[0], vid[k]), k
+    finally:
+        eng.set_compute_dtype("fp32")
+
+
 def test_full_vae_encode_vs_oracle(full):
     """AutoencoderKL.encode at 288x512 (train_finetune_videodiffusion.py:264, generate_1200_latent.py:38) vs the oracle."""
     from oracle import vae_encode
