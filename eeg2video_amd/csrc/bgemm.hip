@@ -301,33 +301,56 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
         // for that DMA, which would put the two-stages-in-flight ring back to one)
         static_assert(!LIN, "three-stage ring: 3x3 convs");
         constexpr int PIECES = APW + BPW;                   // DMA instructions of one stage and wave
-        unsigned pixr[9][APW];
+        // per (tap, piece) the lane's complete byte offset into the current source -- pixel x row stride + its 16-byte chunk, or out of
+        // window -- so that a load is issued with NO vector arithmetic: the chunk's channel offset rides in the scalar offset.  (The
+        // in-order wave pays every vector instruction in issue slots next to its MFMAs: with all waits, barriers and A loads removed
+        // the loop still ran at 0.61 matrix-pipe busy.)  Recomputed from the LDS table when the source changes (concat).
+        unsigned aoff[9][APW];
+        auto load_aoff = [&](const unsigned ld2) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int i = 0; i < APW; ++i) pixr[t][i] = tab[t * BM + a_row[i]];
+                for (int i = 0; i < APW; ++i) {
+                    const unsigned pix = tab[t * BM + a_row[i]];
+                    aoff[t][i] = pix != ~0u ? __umul24(pix, ld2) + a_kc[i] * 16u : OOB;
+                }
+        };
+        load_aoff((unsigned)ldb);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         auto issue_t = [&](auto Tc, auto Bc) {
             constexpr int T = decltype(Tc)::value, BUF = decltype(Bc)::value;
             char* Ab = smem + BUF * STAGE;
             char* Bb = Ab + A_BYTES;
             const __amdgpu_buffer_rsrc_t rsa = rsrc_of(k_src ? a1b : a0b);
             const unsigned colb = (unsigned)k_cb * 2u;
-#pragma unroll
-            for (int i = 0; i < APW; ++i) {
-                const bool ok = (pixr[T][i] != ~0u) & (k_cb + (int)a_kc[i] * 8 < cseg);
-                const unsigned off = ok ? __umul24(pixr[T][i], (unsigned)ldb) + colb + a_kc[i] * 16u : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(Ab + (wave * APW + i) * 1024), 16, off, 0, 0, 0);
-            }
             const int cbase = (k_src ? p.c0 : 0) + k_cb;
             const int koffb = ((cbase / BKE) * 9 + T) * BKE * 2;
+            if (k_cb + BKE <= cseg) {                       // the chunk lies inside the segment (always, but for a 4- or 8-channel input)
 #pragma unroll
-            for (int j = 0; j < BPW; ++j) {
-                const bool ok = k_cb + (int)b_kc[j] * 8 < cseg;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(Bb + (wave * BPW + j) * 1024), 16, ok ? b_off[j] : OOB, koffb, 0, 0);
+                for (int i = 0; i < APW; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(Ab + (wave * APW + i) * 1024), 16, aoff[T][i], colb, 0, 0);
+#pragma unroll
+                for (int j = 0; j < BPW; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(Bb + (wave * BPW + j) * 1024), 16, b_off[j], koffb, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < APW; ++i) {
+                    const bool ok = k_cb + (int)a_kc[i] * 8 < cseg;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(Ab + (wave * APW + i) * 1024), 16, ok ? aoff[T][i] : OOB, colb, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < BPW; ++j) {
+                    const bool ok = k_cb + (int)b_kc[j] * 8 < cseg;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(Bb + (wave * BPW + j) * 1024), 16, ok ? b_off[j] : OOB, koffb, 0, 0);
+                }
             }
             if constexpr (T == 8) {                         // next chunk (then next source)
                 k_cb += BKE;
-                if (k_cb >= cseg && k_src == 0 && p.c1 > 0) { k_src = 1; k_cb = 0; cseg = p.c1; ldb = p.lda1 * 2; }
+                if (k_cb >= cseg && k_src == 0 && p.c1 > 0) {
+                    k_src = 1; k_cb = 0; cseg = p.c1; ldb = p.lda1 * 2;
+                    load_aoff((unsigned)ldb);               // (the table is not written after the tile's first barrier)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
             }
         };
         const int ngroups = steps0 + steps1;                // nk = 9 * ngroups
