@@ -403,9 +403,16 @@ static void decode_to_video(e2v_ctx* c, const float* z_cl, int B, int F, int h, 
     const int HW8 = 64 * h * w;
     const int C3 = c->cfg.vae_in_channels;
     Act frames(c->pool, (int64_t)B * F * HW8, C3);
-    for (int b = 0; b < B; ++b)        // one clip (F frames) per pass keeps the workspace at ~1 clip
-        c->vae_decode_frames(z_cl + (size_t)b * F * h * w * c->cfg.vae_latent_channels, F, h, w,
+    // frames are independent samples, so the grouping does not change a bit of the result.  fp32: one clip (F frames) per pass keeps
+    // the workspace at ~1 clip.  bf16 mode: four -- the 36x64 levels of ONE clip (M = 13 824 rows) are 432 tiles for 512 slots; 0.6 % of
+    // a B = 32 pass (same-box A/B; fp32: +-0), 0.9 GB per 288x512x128 bf16 tensor.  E2V_VAE_CLIPS_PER_PASS overrides both.
+    static const int forced = [] { const char* e = std::getenv("E2V_VAE_CLIPS_PER_PASS"); return e ? std::atoi(e) : 0; }();
+    const int group = forced > 0 ? forced : (c->bf16_compute ? 4 : 1);
+    for (int b = 0; b < B; b += group) {
+        const int nb = B - b < group ? B - b : group;
+        c->vae_decode_frames(z_cl + (size_t)b * F * h * w * c->cfg.vae_latent_channels, nb * F, h, w,
                              frames.p + (size_t)b * F * HW8 * C3, s);
+    }
     nchw_frames_to_ncfhw(frames.p, C3, videos, B, F, C3, HW8, post ? 0.5f : 1.0f, post ? 0.5f : 0.0f, post ? 1 : 0, s);
 }
 
