@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+T_PROC = time.time()           # (process age for the budget guard; refined from /proc below)
 TFLOP_UNET_SAMPLE = 2.962      # SURVEY.md App. B (2 x MAC, direct-conv count)
 TFLOP_VAE_CLIP = 8.448
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip table
@@ -60,6 +61,17 @@ def parse_args(argv):
                     help="fp32 = BASELINE configs[1] (default, the metric's configuration); bf16 = configs[2]")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--gather", default="fp32", choices=["fp32", "uint8"],
+                    help="what the ranks exchange and rank 0 copies to the host: the fp32 frames (the reference's .cpu().float(), default) or "
+                         "their uint8 form (save_videos_grid's (x * 255) truncation, done on the GPU: 4x fewer xGMI / PCIe bytes)")
+    ap.add_argument("--gather-impl", default="torch", choices=["torch", "cabi"],
+                    help="the all-gather through torch.distributed (default) or below the C ABI (e2v_allgather_frames on the library's own "
+                         "RCCL communicator; torch.distributed then only ships the 128-byte id)")
+    ap.add_argument("--no-configs2", action="store_true",
+                    help="skip the BASELINE configs[2] leg (bf16, B = 32) that a default fp32 run at N = 1 attaches to its JSON line")
+    ap.add_argument("--configs2-budget-s", type=float, default=455.0,
+                    help="run the configs[2] leg only if the process is younger than this when the fp32 part is done (the driver's limit "
+                         "is 600 s; the leg takes ~50 s and the CPU baseline ~65 s after it)")
     ap.add_argument("--dist-single", action="store_true",
                     help="N = 1 rehearsal of the collective: initialise the process group (world size 1) and run the frame "
                          "all-gather through it, so that the RCCL code path executes on a one-GPU box")
@@ -166,6 +178,102 @@ def cpu_baseline(pipe_gen, usd, vsd, ucfg, vcfg, ddim_steps, guidance):
         "frames_max_abs": frames_err, "final_latents_max_abs_over_max_ref": lat_err}
 
 
+def process_age_s() -> float:
+    try:
+        import psutil
+        return time.time() - psutil.Process().create_time()
+    except Exception:
+        return time.time() - T_PROC
+
+
+def instrumented_pass(eng, lat, cond, unc, ddim_steps, guidance, B, dtype, value_per_gpu, kernel_table_path=""):
+    """Roofline of the dominant kernel class: HIP events (on the launch stream, inside the library) around every launch of one
+    e2v_generate pass that is the timed workload itself.  Returns (roofline object, per-class table)."""
+    eng.profile_begin()
+    eng.generate(lat, cond, unc, ddim_steps, guidance, 0.0, decode=True)
+    table = eng.profile_end()
+    tot_ms = sum(v["ms"] for v in table.values())
+    for k, v in table.items():
+        v["avg_us"] = 1e3 * v["ms"] / max(v["launches"], 1)
+        v["tflops"] = v["flops"] / (v["ms"] * 1e9) if v["ms"] > 0 else 0.0
+        v["gbps"] = v["bytes"] / (v["ms"] * 1e6) if v["ms"] > 0 else 0.0
+        v["share"] = v["ms"] / tot_ms if tot_ms > 0 else 0.0
+    dom = max(table, key=lambda k: table[k]["ms"])
+    d = table[dom]
+    # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside the process, so this is the
+    # figure of the committed rocprofv3 --pmc passes over this very command (tools/profile_round.sh), used only when
+    # the configuration matches the one those passes ran
+    traffic, traffic_source = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
+    if os.path.isfile(pmc):
+        try:
+            rec = json.load(open(pmc))
+            ent = rec.get(dom, {})
+            if ent and ent.get("batch", 8) == B and ent.get("dtype", "fp32") == dtype:
+                traffic = ent.get("hbm_bytes_per_launch")
+                traffic_source = f"profiles/pmc_dominant_kernel.json (static: {rec.get('_source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes')})"
+        except Exception:
+            traffic = None
+    if dom in HBM_BOUND:
+        roof = {"bound": "hbm", "achieved": d["gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": d["gbps"] / PEAK_HBM_GBPS}
+    else:
+        # f32x3 executes 6 bf16 MFMA flops per fp32 flop counted: its fp32-equivalent ceiling is the bf16 peak / 6
+        peak = PEAK_BF16_MFMA_TFLOPS / 6 if "f32x3" in dom else PEAK_BF16_MFMA_TFLOPS if "bf16" in dom else PEAK_F32_MFMA_TFLOPS
+        roof = {"bound": "mfma", "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": d["tflops"] / peak}
+    roof.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": dom, "launches": d["launches"],
+                 "avg_launch_us": d["avg_us"], "flops_per_launch": d["flops"] / max(d["launches"], 1),
+                 "bytes_per_launch": d["bytes"] / max(d["launches"], 1), "share_of_gpu_time": d["share"],
+                 "sample": f"HIP events around every launch of one e2v_generate pass ({ddim_steps} DDIM steps + decode, B={B})",
+                 "whole_path_direct_conv_flops_over_f32_mfma_peak": value_per_gpu * (2 * ddim_steps * TFLOP_UNET_SAMPLE + TFLOP_VAE_CLIP) / PEAK_F32_MFMA_TFLOPS})
+    if kernel_table_path:
+        os.makedirs(os.path.dirname(os.path.abspath(kernel_table_path)), exist_ok=True)
+        json.dump(table, open(kernel_table_path, "w"), indent=1, sort_keys=True)
+    log(f"kernel classes (instrumented pass, {dtype} B={B}): " + ", ".join(
+        f"{k}: {v['share'] * 100:.1f}% {v['tflops']:.1f}TF {v['gbps']:.0f}GB/s" for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"])))
+    return roof, table
+
+
+def configs2_leg(eng, args, host_frames_u8=None):
+    """BASELINE configs[2] inside the default run: "1xMI355X: bf16 UNet3D with fp32 GroupNorm, batch=32" -- the same engine switched
+    to the bf16-activation mode, B = 32 fresh synthetic clips resident in HBM, a 2-step warm-up pass (builds the bf16 weight forms),
+    2 timed passes (e2v_generate + D2H of the fp32 frames, as the headline) and one event-instrumented pass."""
+    import numpy as np
+    import torch
+    from eeg2video_amd.weights import counter_normal
+    B = 32
+    dev = eng.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    lat = torch.stack([t(counter_normal(1234 + k, "latent", (4, 6, 36, 64))) for k in range(B)]).to(dev)
+    cond = torch.stack([t(counter_normal(1235 + 7919 * k, "cond", (77, 768))) for k in range(B)]).to(dev)
+    unc = t(counter_normal(1236, "uncond", (1, 77, 768))).to(dev)
+    host = torch.empty((B, 3, 6, 288, 512), dtype=torch.float32).pin_memory()
+    eng.set_compute_dtype("bf16")
+    try:
+        eng.generate(lat, cond, unc, 2, args.guidance, 0.0, decode=True)
+        torch.cuda.synchronize()
+        n = 2
+        t0 = time.perf_counter()
+        for _ in range(n):
+            frames = eng.generate(lat, cond, unc, args.ddim_steps, args.guidance, 0.0, decode=True)
+            host.copy_(frames, non_blocking=True)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        finite = bool(torch.isfinite(frames).all().item())
+        value = B * n / el
+        roof, _ = instrumented_pass(eng, lat, cond, unc, args.ddim_steps, args.guidance, B, "bf16", value,
+                                    (args.kernel_table + ".configs2.json") if args.kernel_table else "")
+    finally:
+        eng.set_compute_dtype("fp32")
+    return {"value": value, "unit": "clips/s", "ms_per_step": 1e3 * el / n, "steps": n, "warmup": "one 2-DDIM-step pass",
+            "dtype": "bf16", "output_finite": finite,
+            "config": {"workload": (f"1xMI355X: batch={B} synthetic latents [B,4,6,36,64] + [B,77,768] cond, {args.ddim_steps}-step DDIM, CFG "
+                                    f"{args.guidance}, 288x512x6 VAE decode, bf16 MFMA, bf16 activations in HBM, fp32 accumulate / norm "
+                                    "statistics / softmax (BASELINE configs[2])"),
+                       "clips_per_gpu": B, "unet_samples_per_ddim_step": 2 * B,
+                       "timed_region": "e2v_generate (inputs in HBM) + D2H of the fp32 frames into pinned host memory"},
+            "roofline": roof}
+
+
 def main() -> int:
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -226,7 +334,9 @@ def main() -> int:
     cond = torch.stack([t(counter_normal(1235 + 7919 * (rank * B + k), "cond", (77, 768))) for k in range(B)]).to(dev)
     unc = t(counter_normal(1236, "uncond", (1, 77, 768))).to(dev)
     # where the frames end up: the reference's `.cpu().float().numpy()` (pipeline_tuneeeg2video.py:183); rank 0 is the consumer
-    host_frames = torch.empty((world * B, 3, 6, 288, 512), dtype=torch.float32).pin_memory() if rank == 0 else None
+    as_u8 = args.gather == "uint8"
+    host_frames = torch.empty((world * B, 3, 6, 288, 512), dtype=torch.uint8 if as_u8 else torch.float32).pin_memory() if rank == 0 else None
+    gather_engine = eng if args.gather_impl == "cabi" else None
     if rank == 0:
         log(f"setup {time.perf_counter() - t_setup:.1f} s; device memory held {eng.device_bytes() / 2**30:.2f} GiB")
         if os.environ.get("E2V_LOG_MAPS"):       # profiling aid: where the runtime / tool libraries sit, so that a native backtrace can be attributed
@@ -242,7 +352,9 @@ def main() -> int:
     def step():
         frames = eng.generate(lat, cond, unc, args.ddim_steps, args.guidance, 0.0, decode=True)
         if use_dist:
-            frames = all_gather_frames(frames, force_collective=True)
+            frames = all_gather_frames(frames, as_uint8=as_u8, force_collective=True, engine=gather_engine)
+        elif as_u8:
+            frames = eng.frames_to_uint8(frames)
         if host_frames is not None:
             host_frames.copy_(frames, non_blocking=True)
         return frames
@@ -256,14 +368,21 @@ def main() -> int:
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
+    t_own = time.perf_counter() - t0
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    own_ms = None
     if use_dist:
+        # a rank's OWN time for its K steps (up to the sync, before the closing barrier): a straggler shows as a low per-rank rate
+        tt = torch.tensor([t_own], device=dev, dtype=torch.float64)
+        alls = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(alls, tt)
+        own_ms = [1e3 * float(a.item()) / args.steps for a in alls]
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
-    finite = bool(torch.isfinite(out).all().item())
+    finite = bool(torch.isfinite(out.float()).all().item())
     clips = world * B * args.steps
     value = clips / elapsed
 
@@ -275,11 +394,11 @@ def main() -> int:
         dist.barrier()
         t1 = time.perf_counter()
         for _ in range(3):
-            g = all_gather_frames(frames1, force_collective=True)
+            g = all_gather_frames(frames1, as_uint8=as_u8, force_collective=True, engine=gather_engine)
         torch.cuda.synchronize()
         gather_ms = 1e3 * (time.perf_counter() - t1) / 3
     else:
-        g = frames1
+        g = eng.frames_to_uint8(frames1) if as_u8 else frames1
     if host_frames is not None:
         t1 = time.perf_counter()
         for _ in range(3):
@@ -293,50 +412,23 @@ def main() -> int:
     if rank == 0:
         roof = None
         if not args.no_roofline:
-            # ---- roofline of the dominant kernel: HIP events around every launch of an instrumented pass --------
             if args.profile_ddim_steps <= 0:
                 args.profile_ddim_steps = args.ddim_steps
-            eng.profile_begin()
-            eng.generate(lat, cond, unc, args.profile_ddim_steps, args.guidance, 0.0, decode=True)
-            table = eng.profile_end()
-            tot_ms = sum(v["ms"] for v in table.values())
-            for k, v in table.items():
-                v["avg_us"] = 1e3 * v["ms"] / max(v["launches"], 1)
-                v["tflops"] = v["flops"] / (v["ms"] * 1e9) if v["ms"] > 0 else 0.0
-                v["gbps"] = v["bytes"] / (v["ms"] * 1e6) if v["ms"] > 0 else 0.0
-                v["share"] = v["ms"] / tot_ms if tot_ms > 0 else 0.0
-            dom = max(table, key=lambda k: table[k]["ms"])
-            d = table[dom]
-            # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside the process, so this is the
-            # figure of the committed rocprofv3 --pmc passes over this very command (tools/profile_round.sh), used only when
-            # the configuration matches the one those passes ran
-            traffic, traffic_source = None, None
-            pmc = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
-            if os.path.isfile(pmc):
+            roof, _ = instrumented_pass(eng, lat, cond, unc, args.profile_ddim_steps, args.guidance, B, args.dtype, value / world,
+                                        args.kernel_table)
+
+        # ---- BASELINE configs[2] (bf16, B = 32) as a second leg of the default run, inside the driver's wall-clock budget ----
+        configs2 = None
+        if world == 1 and args.dtype == "fp32" and not args.no_configs2 and not args.no_roofline and not use_dist:
+            age = process_age_s()
+            if age < args.configs2_budget_s:
+                log(f"configs[2] leg: process age {age:.0f} s < {args.configs2_budget_s:.0f} s, running")
                 try:
-                    rec = json.load(open(pmc))
-                    ent = rec.get(dom, {})
-                    if ent and ent.get("batch", 8) == B and ent.get("dtype", "fp32") == args.dtype:
-                        traffic = ent.get("hbm_bytes_per_launch")
-                        traffic_source = f"profiles/pmc_dominant_kernel.json (static: {rec.get('_source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes')})"
-                except Exception:
-                    traffic = None
-            if dom in HBM_BOUND:
-                roof = {"bound": "hbm", "achieved": d["gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": d["gbps"] / PEAK_HBM_GBPS}
+                    configs2 = configs2_leg(eng, args)
+                except Exception as e:      # the headline line must survive a failure of the extra leg; the reason is reported
+                    configs2 = {"skipped": f"failed: {type(e).__name__}: {e}"}
             else:
-                # f32x3 executes 6 bf16 MFMA flops per fp32 flop counted: its fp32-equivalent ceiling is the bf16 peak / 6
-                peak = PEAK_BF16_MFMA_TFLOPS / 6 if "f32x3" in dom else PEAK_BF16_MFMA_TFLOPS if "bf16" in dom else PEAK_F32_MFMA_TFLOPS
-                roof = {"bound": "mfma", "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": d["tflops"] / peak}
-            roof.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": dom, "launches": d["launches"],
-                         "avg_launch_us": d["avg_us"], "flops_per_launch": d["flops"] / max(d["launches"], 1),
-                         "bytes_per_launch": d["bytes"] / max(d["launches"], 1), "share_of_gpu_time": d["share"],
-                         "sample": f"HIP events around every launch of one e2v_generate pass ({args.profile_ddim_steps} DDIM steps + decode, B={B})",
-                         "whole_path_direct_conv_flops_over_f32_mfma_peak": (value / world) * (2 * args.ddim_steps * TFLOP_UNET_SAMPLE + TFLOP_VAE_CLIP) / PEAK_F32_MFMA_TFLOPS})
-            if args.kernel_table:
-                os.makedirs(os.path.dirname(os.path.abspath(args.kernel_table)), exist_ok=True)
-                json.dump(table, open(args.kernel_table, "w"), indent=1, sort_keys=True)
-            log("kernel classes (instrumented pass): " + ", ".join(
-                f"{k}: {v['share'] * 100:.1f}% {v['tflops']:.1f}TF {v['gbps']:.0f}GB/s" for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"])))
+                configs2 = {"skipped": f"process age {age:.0f} s >= budget {args.configs2_budget_s:.0f} s (the driver's limit is 600 s)"}
 
         cpu, parity = None, None
         if world == 1 and not args.no_cpu_baseline:
@@ -358,10 +450,13 @@ def main() -> int:
                        "clips_per_gpu": B, "ddim_steps": args.ddim_steps, "guidance_scale": args.guidance,
                        "unet_samples_per_ddim_step": 2 * B, "weights": "random-init SD-v1-4 architecture, counter RNG seed 42/43",
                        "timed_region": "e2v_generate (inputs in HBM)" + (" + all-gather of frames" if use_dist else "") +
-                                       " + D2H of the fp32 frames into pinned host memory (rank 0)",
-                       "collective": (f"{args.backend} all-gather of decoded frames over {rccl_ranks} rank(s)" if use_dist else "none")},
+                                       f" + D2H of the {args.gather} frames into pinned host memory (rank 0)",
+                       "collective": (f"{args.backend} all-gather of decoded frames ({args.gather}) over {rccl_ranks} rank(s)" if use_dist else "none")},
             "gather_ms": gather_ms, "d2h_ms": d2h_ms, "rccl_ranks": rccl_ranks if args.backend == "nccl" else 0,
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "output_finite": finite,
+            "gather": {"dtype": args.gather, "impl": ("e2v_allgather_frames (C ABI, library-owned RCCL communicator)" if args.gather_impl == "cabi"
+                                                      else f"torch.distributed ({args.backend})") if use_dist else "none"},
+            "per_rank_clips_per_s": ({"min": B * 1e3 / max(own_ms), "max": B * 1e3 / min(own_ms), "ms_per_step": own_ms} if own_ms else None),
+            "roofline": roof, "configs2": configs2, "cpu_baseline": cpu, "parity": parity, "output_finite": finite,
             "gpu_over_cpu": (value / cpu["value"]) if cpu else None,
         }
         sys.stdout.flush()

@@ -42,6 +42,7 @@ _i, _f, _i64, _p = C.c_int, C.c_float, C.c_int64, C.c_void_p
 #: every symbol the two headers declare: name -> (restype, argtypes)
 SIGNATURES = {
     "e2v_default_config": (None, [C.POINTER(E2VConfig)]),
+    "e2v_config_size": (_i64, []),
     "e2v_version": (C.c_char_p, []),
     "e2v_create": (_i, [C.POINTER(E2VConfig), _i, C.POINTER(_ctx)]),
     "e2v_destroy": (None, [_ctx]),
@@ -70,6 +71,11 @@ SIGNATURES = {
     "e2v_set_compute_dtype": (_i, [_ctx, _i]),
     "e2v_set_conv_algo": (_i, [_ctx, _i]),
     "e2v_device_bytes": (_i64, [_ctx]),
+    "e2v_comm_unique_id": (_i, [_p]),
+    "e2v_comm_init": (_i, [_ctx, _p, _i, _i]),
+    "e2v_comm_world": (_i, [_ctx]),
+    "e2v_allgather_frames": (_i, [_ctx, _p, _i64, _i, _p, _stream]),
+    "e2v_comm_destroy": (_i, [_ctx]),
     "e2v_profile_begin": (_i, [_ctx]),
     "e2v_profile_end": (_i64, [_ctx, C.c_char_p, _i64]),
     # eeg2video_hip_ops.h
@@ -107,5 +113,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.e2v_config_size() != C.sizeof(E2VConfig):
+        raise ImportError(f"{LIB_PATH}: e2v_config is {lib.e2v_config_size()} bytes in the library, {C.sizeof(E2VConfig)} in this binding "
+                          "(include/eeg2video_hip.h and eeg2video_amd/_lib.py disagree)")
     _lib = lib
     return lib

@@ -90,6 +90,8 @@ void e2v_default_config(e2v_config* c) {
     c->sem_in_features = 310; c->sem_hidden = 10000; c->sem_tokens = 77;
 }
 
+int64_t e2v_config_size(void) { return (int64_t)sizeof(e2v_config); }
+
 const char* e2v_version(void) { return "eeg2video_hip 0.1 (gfx950, fp32 MFMA)"; }
 
 e2v_status e2v_create(const e2v_config* cfg, int device, e2v_ctx** out) {
@@ -138,6 +140,7 @@ void e2v_destroy(e2v_ctx* c) {
     if (c->device < 0) { delete c; return; }
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    (void)e2v_comm_destroy(c);
     for (auto& kv : c->raw) if (kv.second.d) (void)hipFree(kv.second.d);
     for (float* p : c->owned) (void)hipFree(p);
     for (auto& part : c->owned_part) for (float* p : part) (void)hipFree(p);
@@ -507,8 +510,9 @@ e2v_status e2v_generate(e2v_ctx* c, const float* latents, const float* cond, con
             ddim_coeffs(c, ts[i], ts[i] - ratio, co);
             ddim_cfg_step(eps.p, cfg_on ? eps.p + per * B : nullptr, x.p, x.p, (long long)(per * B), guidance, co[0], co[1],
                           co[2], co[3], s);                                      // :320-325
-            // profiling aid: rocprofv3 --pmc (ROCm 7.2) segfaults in its dispatch hook once ~8k launches are queued
-            // behind each other; E2V_SYNC_EACH_STEP=1 drains the stream after every DDIM step (never set in a timed run)
+            // profiling aid: under rocprofv3 --pmc (ROCm 7.2) rocprofiler-sdk's queue-intercept callback faulted with a whole pass
+            // (~34 000 launches, ~680 per DDIM step) queued behind the GPU (profiles/r02_pmc_async_abort_README.md names the frames);
+            // E2V_SYNC_EACH_STEP=1 drains the stream after every DDIM step.  Read once per process; never set in a timed run
             static const bool sync_each = [] { const char* e = std::getenv("E2V_SYNC_EACH_STEP"); return e && std::atoi(e) != 0; }();
             if (sync_each) E2V_HIP(hipStreamSynchronize(s));
         }

@@ -15,6 +15,7 @@
 #include "igemm_epi.h"
 #include "prof.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 
@@ -40,7 +41,11 @@ bool set_knob(const char* name, int value) {
     auto& t = knob_table();
     auto it = t.find(name);
     if (it == t.end()) {
-        static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_S3", "E2V_BGEMM_256LIN", "E2V_BGEMM_256_MINROUNDS", "E2V_BGEMM_256", "E2V_BGEMM_LIN", "E2V_BGEMM_ABLATE"};
+        static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_S3", "E2V_BGEMM_256LIN", "E2V_BGEMM_256_MINROUNDS", "E2V_BGEMM_256", "E2V_BGEMM_LIN", "E2V_BGEMM_T256"
+#ifdef E2V_ABLATE
+                                            , "E2V_BGEMM_ABLATE"
+#endif
+        };
         bool ok = false;
         for (const char* k : known) ok = ok || std::string(k) == name;
         if (!ok) return false;
@@ -927,7 +932,8 @@ bool bgemm_all_n64(const IgemmArgs& a) {
     return (a.c0 + a.c1) <= maxk && !a.geglu;
 }
 
-void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
+void bgemm_launch(const IgemmArgs& a_in, int ntiles, hipStream_t s) {
+    IgemmArgs a = a_in;
     constexpr size_t smem = (size_t)2 * 128 * 128 * 2 + 9 * 128 * sizeof(unsigned);     // two stages of (128 + 128) rows + gather table
     static bool configured = false;
     if (!configured) {
@@ -944,8 +950,15 @@ void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s) {
         pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t" + std::to_string(a.taps) +
                  (a.stride > 1 ? " s2" : "") + (a.upsample ? " up" : "") + (a.c1 ? " cat" : "") + (a.geglu ? " geglu" : "") +
                  (a.batch > 1 ? " b" + std::to_string(a.batch) : "");
+#ifdef E2V_ABLATE
+    // timing experiments (make EXTRA=-DE2V_ABLATE): drop the output stores / zero the A loads -- the results are WRONG, so the
+    // switch does not exist in the shipped build
     static const int* const ablate = knob("E2V_BGEMM_ABLATE", 0);
-    const_cast<IgemmArgs&>(a).ablate = *ablate;
+    a.ablate = *ablate;
+    if (a.ablate) { static bool said = false; if (!said) { said = true; fprintf(stderr, "libeeg2video_hip: E2V_BGEMM_ABLATE=%d -- GEMM RESULTS ARE WRONG (timing build)\n", a.ablate); } }
+#else
+    a.ablate = 0;
+#endif
     const double out_b = a.out_f32 ? 4.0 : 2.0;
     ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
                  a.batch * (2.0 * rows_in * (a.c0 + a.c1) + 2.0 * a.N * K + out_b * a.M * (a.geglu ? a.N / 2 : a.N)), s);

@@ -126,6 +126,7 @@ struct e2v_ctx {
     // device blocks made by finalize(), per part (bit index of `which`), so that finalizing a part again frees what it replaces
     std::vector<float*> owned_part[3];
     std::unordered_map<void*, size_t> owned_bytes;
+    void* comm = nullptr; int comm_rank = 0, comm_world = 0;     // RCCL communicator of e2v_comm_init (comm.cpp)
     int alloc_part = -1;                                         // >= 0: dev_alloc files the block under owned_part[alloc_part]
     void free_part(int part);
 

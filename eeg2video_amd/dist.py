@@ -30,11 +30,18 @@ def frames_to_uint8(frames: torch.Tensor) -> torch.Tensor:
 
 
 def all_gather_frames(frames: torch.Tensor, group: Optional[dist.ProcessGroup] = None, as_uint8: bool = False,
-                      force_collective: bool = False) -> torch.Tensor:
+                      force_collective: bool = False, engine=None) -> torch.Tensor:
     """Every rank contributes ``[b_r, 3, F, H, W]`` (``b_r`` may differ by one between ranks) and receives the
     clips of all ranks in rank order, ``[sum b_r, 3, F, H, W]``.  Single-process: returns the input, unless
     ``force_collective`` asks for the collective to run even over a one-rank group (``bench.py --dist-single``: the RCCL
-    code path on a one-GPU box)."""
+    code path on a one-GPU box).
+
+    ``engine``: run the exchange BELOW the C ABI -- ``e2v_allgather_frames`` on the library's own RCCL communicator
+    (``Engine.comm_init``; ``torch.distributed`` then only ships the 128-byte communicator id), with the uint8 conversion fused in
+    front of it.  Needs the same ``b`` on every rank (the benchmark's and the sweep's full batches)."""
+    if engine is not None and dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective):
+        engine.comm_init(group)
+        return engine.allgather_frames(frames, as_uint8=as_uint8)
     x = frames_to_uint8(frames) if as_uint8 else frames
     if not (dist.is_available() and dist.is_initialized()):
         return x

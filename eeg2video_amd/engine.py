@@ -322,6 +322,38 @@ class Engine:
         self._check(self.lib.e2v_frames_to_uint8(self.ctx, v.data_ptr(), out.data_ptr(), v.numel(), _stream()))
         return out
 
+    # ------------------------------------------------------------------ the one exchange of the path
+    def comm_init(self, group=None) -> int:
+        """Open the library's own RCCL communicator over the ranks of the (already initialised) ``torch.distributed`` group:
+        rank 0 draws the id, ``torch.distributed`` only ships its 128 bytes.  Returns the world size."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if self.lib.e2v_comm_world(self.ctx) == world:
+            return world
+        buf = (C.c_ubyte * 128)()
+        if rank == 0:
+            if self.lib.e2v_comm_unique_id(buf) != _lib.E2V_OK:
+                raise RuntimeError("e2v_comm_unique_id failed (is librccl.so loadable?)")
+        ids = [bytes(buf)]
+        dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = (C.c_ubyte * 128).from_buffer_copy(ids[0])
+        self._check(self.lib.e2v_comm_init(self.ctx, raw, rank, world))
+        return world
+
+    def comm_destroy(self) -> None:
+        self._check(self.lib.e2v_comm_destroy(self.ctx))
+
+    def allgather_frames(self, frames: torch.Tensor, as_uint8: bool = False) -> torch.Tensor:
+        """``[b,3,F,H,W]`` fp32 frames of this rank -> ``[world*b,3,F,H,W]`` of all ranks (fp32 or uint8), one ``ncclAllGather``
+        issued by the library on the current stream; every rank must hold the same ``b``."""
+        world = self.lib.e2v_comm_world(self.ctx)
+        if world <= 0:
+            raise RuntimeError("allgather_frames: no communicator (Engine.comm_init first)")
+        v = self._dev(frames, "frames")
+        out = torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), device=self.device, dtype=torch.uint8 if as_uint8 else torch.float32)
+        self._check(self.lib.e2v_allgather_frames(self.ctx, v.data_ptr(), v.numel(), int(as_uint8), out.data_ptr(), _stream()))
+        return out
+
     # ------------------------------------------------------------------ kernel-level ops (channel-last tensors)
     def op_conv3x3(self, x0, w, bias=None, x1=None, *, n_img, Hs, Ws, Hi=None, Wi=None, stride=1, pad_lo=1, pad_hi=1,
                    rowbias=None, rows_per_sample=1, resid=None):

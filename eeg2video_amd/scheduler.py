@@ -414,17 +414,26 @@ SCHEDULERS = {
 
 
 def scheduler_from_config(config: dict, engine=None):
-    """Build the mirror a ``scheduler/scheduler_config.json`` names; unknown keys (``_diffusers_version``, ``trained_betas``:
-    null, ...) are dropped, keys the mirror does not accept raise as the class itself would."""
+    """Build the mirror a ``scheduler/scheduler_config.json`` names.  Keys that only describe the file (``_class_name``,
+    ``_diffusers_version``) are dropped; a key that CHANGES THE ARITHMETIC and is set to something this build does not implement
+    raises ``NotImplementedError`` whether or not the mirror's constructor knows the key (a ``v_prediction`` DDIM config must
+    not load silently as epsilon prediction); any other key the mirror does not model is dropped."""
     import inspect
     name = config.get("_class_name", "DDIMScheduler")
     if name not in SCHEDULERS:
         raise ValueError(f"scheduler class {name!r} is not one of {sorted(SCHEDULERS)}")
     cls = SCHEDULERS[name]
+    #: key -> the only value(s) implemented (diffusers 0.11.1 defaults of the Stable-Diffusion configs)
+    only = {"prediction_type": ("epsilon",), "trained_betas": (None,), "thresholding": (False,), "set_alpha_to_one": (False,),
+            "beta_schedule": ("scaled_linear",), "variance_type": (None, "fixed_small"),
+            "rescale_betas_zero_snr": (False,), "timestep_spacing": ("leading",), "use_karras_sigmas": (False,)}
+    for k, ok in only.items():
+        if k in config and config[k] not in ok:
+            raise NotImplementedError(f"{name}: {k}={config[k]!r} is not implemented on this path (supported: {ok})")
     params = inspect.signature(cls.__init__).parameters
     kw = {k: v for k, v in config.items() if k in params and not k.startswith("_")}
-    if config.get("trained_betas") is not None:
-        raise NotImplementedError("trained_betas is not supported")
+    if kw.get("clip_sample"):          # the pipeline's constructor overrides it (pipeline_tuneeeg2video.py:73-84: "clip_sample ... set to False")
+        kw["clip_sample"] = False
     return cls(engine=engine, **kw)
 
 

@@ -19,6 +19,17 @@ from .engine import Engine
 from .weights import UNetConfig, VAEConfig, synth_state_dict, unet_param_spec
 
 WEIGHTS_NAME = "diffusion_pytorch_model.bin"      # diffusers.utils.WEIGHTS_NAME (unet.py:439-441)
+SAFETENSORS_NAME = "diffusion_pytorch_model.safetensors"
+
+
+def _load_checkpoint(path: str) -> dict:
+    """State dict of a diffusers-layout model directory: the ``.safetensors`` file when there is one, else the ``.bin`` unpickled
+    with ``weights_only=True`` (a state dict of tensors needs nothing more; a checkpoint directory is user-supplied input)."""
+    st = os.path.join(path, SAFETENSORS_NAME)
+    if os.path.isfile(st):
+        from safetensors.torch import load_file
+        return dict(load_file(st, device="cpu"))
+    return torch.load(os.path.join(path, WEIGHTS_NAME), map_location="cpu", weights_only=True)
 
 
 class FrozenDict(dict):
@@ -135,6 +146,41 @@ class UNet3DConditionModel:
     def requires_grad_(self, flag: bool = False):
         return self
 
+    # -- memory knobs of the reference object: accepted, validated as the reference validates them, and without effect --------
+    def set_attention_slice(self, slice_size="auto"):
+        """``unet.py:209-272``.  Sliced attention trades speed for the memory of the ``[heads, N, 2N]`` score tensor; the fused
+        attention kernels never materialise that tensor, so there is nothing to slice.  The argument checks (one entry per
+        attention layer -- attn1, attn2, attn_temp of the 16 transformer blocks -- each at most the head count) are the
+        reference's, with its messages."""
+        n_blocks = sum(1 for t in self.ucfg.down_block_types if t.startswith("CrossAttn")) * self.ucfg.layers_per_block + 1 + \
+            sum(1 for t in self.ucfg.up_block_types if t.startswith("CrossAttn")) * (self.ucfg.layers_per_block + 1)
+        dims = [self.ucfg.attention_head_dim] * (3 * n_blocks)
+        if slice_size == "auto":
+            slice_size = [d // 2 for d in dims]
+        elif slice_size == "max":
+            slice_size = len(dims) * [1]
+        slice_size = len(dims) * [slice_size] if not isinstance(slice_size, list) else slice_size
+        if len(slice_size) != len(dims):
+            raise ValueError(
+                f"You have provided {len(slice_size)}, but {self.config} has {len(dims)} different"
+                f" attention layers. Make sure to match `len(slice_size)` to be {len(dims)}."
+            )
+        for size, dim in zip(slice_size, dims):
+            if size is not None and size > dim:
+                raise ValueError(f"size {size} has to be smaller or equal to {dim}.")
+        self._attention_slice = list(slice_size)
+
+    def enable_gradient_checkpointing(self):
+        """``ModelMixin.enable_gradient_checkpointing`` -> ``_set_gradient_checkpointing`` (``unet.py:274-276``): a training-time
+        memory knob; this object only runs inference."""
+        self.gradient_checkpointing = True
+
+    def disable_gradient_checkpointing(self):
+        self.gradient_checkpointing = False
+
+    def enable_xformers_memory_efficient_attention(self, *a, **k):      # train_finetune_videodiffusion.py:130-134
+        return None
+
     def state_dict_spec(self):
         return unet_param_spec(self.ucfg)
 
@@ -169,9 +215,9 @@ class UNet3DConditionModel:
         names = set(inspect.signature(cls.__init__).parameters) - {"self"}
         model = cls(**{k: v for k, v in config.items() if k in names}, **kw)
         model_file = os.path.join(path, WEIGHTS_NAME)
-        if not os.path.isfile(model_file):
+        if not os.path.isfile(model_file) and not os.path.isfile(os.path.join(path, SAFETENSORS_NAME)):
             raise RuntimeError(f"{model_file} does not exist")                                    # unet.py:442-443
-        sd = torch.load(model_file, map_location="cpu")
+        sd = _load_checkpoint(path)
         if inflate_2d:                                                                            # unet.py:445-447
             spec = model.state_dict_spec()
             fresh = synth_state_dict({k: s for k, s in spec.items() if "_temp." in k}, mode="reference_init")

@@ -128,14 +128,10 @@ class AutoencoderKL:
             raise RuntimeError(f"the engine was created for a VAE of {engine.vae_cfg}, the checkpoint holds {config}: create the UNet "
                                "with vae_config=AutoencoderKL.config_from_dir(<dir>/vae)")
         model = cls(config, engine=engine, unet_config=unet_config, device=device)
-        bin_file, st_file = os.path.join(path, "diffusion_pytorch_model.bin"), os.path.join(path, "diffusion_pytorch_model.safetensors")
-        if os.path.isfile(bin_file):
-            sd = torch.load(bin_file, map_location="cpu")
-        elif os.path.isfile(st_file):
-            from safetensors.torch import load_file
-            sd = load_file(st_file)
-        else:
-            raise RuntimeError(f"{bin_file} does not exist")
+        from .unet import SAFETENSORS_NAME, WEIGHTS_NAME, _load_checkpoint
+        if not os.path.isfile(os.path.join(path, WEIGHTS_NAME)) and not os.path.isfile(os.path.join(path, SAFETENSORS_NAME)):
+            raise RuntimeError(f"{os.path.join(path, WEIGHTS_NAME)} does not exist")
+        sd = _load_checkpoint(path)          # .safetensors preferred; .bin with weights_only=True
         return model.load_state_dict(sd)
 
     def decode(self, z: torch.Tensor, return_dict: bool = True):

@@ -20,7 +20,8 @@ import numpy as np
 import torch
 
 
-def main(argv=None):
+def main(argv=None, engine=None):
+    """``engine``: an already built full-size ``Engine`` (tests reuse one; its semantic-predictor weights are (re)loaded here)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiny", action="store_true")
     ap.add_argument("--concepts", type=int, default=40)
@@ -50,11 +51,17 @@ def main(argv=None):
                         else (UNetConfig(), VAEConfig(), SemanticConfig()))
     F, h, w = (3, 4, 6) if args.tiny else (6, 36, 64)
     t_setup = time.perf_counter()
-    eng = Engine(ucfg, vcfg, local, sem_cfg=scfg)
-    eng.load_state_dict(synth_state_dict(unet_param_spec(ucfg), seed=42, mode="reference_init"))
-    eng.load_state_dict(synth_state_dict(vae_param_spec(vcfg), seed=43, mode="reference_init"), prefix="vae.")
-    eng.finalize(Engine.UNET | Engine.VAE)
-    sem = CLIP(scfg, engine=eng).init_synthetic(44)
+    if engine is not None:
+        eng = engine
+    else:
+        eng = Engine(ucfg, vcfg, local, sem_cfg=scfg)
+        eng.load_state_dict(synth_state_dict(unet_param_spec(ucfg), seed=42, mode="reference_init"))
+        eng.load_state_dict(synth_state_dict(vae_param_spec(vcfg), seed=43, mode="reference_init"), prefix="vae.")
+        eng.finalize(Engine.UNET | Engine.VAE)
+    sem = CLIP(scfg, engine=eng)
+    if getattr(eng, "_sweep_sem_seed", None) != 44:                 # (a reused engine keeps the 0.89 G synthetic parameters)
+        sem.init_synthetic(44)
+        eng._sweep_sem_seed = 44
     eng.set_compute_dtype(args.dtype)
     dev = eng.device
     torch.manual_seed(0)

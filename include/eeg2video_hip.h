@@ -72,6 +72,10 @@ typedef struct {
 } e2v_config;
 
 void e2v_default_config(e2v_config* cfg);
+/* sizeof(e2v_config) as THIS build of the library sees it: a binding that declares the struct itself (ctypes, cgo, JNA ...) asserts
+ * its own size against this before the first e2v_default_config / e2v_create, so that a stale field list fails loudly instead
+ * of having the library write past the caller's object. */
+int64_t e2v_config_size(void);
 const char* e2v_version(void);
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -199,6 +203,21 @@ e2v_status e2v_dana_noise(e2v_ctx* ctx, const float* x0, const float* eps_div, c
  * util.py:29) on the device, so that frames cross xGMI / PCIe as 1 byte per sample: videos in [0,1] -> uint8. */
 e2v_status e2v_frames_to_uint8(e2v_ctx* ctx, const float* videos, uint8_t* out, int64_t count, e2v_stream stream);
 
+/* ---- multi-GPU: the one exchange of the path ------------------------------------------------------------------
+ * replaces: nothing in the reference (it generates its 200 clips serially on one GPU, inference_eeg2video.py:90); clips shard
+ * over one process per GPU with no data-path exchange, and the decoded frames of all ranks are gathered at the end.  The
+ * library opens its own RCCL communicator: rank 0 draws an id (128 bytes, HOST memory), the host side ships it to the other
+ * ranks by any channel it has, every rank calls e2v_comm_init (collective: returns when all `world` ranks have called it).
+ * RCCL is resolved at run time from the librccl already in the process (else the ROCm one): E2V_ESTATE if there is none. */
+e2v_status e2v_comm_unique_id(void* id128_host);
+e2v_status e2v_comm_init(e2v_ctx* ctx, const void* id128_host, int rank, int world);
+int e2v_comm_world(const e2v_ctx* ctx);                 /* 0: no communicator */
+/* `frames`: this rank's `count` floats (e.g. [b,3,F,H,W], the same count on every rank); `out`: world * count elements, rank r's
+ * shard at offset r * count -- fp32, or (as_uint8) the (x * 255) truncation save_videos_grid applies (tuneavideo/util.py:29), a
+ * quarter of the xGMI bytes.  One ncclAllGather on `stream`; does not synchronise. */
+e2v_status e2v_allgather_frames(e2v_ctx* ctx, const float* frames, int64_t count, int as_uint8, void* out, e2v_stream stream);
+e2v_status e2v_comm_destroy(e2v_ctx* ctx);              /* also done by e2v_destroy */
+
 /* Per-kernel-class timing with HIP events on the launch stream (used by bench.py for the roofline figures).
  * Between begin and end every kernel launch of the library is bracketed by an event pair and tagged with its
  * algorithmic flops / bytes.  e2v_profile_end synchronises and writes a JSON object
@@ -207,9 +226,11 @@ e2v_status e2v_frames_to_uint8(e2v_ctx* ctx, const float* videos, uint8_t* out, 
 e2v_status e2v_profile_begin(e2v_ctx* ctx);
 int64_t e2v_profile_end(e2v_ctx* ctx, char* json, int64_t cap);
 
-/* Arithmetic of the convolutions / linears (everything else stays fp32): E2V_F32 (default; fp32 MFMA, the parity
- * configuration of BASELINE configs[1]) or E2V_BF16 (BASELINE configs[2]: bf16 MFMA with fp32 accumulation, fp32
- * activations in HBM, fp32 GroupNorm / LayerNorm / softmax).  Takes effect for the following calls.
+/* Arithmetic and storage of the graph's tensors: E2V_F32 (default; fp32 MFMA, fp32 activations, the parity configuration of
+ * BASELINE configs[1]) or E2V_BF16 (BASELINE configs[2]: every tensor the graph stores between kernels is bf16 in HBM, bf16
+ * MFMA with fp32 accumulation; what stays fp32: the latents / DDIM state, eps, the decoded frames, VAE moments and attention
+ * scores, GroupNorm / LayerNorm statistics, softmax, the time-embedding MLP).  The boundary tensors of this header are fp32 in
+ * both modes.  Takes effect for the following calls.
  * E2V_F32X3 (opt-in, experimental): fp32 results from the bf16 matrix pipe -- every operand of a linear / Winograd-domain
  * GEMM is split exactly into three bf16 pieces and the six significant piece products are accumulated in fp32 (error at
  * the level of the fp32 FMA chain); must be selected BEFORE e2v_finalize_weights (the weights are split there), else

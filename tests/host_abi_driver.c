@@ -11,6 +11,7 @@
 
 int main(void) {
     e2v_config cfg;
+    CHECK(e2v_config_size() == (int64_t)sizeof(e2v_config));   /* header and library agree on the struct */
     e2v_default_config(&cfg);
     CHECK(cfg.block_out_channels[0] == 320 && cfg.cross_attention_dim == 768 && cfg.num_train_timesteps == 1000);
     e2v_ctx* ctx = NULL;

@@ -60,3 +60,11 @@ def test_host_cores_is_capped_by_affinity(bench):
     hc = bench.host_cores()
     assert 1 <= hc["cores"] <= hc["affinity"] <= (hc["os_cpu_count"] or 10**6)
     assert isinstance(hc["cpu_model"], str)
+
+
+def test_gather_options_and_budget_guard_parse(bench):
+    a = bench.parse_args(["--gpus", "8", "--dtype", "bf16", "--batch", "32", "--gather", "uint8", "--gather-impl", "cabi"])
+    assert (a.gpus, a.dtype, a.batch, a.gather, a.gather_impl) == (8, "bf16", 32, "uint8", "cabi")
+    d = bench.parse_args([])
+    assert d.gather == "fp32" and d.gather_impl == "torch" and not d.no_configs2 and 300 < d.configs2_budget_s < 600
+    assert 0 <= bench.process_age_s() < 3600

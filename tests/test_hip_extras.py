@@ -1,4 +1,6 @@
 """GPU: the steps either side of the hot path through the C ABI, against the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -124,3 +126,37 @@ def test_configs4_sweep_driver_on_the_tiny_configuration(tmp_path, capsys):
     assert (a.int() - b.int()).abs().max().item() <= 2
     c = mod.main(["--tiny", "--concepts", "1", "--per-concept", "2", "--batch", "2", "--steps", "2", "--dtype", "bf16"])
     assert tuple(c.shape) == (2, 3, 3, 32, 48)
+
+
+def test_cabi_allgather_frames_world_size_1(eng):
+    """e2v_allgather_frames: the exchange of the decoded frames below the C ABI, on the library's own RCCL
+    communicator.  One GPU per box here, so the world is one rank -- that still runs ncclGetUniqueId / ncclCommInitRank /
+    ncclAllGather on the device: fp32 gather = the input, uint8 gather = bit-exact (x * 255) truncation; call-order errors are
+    reported, not crashed on.  torch.distributed (gloo) only ships the 128-byte id."""
+    import ctypes as C
+    import torch.distributed as dist
+    from eeg2video_amd import _lib
+    from eeg2video_amd.dist import all_gather_frames, frames_to_uint8
+    v = torch.rand(2, 3, 3, 16, 24, generator=torch.Generator().manual_seed(3)).cuda()
+    with pytest.raises(RuntimeError, match="no communicator"):
+        eng.allgather_frames(v)
+    assert eng.lib.e2v_allgather_frames(eng.ctx, v.data_ptr(), v.numel(), 0, v.data_ptr(), None) == _lib.E2V_ESTATE
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert eng.comm_init() == 1 and eng.lib.e2v_comm_world(eng.ctx) == 1
+        buf = (C.c_ubyte * 128)()
+        assert eng.lib.e2v_comm_init(eng.ctx, buf, 0, 1) == _lib.E2V_ESTATE        # already holds one
+        out = eng.allgather_frames(v)
+        u8 = eng.allgather_frames(v, as_uint8=True)
+        torch.cuda.synchronize()
+        assert out.dtype == torch.float32 and torch.equal(out, v)
+        assert u8.dtype == torch.uint8 and torch.equal(u8.cpu(), frames_to_uint8(v.cpu()))
+        # the same through the dist helper bench.py / run_sweep.py call
+        assert torch.equal(all_gather_frames(v, force_collective=True, engine=eng), v)
+        assert torch.equal(all_gather_frames(v, as_uint8=True, force_collective=True, engine=eng), u8)
+        eng.comm_destroy()
+        assert eng.lib.e2v_comm_world(eng.ctx) == 0
+    finally:
+        dist.destroy_process_group()

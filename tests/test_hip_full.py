@@ -262,3 +262,87 @@ def test_bf16_persistent_gemm_bit_identical_to_the_tile_kernels(full, B):
             diff = (a - b).abs().max().item()
             print(f"B={B} {name}: PERS/256 = {mode} vs 128-row tile kernels max-abs diff {diff:.3e}")
             assert torch.equal(a, b), (name, mode)
+
+
+def test_configs2_bf16_batch32_equals_single_clip_calls(full):
+    """BASELINE configs[2] at ITS batch: bf16-activation mode, B = 32 clips (64 UNet samples per DDIM step), 2 DDIM steps +
+    decode.  The batch decides which GEMM kernel a layer takes (256-row / 256x256 tiles, persistent or not, VAE clips per pass), so
+    B = 32 is a configuration of its own: clips 0 / 15 / 31 must be BIT-identical to the same clips generated alone, and every
+    frame finite and inside [0, 1]."""
+    pipe = full[0]
+    eng = pipe.unet.engine
+    B = 32
+    lat = torch.stack([_t(counter_normal(1234 + k, "latent", (4, 6, 36, 64))) for k in range(B)]).cuda()
+    cond = torch.stack([_t(counter_normal(1235 + 7919 * k, "cond", (77, 768))) for k in range(B)]).cuda()
+    unc = _t(counter_normal(1236, "uncond", (1, 77, 768))).cuda()
+    try:
+        eng.set_compute_dtype("bf16")
+        vid, lat_out = eng.generate(lat, cond, unc, 2, 12.5, 0.0, decode=True, return_latents=True)
+        assert vid.shape == (B, 3, 6, 288, 512) and torch.isfinite(vid).all() and torch.isfinite(lat_out).all()
+        assert float(vid.min()) >= 0.0 and float(vid.max()) <= 1.0
+        for k in (0, 15, 31):
+            v1, l1 = eng.generate(lat[k:k + 1], cond[k:k + 1], unc, 2, 12.5, 0.0, decode=True, return_latents=True)
+            assert torch.equal(l1[0], lat_out[k]), k
+            assert torch.equal(v1[0], vid[k]), k
+    finally:
+        eng.set_compute_dtype("fp32")
+
+
+def test_config0_bf16_teacher_forced_steps_vs_fp32_oracle(full, config0):
+    """Per-step bf16 check (SURVEY 8(d) procedure ii in the bf16-activation mode): the fp32 oracle's latents of step k-1 go into the
+    bf16 UNet of step k, so that rounding does not chain across steps and a defect of a few 1e-2 in ONE layer cannot hide inside
+    the end-to-end noise.  Bounds, of the tensor's scale (max |ref|): the guided eps (eps_u + 12.5 (eps_c - eps_u), which
+    amplifies the difference of two bf16 forwards 12.5x) < 4e-2, each of the two UNet outputs < 2e-2, the updated latents < 2e-2.
+    Measured on MI355X: printed."""
+    pipe = full[0]
+    eng = pipe.unet.engine
+    lat, cond, unc, ref, trace = config0
+    ts = eng.ddim_timesteps(4)
+    emb = torch.cat([unc, cond]).cuda()
+    x = lat
+    try:
+        eng.set_compute_dtype("bf16")
+        for k, t in enumerate(ts):
+            xg = x.cuda()
+            eps16 = pipe.unet(torch.cat([xg, xg]), int(t), emb).sample
+            eng.set_compute_dtype("fp32")
+            eps32 = pipe.unet(torch.cat([xg, xg]), int(t), emb).sample          # the fp32 HIP path on the same input (1e-5 of the oracle)
+            eng.set_compute_dtype("bf16")
+            guided = eng.cfg_combine(eps16[:1], eps16[1:], 12.5)
+            x_new = eng.ddim_cfg_step(eps16[:1], eps16[1:], xg, 12.5, int(t), int(t) - 250)
+            e_u, e_c = rel_err(eps16[:1], eps32[:1]), rel_err(eps16[1:], eps32[1:])
+            e_g, e_x = rel_err(guided, trace["eps"][k]), rel_err(x_new, trace["latents"][k])
+            print(f"  bf16 teacher-forced step {k} (t = {int(t)}): eps_uncond {e_u:.3e} eps_cond {e_c:.3e} (vs fp32 HIP) | "
+                  f"guided eps {e_g:.3e} latents {e_x:.3e} (vs fp32 oracle), all max-abs / max-ref")
+            assert torch.isfinite(eps16).all()
+            assert e_u < 2e-2 and e_c < 2e-2, k
+            assert e_g < 4e-2 and e_x < 2e-2, k
+            x = trace["latents"][k]
+    finally:
+        eng.set_compute_dtype("fp32")
+
+
+def test_configs4_sweep_full_size_one_concept_bf16(full, capsys):
+    """BASELINE configs[4] at full size through examples/run_sweep.py (the reference's inference_eeg2video.py:90-100 loop: for each
+    concept, 5 clips): 1 concept x 5 clips, 4-step DDIM, bf16 mode, on the SD-v1-4 sized engine -- GLMNet + Seq2Seq (host torch)
+    -> Semantic Predictor (HIP, 310 -> 10^4 x 4 -> 77 x 768) -> DANA -> e2v_generate -> uint8.  Shapes / dtype / record fields, and
+    the 5 clips as one batch against batches of 2 + 3 + (ragged): the HIP path is bit-identical per clip whatever the batch,
+    the host transformer's GEMMs may round differently with the batch size -> within 2 uint8 levels."""
+    import importlib.util, json, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "run_sweep.py")
+    spec = importlib.util.spec_from_file_location("e2v_sweep_full", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    eng = full[0].unet.engine
+    try:
+        a = mod.main(["--concepts", "1", "--per-concept", "5", "--batch", "5", "--steps", "4", "--dtype", "bf16"], engine=eng)
+        rec = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+        b = mod.main(["--concepts", "1", "--per-concept", "5", "--batch", "2", "--steps", "4", "--dtype", "bf16"], engine=eng)
+    finally:
+        eng.set_compute_dtype("fp32")
+    assert tuple(a.shape) == (5, 3, 6, 288, 512) and a.dtype == torch.uint8
+    assert rec["clips"] == 5 and rec["clips_per_s"] > 0 and 0 <= rec["host_model_share"] < 1 and rec["generate_share"] > 0.5
+    diff = (a.int() - b.int()).abs().max().item()
+    print(f"configs[4] full size: batch of 5 vs batches of 2+2+1: max uint8 difference {diff}; {rec['clips_per_s']:.3f} clips/s at 4 steps")
+    assert diff <= 2
+    assert a.float().std() > 1.0          # not a constant image

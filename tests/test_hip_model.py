@@ -446,3 +446,124 @@ def test_from_pretrained_local_dir_fp16_as_the_reference_script_does(tiny, tmp_p
     out2 = pipe2(None, eeg.cuda(), latents=lat, video_length=f, height=32, width=48, num_inference_steps=3, guidance_scale=12.5,
                  negative_prompt=neg).videos
     assert torch.equal(out2, out)
+
+
+def test_from_pretrained_2d_inflates_a_2d_checkpoint(tiny, tmp_path):
+    """UNet3DConditionModel.from_pretrained_2d (unet.py:415-449; caller train_finetune_videodiffusion.py:110): a 2-D Stable-Diffusion
+    UNet directory -- no `attn_temp` / `norm_temp` keys, 2-D block names in config.json -- loads into the 3-D model; the `_temp.` keys
+    keep the FRESH model's init (unet.py:445-447: `if '_temp.' in k: state_dict.update({k: v})`), everything else comes from the
+    checkpoint.  A missing config / weight file raises RuntimeError as the reference does (:421-422, :442-443)."""
+    from eeg2video_amd.unet import UNet3DConditionModel
+    from eeg2video_amd.vae import AutoencoderKL
+    from oracle import unet3d_forward
+    _, usd, vsd = tiny
+    sd2d = {k: v for k, v in usd.items() if "_temp." not in k}
+    assert 0 < len(sd2d) < len(usd)
+    root = str(tmp_path / "sd2d")
+    _save_sd_dir(root, sd2d, vsd, {"_class_name": "DDIMScheduler", "steps_offset": 1}, half=False)
+    vcfg = AutoencoderKL.config_from_dir(os.path.join(root, "vae"))
+    unet = UNet3DConditionModel.from_pretrained_2d(root, subfolder="unet", vae_config=vcfg)
+    # the state dict the reference would end up with: checkpoint values + fresh `_temp.` parameters of this architecture
+    fresh = synth_state_dict({k: s for k, s in unet.state_dict_spec().items() if "_temp." in k}, mode="reference_init")
+    full = dict(sd2d)
+    full.update({k: _t(v) for k, v in fresh.items()})
+    assert set(full) == set(usd)
+    assert float(full["down_blocks.0.attentions.0.transformer_blocks.0.attn_temp.to_out.0.weight"].abs().max()) == 0.0   # attention.py:201
+    x = _t(counter_normal(5, "x", (2, 4, 3, 9, 12)))
+    cond = _t(counter_normal(6, "c", (2, 11, TINY_UNET.cross_attention_dim)))
+    y = unet(x.cuda(), 333, cond.cuda())["sample"]
+    ref = unet3d_forward(full, TINY_UNET, x, 333, cond)
+    assert rel_err(y, ref) < 1e-4
+    with pytest.raises(RuntimeError, match="does not exist"):
+        UNet3DConditionModel.from_pretrained_2d(str(tmp_path / "nowhere"), subfolder="unet")
+    os.remove(os.path.join(root, "unet", "diffusion_pytorch_model.bin"))
+    with pytest.raises(RuntimeError, match="does not exist"):
+        UNet3DConditionModel.from_pretrained_2d(root, subfolder="unet", vae_config=vcfg)
+
+
+def test_memory_knobs_of_the_reference_objects_are_accepted(tiny):
+    """set_attention_slice (unet.py:209-272), enable_gradient_checkpointing (:274-276), enable_sequential_cpu_offload
+    (pipeline_tuneeeg2video.py:121-131): a caller that sets them keeps working; the argument checks and messages of
+    set_attention_slice are the reference's; the output does not change."""
+    pipe, _, _ = tiny
+    unet = pipe.unet
+    x = _t(counter_normal(5, "x", (1, 4, 3, 8, 8))).cuda()
+    cond = _t(counter_normal(6, "c", (1, 7, TINY_UNET.cross_attention_dim))).cuda()
+    before = unet(x, 10, cond).sample
+    unet.set_attention_slice("auto")
+    unet.set_attention_slice("max")
+    unet.set_attention_slice(2)
+    n_layers = 3 * 16                                      # attn1, attn2, attn_temp of the 16 transformer blocks
+    unet.set_attention_slice([1] * n_layers)
+    with pytest.raises(ValueError, match="different attention layers"):
+        unet.set_attention_slice([1] * (n_layers - 1))
+    with pytest.raises(ValueError, match="has to be smaller or equal to"):
+        unet.set_attention_slice(TINY_UNET.attention_head_dim + 1)
+    unet.enable_gradient_checkpointing()
+    pipe.enable_sequential_cpu_offload()
+    pipe.enable_sequential_cpu_offload(gpu_id=0)
+    with pytest.raises(ValueError):
+        pipe.enable_sequential_cpu_offload(gpu_id=7)
+    pipe.enable_attention_slicing()
+    assert torch.equal(unet(x, 10, cond).sample, before)
+
+
+def test_text_prompt_twin_with_precomputed_embeddings(tiny):
+    """pipeline_tuneavideo.py:315-412 (caller train_finetune_videodiffusion.py:331-335): same kwargs -- prompt, negative_prompt,
+    num_videos_per_prompt -- with the prompt given as precomputed [B,77,768]-style embeddings (the CLIP text encoder is outside the
+    path): identical frames to the EEG pipeline fed the same embeddings; the reference's errors for a bad prompt type / mismatched
+    negative prompt; a str prompt without tokenizer / text_encoder says what is missing; with a (stub) tokenizer + text encoder
+    the str path runs, the empty prompt giving the unconditional embedding (:189-190)."""
+    from eeg2video_amd.pipeline_tuneavideo import TuneAVideoPipeline as TextPipeline
+    pipe, _, _ = tiny
+    tp = TextPipeline(vae=pipe.vae, text_encoder=None, tokenizer=None, unet=pipe.unet, scheduler=pipe.scheduler)
+    tp.set_progress_bar_config(disable=True)
+    d, tok, f = TINY_UNET.cross_attention_dim, 77, 3
+    emb = _t(counter_normal(80, "emb", (2, tok, d)))
+    neg = _t(counter_normal(81, "neg", (1, tok, d)))
+    lat = _t(counter_normal(82, "lat", (2, 4, f, 4, 6)))
+    a = tp(emb, video_length=f, height=32, width=48, num_inference_steps=3, guidance_scale=7.5, negative_prompt=neg, latents=lat).videos
+    b = pipe(None, emb.reshape(2, -1).cuda(), latents=lat, video_length=f, height=32, width=48, num_inference_steps=3, guidance_scale=7.5,
+             negative_prompt=neg).videos
+    assert a.shape == (2, 3, f, 32, 48) and torch.equal(a, b)
+    # num_videos_per_prompt repeats each prompt's embedding (:182-184); latents are per generated video
+    lat4 = _t(counter_normal(83, "lat4", (4, 4, f, 4, 6)))
+    c = tp(emb, video_length=f, height=32, width=48, num_inference_steps=2, guidance_scale=7.5, negative_prompt=neg, latents=lat4,
+           num_videos_per_prompt=2).videos
+    e = pipe(None, emb.repeat_interleave(2, 0).reshape(4, -1).cuda(), latents=lat4, video_length=f, height=32, width=48,
+             num_inference_steps=2, guidance_scale=7.5, negative_prompt=neg).videos
+    assert torch.equal(c, e)
+    with pytest.raises(ValueError, match="`prompt` has to be of type"):
+        tp(3.0, video_length=f, height=32, width=48)
+    with pytest.raises(TypeError, match="`negative_prompt` should be the same type"):
+        tp(emb, video_length=f, height=32, width=48, negative_prompt="a photo", latents=lat)
+    with pytest.raises(ValueError, match="tokenizer"):
+        tp("a panda", video_length=f, height=32, width=48, latents=lat[:1])
+
+    class Tok:                      # minimal stand-ins with the transformers CLIP call interface
+        model_max_length = tok
+
+        def __call__(self, prompts, padding=None, max_length=None, truncation=None, return_tensors=None):
+            ids = torch.zeros((len(prompts), max_length), dtype=torch.long)
+            for i, p in enumerate(prompts):
+                ids[i, :len(p)] = torch.tensor([ord(ch) % 50 + 1 for ch in p][:max_length], dtype=torch.long)
+            return type("Enc", (), {"input_ids": ids, "attention_mask": (ids > 0).long()})()
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.table = torch.nn.Embedding(64, d)
+
+        def forward(self, ids, attention_mask=None):
+            return (self.table(ids),)
+
+    enc = Enc().cuda()
+    tp2 = TextPipeline(vae=pipe.vae, text_encoder=enc, tokenizer=Tok(), unet=pipe.unet, scheduler=pipe.scheduler)
+    tp2.set_progress_bar_config(disable=True)
+    v = tp2(["a panda", "a bear"], video_length=f, height=32, width=48, num_inference_steps=2, guidance_scale=7.5, latents=lat).videos
+    with torch.no_grad():
+        pe = enc(Tok()(["a panda", "a bear"], max_length=tok).input_ids.cuda())[0]
+        ne = enc(Tok()(["", ""], max_length=tok).input_ids.cuda())[0]
+    w = tp(pe, video_length=f, height=32, width=48, num_inference_steps=2, guidance_scale=7.5, negative_prompt=ne, latents=lat).videos
+    assert torch.equal(v, w)

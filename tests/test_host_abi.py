@@ -159,3 +159,56 @@ def test_mirror_input_checks_need_no_gpu():
         p.check_inputs(torch.zeros(1), 288, 512, None)
     with pytest.raises(ValueError, match="Unexpected latents shape"):
         p.prepare_latents(1, 4, 6, 288, 512, torch.float32, torch.device("cpu"), None, torch.zeros(1, 4, 6, 36, 63))
+
+
+def test_config_struct_size_is_guarded_across_the_abi(lib):
+    """e2v_config_size(): the library's sizeof(e2v_config) equals the binding's, and the struct a maintainer would paste from
+    INTEGRATION.md section 2 (extracted from the document and executed) has that size too -- a stale field list fails here instead
+    of e2v_default_config writing past the caller's object."""
+    assert lib.e2v_config_size() == C.sizeof(_lib.E2VConfig)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"^class E2VConfig\(C\.Structure\):.*?\n(?=\n)", text, flags=re.S | re.M)
+    assert m, "INTEGRATION.md no longer shows the E2VConfig binding"
+    ns = {"C": C}
+    exec(m.group(0), ns)
+    doc_cfg = ns["E2VConfig"]
+    assert C.sizeof(doc_cfg) == lib.e2v_config_size()
+    assert [f[0] for f in doc_cfg._fields_] == [f[0] for f in _lib.E2VConfig._fields_]
+    cfg = doc_cfg()
+    lib.e2v_default_config(C.cast(C.byref(cfg), C.POINTER(_lib.E2VConfig)))
+    assert cfg.sem_in_features == 310 and cfg.sem_hidden == 10000 and cfg.sem_tokens == 77 and cfg.steps_offset == 1
+
+
+def test_collective_entry_points_report_call_order_errors(lib, host_ctx):
+    """The C-ABI collective without a GPU: no communicator -> world 0, E2V_ESTATE from the gather (host-only context), destroy of
+    nothing is fine, null arguments are E2V_EINVAL.  (The RCCL calls themselves run in the -m gpu test.)"""
+    assert lib.e2v_comm_world(host_ctx) == 0
+    assert lib.e2v_comm_destroy(host_ctx) == 0
+    buf = (C.c_float * 4)()
+    assert lib.e2v_allgather_frames(host_ctx, buf, 4, 0, buf, None) == _lib.E2V_ESTATE
+    assert lib.e2v_allgather_frames(None, buf, 4, 0, buf, None) == _lib.E2V_EINVAL
+    assert lib.e2v_comm_init(None, buf, 0, 1) == _lib.E2V_EINVAL
+    assert lib.e2v_comm_unique_id(None) == _lib.E2V_EINVAL
+
+
+def test_scheduler_config_with_unsupported_arithmetic_is_refused():
+    """scheduler_from_config: a key that changes the arithmetic and is set to something this build does not implement must raise,
+    whether or not the mirror's constructor knows the key -- a v_prediction DDIM config (diffusers 0.11.1 supports it) must not
+    load silently as epsilon prediction.  Descriptive keys are dropped; clip_sample = True is overridden as the pipeline's
+    constructor does (pipeline_tuneeeg2video.py:73-84)."""
+    from eeg2video_amd.scheduler import scheduler_from_config
+    base = {"_class_name": "DDIMScheduler", "_diffusers_version": "0.11.1", "beta_start": 0.00085, "beta_end": 0.012,
+            "beta_schedule": "scaled_linear", "num_train_timesteps": 1000, "steps_offset": 1, "trained_betas": None}
+    s = scheduler_from_config(dict(base, clip_sample=True, prediction_type="epsilon"))
+    assert type(s).__name__ == "DDIMScheduler" and s.config.clip_sample is False
+    for cls in ("DDIMScheduler", "PNDMScheduler", "EulerDiscreteScheduler", "DPMSolverMultistepScheduler"):
+        with pytest.raises(NotImplementedError, match="prediction_type"):
+            scheduler_from_config(dict(base, _class_name=cls, prediction_type="v_prediction"))
+    with pytest.raises(NotImplementedError, match="trained_betas"):
+        scheduler_from_config(dict(base, trained_betas=[0.1, 0.2]))
+    with pytest.raises(NotImplementedError, match="set_alpha_to_one"):
+        scheduler_from_config(dict(base, set_alpha_to_one=True))
+    with pytest.raises(NotImplementedError, match="thresholding"):
+        scheduler_from_config(dict(base, _class_name="DPMSolverMultistepScheduler", thresholding=True))
+    with pytest.raises(ValueError):
+        scheduler_from_config(dict(base, _class_name="KarrasVeScheduler"))

@@ -3,10 +3,11 @@
 # and separate PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) over the same workload, written under gpurun_out/ and folded
 # into profiles/ by the caller.   usage: tools/profile_round.sh <tag> [bench.py args ...]      e.g. r02_fp32_b8 / r02_bf16_b32 --dtype bf16
 #
-# The counter passes run the workload AS IT IS TIMED (one warm-up + one pass, every launch queued asynchronously): round 1 ran
-# them with E2V_SYNC_EACH_STEP=1 because a pass had died with a segmentation fault and no record of it was kept.  Every pass
-# now keeps its stderr (PYTHONFAULTHANDLER prints the Python frame of a fatal signal), a failing pass is recorded and NOT
-# retried, and the remaining passes of the call are skipped.
+# The kernel-trace pass runs the workload AS IT IS TIMED (every launch queued asynchronously).  The counter passes are run with
+# SYNC=1 (E2V_SYNC_EACH_STEP=1: the stream is drained after every DDIM step, <= ~680 launches in flight instead of a whole pass of
+# ~34 000): with the deep queue rocprofiler-sdk's queue-intercept callback faulted (profiles/r02_pmc_async_abort_README.md names
+# the frames).  Per-dispatch counters do not depend on queue depth.  Every pass keeps its stderr, a failing pass is recorded
+# and NOT retried, and the remaining passes of the call are skipped.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
@@ -21,8 +22,7 @@ echo "stats pass rc=$?"
 fi
 PARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-roofline $*"
 export E2V_LOG_MAPS=1
-# SYNC=1: drain the stream after every DDIM step in the counter passes (profiles/r02_pmc_async_abort_README.md: with ~45k launches
-# queued the profiler's dispatch interception died in round 1 and again, recorded, in round 2)
+# SYNC=1: drain the stream after every DDIM step in the counter passes (see the header)
 if [ "${SYNC:-0}" = "1" ]; then export E2V_SYNC_EACH_STEP=1; fi
 if [ "${SKIP_STATS:-0}" = "1" ]; then echo "stats pass skipped"; fi
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
@@ -37,7 +37,7 @@ for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES
     fi
 done
 cd $R
-python3 tools/pmc_to_json.py $OUT $OUT/pmc_summary.json "bench.py $PARGS" || true
+python3 tools/pmc_to_json.py $OUT $OUT/pmc_summary.json "bench.py $PARGS" "${E2V_SYNC_EACH_STEP:-0}" || true
 find $OUT -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT -name "*.csv" ! -name "kernel_stats.csv" -size +2M -delete
 ls -la $OUT
