@@ -1,0 +1,481 @@
+// bf16 implicit-GEMM convolution / linear on 256-row x 256- or 320-column workgroup tiles: the deep-pipelined form of bgemm.hip.
+//
+// Same contract as bgemm.hip (out[m][n] = epilogue(sum_{tap,c} A[src(m,tap)][c] W[n][k(tap,c)]), bf16 rows in HBM, LDS-DMA staging with
+// the gather in the per-lane SOURCE address, XOR-swizzled 128-byte LDS rows, fp32 accumulation) -- what changes is the tile and the
+// schedule.  bgemm.hip's 64 x 64 wave tiles read 16 LDS fragments per 16 MFMAs, move 48 KB into LDS per 256 x 128 x 64 tile step and
+// march eight waves in lockstep through one barrier per step (PMC: matrix pipe 0.41 busy over a pass, waves 37 % in waits, 2.35x
+// the algorithmic bytes through L2).  Here:
+//   * workgroup tile 256 x (64 NT) with NT = 4 or 5: 8 waves as 2 (M) x 4 (N), wave tile 128 rows x 16 NT columns (64 or 80), i.e.
+//     8 x NT tiles of v_mfma_f32_16x16x32_bf16 = 128 / 160 accumulator registers.  N = 320, 640, 960, 1280, 1920, 2560 ... of the UNet
+//     are all multiples of 320, so the 256 x 320 tile wastes no column; GEGLU (value / gate interleaved per 64 columns) and the
+//     VAE's 256 / 512 channels take 256 x 256.  Per 64-deep K step a wave reads 16 + 2 NT fragments for 64 / 80 MFMAs and the
+//     workgroup moves 64 / 72 KB into LDS: 0.67x / 0.6x the L2 -> LDS bytes per flop of the 256 x 128 tile, a third of its LDS reads;
+//   * two K-step buffers (all of the tile's LDS: 128 / 144 KB), each restaged PIECEWISE while it is still being consumed: a K step
+//     is four phases -- quadrant (rows 0-63 | 64-127 of the wave) x (first | second group of column tiles), K = 64 each -- and the
+//     half of X / of W a phase has read for the last time is refilled, for the K step after next, one phase later (units q0, n1,
+//     q1, n0 behind phases 0, 1, 2, 3).  Three such units (6 LDS-DMA instructions per wave) stay in flight behind the counted
+//     `s_waitcnt vmcnt(6)` that ends a K step; vmcnt is never 0 in the loop.  (The first column group's fragments are read again in
+//     phase 3 instead of being kept over phases 1-2: 160 accumulators + 56 fragment registers is what fits 256 VGPRs at NT = 5);
+//   * the two wave rows (waves 0-3 | 4-7: one of each per SIMD) run one barrier apart: between two barriers one of them issues its
+//     LDS reads and its DMA while the other one owns the matrix pipe with 16 / 24 back-to-back MFMAs (`s_setprio` around the
+//     cluster keeps the compiler from spreading it over the barriers).
+// RAW: a unit's DMA is retired by its wave's counted vmcnt in front of a barrier that every reader passes before the phase
+// that reads it.  WAR: every phase's fragment reads are retired (`lgkmcnt(0)`) in front of the barrier that precedes the
+// earliest refill of what they read.  (cdna_hip_programming.md, "The 256^2 8-phase template"; the schedule here is this file's.)
+//
+// The arithmetic is v_mfma_f32_16x16x32_bf16 (bgemm.hip: 32x32x16): the two round differently inside a K = 32 / K = 16 block, so a
+// layer must take the same kernel whatever the batch -- eligibility below depends on the LAYER (N, K, taps), never on M.
+#include "igemm_epi.h"
+#include "prof.h"
+
+#include <string>
+
+namespace e2v {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr unsigned T256_OOB = 0x80000000u;      // beyond every descriptor window: the buffer unit returns zeros / drops the store
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t t256_rsrc(const void* ptr, const int records) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, records, 0x00020000);
+}
+
+template <int NT, bool LIN>
+__global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
+    constexpr int BM = 256, WN = 16 * NT, BN = 4 * WN;
+    constexpr int N0 = (NT + 1) / 2, N1 = NT / 2;            // column tiles of a wave: first group (phases 0, 3), second group (phases 1, 2)
+    constexpr int ROWB = 128;                                // bytes per LDS row = one 64-deep K step of bf16
+    constexpr int XBYTES = BM * ROWB, KT = (BM + BN) * ROWB; // one K-step buffer: X rows, then W rows
+    constexpr int PW0 = N0, PW1 = 2;                         // 1-KB DMA pieces per wave: W first group (16 N0 rows x 4 wave columns / 8 / 8 waves), second group
+    constexpr int INFLIGHT = 2 + PW1 + 2;                    // DMA instructions of the three units (q0, n1, q1) that stay in flight over a K-step boundary
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- tile of this workgroup: XCD x (= blockIdx % 8, blocks are dealt round-robin) owns a contiguous run of row blocks, column
+    // tiles of one row block adjacent (they share the gathered X rows in that XCD's L2)
+    const int nct = (p.N + BN - 1) / BN;
+    const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
+    if (loc >= (rb_hi - rb_lo) * nct) return;
+    const int bm = rb_lo + loc / nct;
+    const int n0 = (loc % nct) * BN;
+
+    const int steps0 = p.c0 >> 6, steps1 = p.c1 >> 6;        // channel counts are multiples of 64 (launcher)
+    const int nk = p.taps * (steps0 + steps1);
+
+    // ---- DMA geometry.  A 1-KB piece = 8 LDS rows; lane -> (row r8 of the piece, 16-byte position pp); the chunk FETCHED for position
+    // pp of tile row r is pp ^ ((r >> 1) & 7) (source-side swizzle; the fragment reads apply the same XOR).
+    const int r8 = lane >> 3, pp = lane & 7;
+    // X: unit q0 = the first 64 rows of both wave rows (tile rows 0-63, 128-191), unit q1 = the other 64 (64-127, 192-255); a wave
+    // moves 16 consecutive rows (2 pieces) of each: rows xb + {0, 8} (+ 64) + r8
+    const int xb = (wave < 4 ? 16 * wave : 128 + 16 * (wave - 4));
+    // W: unit n0 = the first 16 N0 columns of every wave column, unit n1 = the other 32; wave -> wave column wave >> 1, half wave & 1
+    const int wb0 = (wave >> 1) * WN + (wave & 1) * 8 * PW0;
+    const int wb1 = (wave >> 1) * WN + 16 * N0 + (wave & 1) * 16;
+
+    const char* wsrc = reinterpret_cast<const char*>(p.w16) + (size_t)n0 * p.ldw * 2;
+    const int wrows = min(BN, p.N - n0);
+    // rows beyond N fall out of the descriptor window (the range check covers voffset + the instruction offset; the K position rides
+    // in the scalar offset, outside it): no per-lane column masks
+    const __amdgpu_buffer_rsrc_t rw = t256_rsrc(wsrc, wrows * p.ldw * 2);
+    unsigned w_off[PW0 + PW1];
+#pragma unroll
+    for (int j = 0; j < PW0 + PW1; ++j) {
+        const int r = (j < PW0 ? wb0 + 8 * j : wb1 + 8 * (j - PW0)) + r8;
+        w_off[j] = (unsigned)(r * p.ldw * 2) + (unsigned)((pp ^ ((r >> 1) & 7)) * 16);
+    }
+
+    // X source offsets.  LIN: row * row stride + chunk, rows beyond M out of the window.  Conv: the pixel under tap (0, 0) of the
+    // lane's four rows (tile rows xb + r8 + {0, 8, 64, 72}) times the row stride, relative to a descriptor based pad rows + pad pixels
+    // BEFORE the tile's first image, so that the offset is never negative; the tap's displacement (ky Ws + kx) x stride rides in the
+    // scalar offset; a 9-bit mask per row says which taps fall inside the image (zero padding, rows beyond M: out of window).
+    unsigned x_off[4], x_mask[4];
+    const int hw_out = p.Ho * p.Wo, hw_in = p.Hs * p.Ws;
+    const int img0 = LIN ? 0 : (bm * BM) / hw_out;
+    const __bf16* const a0 = reinterpret_cast<const __bf16*>(p.a0);
+    const __bf16* const a1 = reinterpret_cast<const __bf16*>(p.a1);
+    const long xrow0 = LIN ? (long)bm * BM : (long)img0 * hw_in - (long)(p.pad * p.Ws + p.pad);
+    const int xrows = min(BM, p.M - bm * BM);                // valid rows of this tile
+    int k_src = 0, k_chunk = 0, k_tap = 0;                   // issue side: source, 64-channel chunk within it, tap
+    unsigned ld2 = (unsigned)p.lda0 * 2u;
+    auto x_setup = [&](const unsigned l2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = xb + (j & 1) * 8 + (j >> 1) * 64 + r8;
+            const unsigned kcb = (unsigned)((pp ^ ((r >> 1) & 7)) * 16);
+            if constexpr (LIN) {
+                x_off[j] = (unsigned)r * l2 + kcb;
+                x_mask[j] = 1u;
+            } else {
+                const int m = bm * BM + r;
+                unsigned mask = 0, off = 0;
+                if (m < p.M) {
+                    const int img = m / hw_out;
+                    const int rem = m - img * hw_out;
+                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                    off = (unsigned)(((img - img0) * p.Hs + oy * p.stride) * p.Ws + ox * p.stride) * l2 + kcb;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int iy = oy * p.stride - p.pad + t / 3, ix = ox * p.stride - p.pad + t % 3;
+                        mask |= ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) ? (1u << t) : 0u;
+                    }
+                }
+                x_off[j] = off;
+                x_mask[j] = mask;
+            }
+        }
+    };
+    x_setup(ld2);
+    auto x_rsrc = [&]() {
+        const __bf16* base = (k_src ? a1 : a0) + xrow0 * (long)(k_src ? p.lda1 : p.lda0);
+        return t256_rsrc(base, LIN ? (int)((unsigned)xrows * ld2) : 0x7FFFFFF0);
+    };
+    __amdgpu_buffer_rsrc_t rx = x_rsrc();
+
+    // One unit of a K step into buffer `buf`.  Units are issued in the order q0, n1, q1, n0 of a K step (X's position advances behind
+    // q1, W's behind n0); a unit past the last K step is issued all the same, out of window (it writes zeros where nothing
+    // reads any more): every phase then has the same number of DMA instructions in front of the counted waits.
+    bool x_live = true;
+    unsigned x_so = 0;                                       // scalar offset of the K step being fetched from X
+    auto issue_x = [&](const int half, char* buf) {          // half 0: unit q0, 1: unit q1
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = half * 2 + i;
+            unsigned off = x_off[j];
+            if constexpr (!LIN) off = ((x_mask[j] >> k_tap) & 1u) ? off : T256_OOB;
+            if (!x_live) off = T256_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(buf + (xb + half * 64 + i * 8) * ROWB), 16, off, x_so, 0, 0);
+        }
+    };
+    auto advance_x = [&]() {                                 // to the next K step: tap fastest, then chunk, then source
+        if (!x_live) return;
+        if (++k_tap == p.taps) {
+            k_tap = 0;
+            if (++k_chunk == (k_src ? steps1 : steps0)) {
+                k_chunk = 0;
+                if (k_src == 0 && steps1 > 0) {
+                    k_src = 1;
+                    ld2 = (unsigned)p.lda1 * 2u;
+                    x_setup(ld2);
+                    rx = x_rsrc();
+                } else {
+                    x_live = false;
+                }
+            }
+        }
+        const int dy = LIN ? 0 : k_tap / 3, dx = LIN ? 0 : k_tap - 3 * dy;
+        x_so = (unsigned)k_chunk * 128u + (unsigned)(dy * p.Ws + dx) * ld2;
+    };
+    int w_kt = 0;                                            // K step the W units fetch next (n1 first, n0 advances it)
+    auto issue_w = [&](const int grp, char* buf) {
+        const unsigned so = (unsigned)w_kt * 128u;
+        const bool live = w_kt < nk;
+        if (grp == 0) {
+#pragma unroll
+            for (int j = 0; j < PW0; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(buf + XBYTES + (wb0 + 8 * j) * ROWB), 16, live ? w_off[j] : T256_OOB, so, 0, 0);
+            ++w_kt;
+        } else {
+#pragma unroll
+            for (int j = 0; j < PW1; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(buf + XBYTES + (wb1 + 8 * j) * ROWB), 16, live ? w_off[PW0 + j] : T256_OOB, so, 0, 0);
+        }
+    };
+
+    // ---- fragments: v_mfma_f32_16x16x32_bf16 with the WEIGHT tile as the first operand: lane -> (row fl of a 16-row tile, k chunk
+    // fq of the 32-deep step); the result holds pixel fl, channels 4 fq + {0..3} of the 16 x 16 tile in its four registers
+    const int fl = lane & 15, fq = lane >> 4;
+    const int fsw = (fl >> 1) & 7;                           // tiles start at multiples of 16 rows: they do not enter (row >> 1) & 7
+    const unsigned fo0 = (unsigned)(((0 + fq) ^ fsw) * 16), fo1 = (unsigned)(((4 + fq) ^ fsw) * 16);
+    const char* const xfr = smem + (wr * 128 + fl) * ROWB;
+    const char* const wfr = smem + XBYTES + (wc * WN + fl) * ROWB;
+    bf16x8 xf[4][2], wf0[N0][2], wf1[N1][2];
+    f32x4v acc[2][4][NT];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[h][mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    auto read_x = [&](const int bufo, const int half) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            xf[mt][0] = *reinterpret_cast<const bf16x8*>(xfr + bufo + (half * 64 + mt * 16) * ROWB + fo0);
+            xf[mt][1] = *reinterpret_cast<const bf16x8*>(xfr + bufo + (half * 64 + mt * 16) * ROWB + fo1);
+        }
+    };
+    auto read_w0 = [&](const int bufo) {
+#pragma unroll
+        for (int nt = 0; nt < N0; ++nt) {
+            wf0[nt][0] = *reinterpret_cast<const bf16x8*>(wfr + bufo + nt * 16 * ROWB + fo0);
+            wf0[nt][1] = *reinterpret_cast<const bf16x8*>(wfr + bufo + nt * 16 * ROWB + fo1);
+        }
+    };
+    auto read_w1 = [&](const int bufo) {
+#pragma unroll
+        for (int nt = 0; nt < N1; ++nt) {
+            wf1[nt][0] = *reinterpret_cast<const bf16x8*>(wfr + bufo + (N0 + nt) * 16 * ROWB + fo0);
+            wf1[nt][1] = *reinterpret_cast<const bf16x8*>(wfr + bufo + (N0 + nt) * 16 * ROWB + fo1);
+        }
+    };
+    auto mma0 = [&](const int half) {                        // quadrant (half, first column group)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < N0; ++nt)
+                    acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt][ks], xf[mt][ks], acc[half][mt][nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto mma1 = [&](const int half) {                        // quadrant (half, second column group)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < N1; ++nt)
+                    acc[half][mt][N0 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt][ks], xf[mt][ks], acc[half][mt][N0 + nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // the two halves of a phase: [reads + DMA of this wave] | barrier | [MFMAs of this wave] | barrier; the fragment reads are
+    // retired in front of the first barrier (WAR, see the header), the compiler may move nothing across either
+    auto phase_sync_a = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto phase_sync_b = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: K step 0 whole, three units (q0, n1, q1) of K step 1
+    char* const buf0 = smem;
+    char* const buf1 = smem + KT;
+    issue_x(0, buf0);                                        // (the X position starts at source 0, chunk 0, tap 0: scalar offset 0)
+    issue_w(1, buf0);
+    issue_x(1, buf0);
+    advance_x();
+    issue_w(0, buf0);
+    issue_x(0, buf1);
+    issue_w(1, buf1);
+    issue_x(1, buf1);
+    advance_x();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+    __builtin_amdgcn_s_barrier();                            // K step 0 has landed for every wave
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();               // the second wave row runs one barrier behind the first
+
+    // K step t in buffer B (byte offset BO): phases 0..3.  DMA issued meanwhile: n0 of step t + 1 (other buffer), then q0, n1, q1 of
+    // step t + 2 (THIS buffer, each one phase behind its last readers).
+    auto kstep = [&](auto Bc) {
+        constexpr int B = decltype(Bc)::value;
+        constexpr int BO = B * KT;
+        char* const mine = smem + BO;
+        char* const other = smem + (KT - BO);
+        // phase 0: quadrant (rows 0-63, first column group)
+        read_w0(BO);
+        read_x(BO, 0);
+        issue_w(0, other);                                   // n0 of the next K step (the other buffer's was read for the last time in its phase 3)
+        phase_sync_a();
+        mma0(0);
+        phase_sync_b();
+        // phase 1: (rows 0-63, second column group)
+        read_w1(BO);
+        issue_x(0, mine);                                    // q0 of the step after next: rows 0-63 were read for the last time in phase 0
+        phase_sync_a();
+        mma1(0);
+        phase_sync_b();
+        // phase 2: (rows 64-127, second column group)
+        read_x(BO, 1);
+        issue_w(1, mine);                                    // n1: read for the last time in phase 1
+        phase_sync_a();
+        mma1(1);
+        phase_sync_b();
+        // phase 3: (rows 64-127, first column group); the K-step boundary
+        read_w0(BO);
+        issue_x(1, mine);                                    // q1: rows 64-127 were read for the last time in phase 2
+        advance_x();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // the next K step has landed; q0, n1, q1 of the one after stay in flight
+        phase_sync_a();
+        mma0(1);
+        phase_sync_b();
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        kstep(std::integral_constant<int, 0>{});
+        kstep(std::integral_constant<int, 1>{});
+    }
+    if (kt < nk) kstep(std::integral_constant<int, 0>{});
+    if (wr == 0) __builtin_amdgcn_s_barrier();               // the first wave row waits for the second one's last phase
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the out-of-window units behind the last K step
+    __builtin_amdgcn_s_barrier();                            // LDS becomes the epilogue's staging area
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue.  A lane holds (pixel fl, channels 4 fq + e) of each 16 x 16 tile; the wave transposes 32 rows at a time through
+    // LDS (32 x WN floats, rows padded by 4 floats) so that a lane ends up with 8 consecutive channels of one row: bias and
+    // time-embedding rows in fp32, the residual as 8 bf16, one rounding, 16-byte stores of whole row segments.
+    constexpr int SLD = WN + 4;
+    float* const st = reinterpret_cast<float*>(smem) + wave * 32 * SLD;
+    constexpr int WNO = LIN ? WN : WN;                       // (GEGLU halves the output width below)
+    const bool geglu = p.geglu != 0;
+    const int wout = geglu ? WN / 2 : WNO;                   // output columns of this wave
+    const int lpr = wout / 8;                                // lanes per output row (8 columns each)
+    const int rpi = 64 / lpr;                                // rows per pass of the wave (NT = 5: 6 rows, 60 lanes)
+    const int ocol = (lane % lpr) * 8;
+    const int orow = lane / lpr;
+    const int ncol0 = geglu ? (n0 + wc * WN) / 2 : n0 + wc * WN;   // first output column of the wave
+    const int Nout = geglu ? p.N / 2 : p.N;
+    const int nn = ncol0 + ocol;
+    const bool lane_on = orow < rpi && nn < Nout;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+    if (!geglu && p.bias && lane_on) {
+        b0 = *reinterpret_cast<const f32x4*>(p.bias + nn);
+        b1 = *reinterpret_cast<const f32x4*>(p.bias + nn + 4);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {                     // 32 rows = two 16-row tiles
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int mt = pr * 2 + t;
+                if (geglu) {
+                    if constexpr (NT == 4) {                 // value tiles 0, 1 | gate tiles 2, 3 of the wave's 64 packed columns
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const int cb = n0 + wc * WN + nt * 16 + 4 * fq;
+                            const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+                            const f32x4 bg = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + cb + 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+                            f32x4 y;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                y[e] = (acc[h][mt][nt][e] * p.alpha + bv[e]) * gelu_erf(acc[h][mt][nt + 2][e] * p.alpha + bg[e]);
+                            *reinterpret_cast<f32x4*>(st + (t * 16 + fl) * SLD + nt * 16 + 4 * fq) = y;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        f32x4 y;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = acc[h][mt][nt][e];
+                        *reinterpret_cast<f32x4*>(st + (t * 16 + fl) * SLD + nt * 16 + 4 * fq) = y;
+                    }
+                }
+            }
+            // (the staging block is private to the wave: its own LDS writes are in order with its own reads)
+            for (int r = orow; r < 32; r += rpi) {
+                const int m = bm * BM + wr * 128 + h * 64 + pr * 32 + r;
+                if (!lane_on || m >= p.M) continue;
+                f32x4 y0 = *reinterpret_cast<const f32x4*>(st + r * SLD + ocol);
+                f32x4 y1 = *reinterpret_cast<const f32x4*>(st + r * SLD + ocol + 4);
+                if (!geglu) {
+                    if (p.alpha != 1.0f) { y0 *= p.alpha; y1 *= p.alpha; }
+                    y0 += b0; y1 += b1;
+                    if (p.rowbias) {
+                        const float* rb = p.rowbias + (size_t)(m / p.rows_per_sample) * p.rb_ld + nn;
+                        y0 += *reinterpret_cast<const f32x4*>(rb);
+                        y1 += *reinterpret_cast<const f32x4*>(rb + 4);
+                    }
+                    if (p.resid) {
+                        if (p.resid_bf16) {
+                            const bf16x8 rr = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.resid) + (size_t)m * p.ldr + nn);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { y0[e] += (float)rr[e]; y1[e] += (float)rr[4 + e]; }
+                        } else {
+                            y0 += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + nn);
+                            y1 += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + nn + 4);
+                        }
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { y0[e] = fmaxf(y0[e], 0.f); y1[e] = fmaxf(y1[e], 0.f); }
+                    }
+                }
+                if (p.out_f32) {
+                    float* o = p.out + (size_t)m * p.ldc + nn;
+                    *reinterpret_cast<f32x4*>(o) = y0;
+                    *reinterpret_cast<f32x4*>(o + 4) = y1;
+                } else {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y0[e]; o[4 + e] = (__bf16)y1[e]; }
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + (size_t)m * p.ldc + nn) = o;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Which layers take the 256-row deep-pipelined tiles.  A function of the LAYER only (see the header: the MFMA shape differs from
+// bgemm.hip's, so a layer must not change kernels with the batch): linears and stride-1 / stride-2 3x3 convs without the nearest
+// resize, channel counts in whole 64-deep K steps, at least E2V_BGEMM_T256_MINK deep, output width a multiple of 320 (256 x 320
+// tiles) or -- GEGLU, VAE -- of 256.  E2V_BGEMM_T256 = 0 switches it off (A/B against bgemm.hip).
+static int t256_tile_cols(const IgemmArgs& a) {
+    static const int* const on = knob("E2V_BGEMM_T256", 1);
+    static const int* const mink = knob("E2V_BGEMM_T256_MINK", 640);
+    if (!*on || !a.a_bf16 || a.batch != 1 || a.upsample || (a.taps != 1 && a.taps != 9)) return 0;
+    if (a.c0 <= 0 || a.c0 % 64 || a.c1 % 64 || a.taps * (a.c0 + a.c1) < *mink) return 0;
+    if (a.geglu) return a.N % 256 == 0 ? 256 : 0;
+    if ((a.N | a.ldc | a.ldr) & 7 || (a.rb_ld & 3)) return 0;
+    if (a.N % 320 == 0) return 320;
+    if (a.N % 256 == 0) return 256;
+    return 0;
+}
+
+bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
+    const int cols = t256_tile_cols(a_in);
+    if (!cols) return false;
+    IgemmArgs a = a_in;
+    a.nbm = (a.M + 255) / 256;
+    int per_xcd = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int nrb = (int)(((long)(x + 1) * a.nbm) >> 3) - (int)(((long)x * a.nbm) >> 3);
+        per_xcd = nrb > per_xcd ? nrb : per_xcd;
+    }
+    const int nct = a.N / cols;
+    const int grid = 8 * per_xcd * nct;
+    const size_t smem = (size_t)2 * (256 + cols) * 128;
+    const bool lin = a.taps == 1;
+    const double K = (double)a.taps * (a.c0 + a.c1);
+    const double rows_in = lin ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
+    std::string pname = "igemm_bf16";
+    if (profiler().on && profiler().detail)
+        pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t" + std::to_string(a.taps) +
+                 (a.stride > 1 ? " s2" : "") + (a.c1 ? " cat" : "") + (a.geglu ? " geglu" : "") + " T" + std::to_string(cols);
+    const double out_b = a.out_f32 ? 4.0 : 2.0;
+    ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K,
+                 2.0 * rows_in * (a.c0 + a.c1) + 2.0 * a.N * K + out_b * a.M * (a.geglu ? a.N / 2 : a.N), s);
+    auto go = [&](auto kern) {
+        static bool cfg = false;
+        if (!cfg) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * (256 + 320) * 128));
+            cfg = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, a);
+    };
+    if (cols == 320) { if (lin) go(bgemm_t256_kernel<5, true>); else go(bgemm_t256_kernel<5, false>); }
+    else             { if (lin) go(bgemm_t256_kernel<4, true>); else go(bgemm_t256_kernel<4, false>); }
+    return true;
+}
+
+}  // namespace e2v

@@ -757,6 +757,7 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
             (reinterpret_cast<uintptr_t>(a.a0) & 15) || (reinterpret_cast<uintptr_t>(a.a1) & 15))
             throw Error(E2V_ESHAPE, "bf16 GEMM: channel counts / row strides must be multiples of 8 (concat seam of a 3x3 conv: 64) and rows 16-byte aligned");
         a.ldw = a.ldw16;
+        if (bgemm_t256_launch(a, s)) return;                 // 256 x 256 / 256 x 320 deep-pipelined tiles (bgemm256.hip), by layer shape
     }
     const char* cls = "igemm_f32";
     if (a.geglu) {                                           // the GEGLU epilogue pairs the two 32-column halves of a wave

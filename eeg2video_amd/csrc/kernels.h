@@ -58,6 +58,7 @@ int* knob(const char* name, int dflt);
 bool set_knob(const char* name, int value);      // false: no kernel has asked for a knob of that name yet and it is not a known one
 void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s);
 bool bgemm_all_n64(const IgemmArgs& a);
+bool bgemm_t256_launch(const IgemmArgs& a, hipStream_t s);                 // bgemm256.hip: true = the layer was eligible and has been launched
 bool bgemm_use_256(const IgemmArgs& a);                                  // schedule hint: 256-row tiles pay for this launch
 
 // weight re-layout helpers (one-off, at finalize)
