@@ -50,9 +50,11 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
     constexpr int BM = 256, WN = 16 * NT, BN = 4 * WN;
     constexpr int N0 = (NT + 1) / 2, N1 = NT / 2;            // column tiles of a wave: first group (phases 0, 3), second group (phases 1, 2)
     constexpr int ROWB = 128;                                // bytes per LDS row = one 64-deep K step of bf16
-    constexpr int XBYTES = BM * ROWB, KT = (BM + BN) * ROWB; // one K-step buffer: X rows, then W rows
-    constexpr int PW0 = N0, PW1 = 2;                         // 1-KB DMA pieces per wave: W first group (16 N0 rows x 4 wave columns / 8 / 8 waves), second group
-    constexpr int INFLIGHT = 2 + PW1 + 2;                    // DMA instructions of the three units (q0, n1, q1) that stay in flight over a K-step boundary
+    constexpr int XBYTES = BM * ROWB, WBYTES = BN * ROWB;    // one K step of X rows / of W rows
+    // LDS: [X, buffer 0][X, buffer 1][W, buffer 0][W, buffer 1] -- both buffers of an operand within the 16-bit immediate offset of
+    // ONE base register per 32-deep k step
+    constexpr int WREG = 2 * XBYTES;
+    constexpr int INFLIGHT = 2 + N1 + 2;                    // DMA instructions of the three units (q0, n1, q1) that stay in flight over a K-step boundary
     typedef __attribute__((address_space(3))) void* lds_ptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -74,32 +76,31 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
     const int nk = p.taps * (steps0 + steps1);
 
     // ---- DMA geometry.  A 1-KB piece = 8 LDS rows; lane -> (row r8 of the piece, 16-byte position pp); the chunk FETCHED for position
-    // pp of tile row r is pp ^ ((r >> 1) & 7) (source-side swizzle; the fragment reads apply the same XOR).
+    // pp of tile row r is pp ^ ((r >> 1) & 7) (source-side swizzle; the fragment reads apply the same XOR).  A wave's pieces of
+    // one operand are 16 rows apart, so that they share the lane's swizzle and ONE offset register: the displacement of a piece is
+    // wave-uniform (a scalar add).
     const int r8 = lane >> 3, pp = lane & 7;
     // X: unit q0 = the first 64 rows of both wave rows (tile rows 0-63, 128-191), unit q1 = the other 64 (64-127, 192-255); a wave
-    // moves 16 consecutive rows (2 pieces) of each: rows xb + {0, 8} (+ 64) + r8
-    const int xb = (wave < 4 ? 16 * wave : 128 + 16 * (wave - 4));
-    // W: unit n0 = the first 16 N0 columns of every wave column, unit n1 = the other 32; wave -> wave column wave >> 1, half wave & 1
-    const int wb0 = (wave >> 1) * WN + (wave & 1) * 8 * PW0;
-    const int wb1 = (wave >> 1) * WN + 16 * N0 + (wave & 1) * 16;
+    // moves rows xb + {0, 16} (+ 64 for q1) + r8
+    const int xb = (wave < 4 ? 0 : 128) + 32 * ((wave & 3) >> 1) + 8 * (wave & 1);
+    // W: wave column wave >> 1, rows wb + 16 i + r8, i < NT: the first N0 pieces are unit n0 (the first 16 N0 columns of the wave
+    // column), the other two unit n1
+    const int wb = (wave >> 1) * WN + 8 * (wave & 1);
 
     const char* wsrc = reinterpret_cast<const char*>(p.w16) + (size_t)n0 * p.ldw * 2;
-    const int wrows = min(BN, p.N - n0);
-    // rows beyond N fall out of the descriptor window (the range check covers voffset + the instruction offset; the K position rides
-    // in the scalar offset, outside it): no per-lane column masks
-    const __amdgpu_buffer_rsrc_t rw = t256_rsrc(wsrc, wrows * p.ldw * 2);
-    unsigned w_off[PW0 + PW1];
-#pragma unroll
-    for (int j = 0; j < PW0 + PW1; ++j) {
-        const int r = (j < PW0 ? wb0 + 8 * j : wb1 + 8 * (j - PW0)) + r8;
-        w_off[j] = (unsigned)(r * p.ldw * 2) + (unsigned)((pp ^ ((r >> 1) & 7)) * 16);
-    }
+    const __amdgpu_buffer_rsrc_t rw_on = t256_rsrc(wsrc, 0x7FFFFFF0);      // (N is a multiple of the tile width: no column masks)
+    const __amdgpu_buffer_rsrc_t r_off = t256_rsrc(wsrc, 0);               // zero records: every load returns zeros
+    const unsigned ldw2 = (unsigned)p.ldw * 2u;
+    const unsigned w_off = (unsigned)(wb + r8) * ldw2 + (unsigned)((pp ^ (((wb + r8) >> 1) & 7)) * 16);
 
-    // X source offsets.  LIN: row * row stride + chunk, rows beyond M out of the window.  Conv: the pixel under tap (0, 0) of the
-    // lane's four rows (tile rows xb + r8 + {0, 8, 64, 72}) times the row stride, relative to a descriptor based pad rows + pad pixels
-    // BEFORE the tile's first image, so that the offset is never negative; the tap's displacement (ky Ws + kx) x stride rides in the
-    // scalar offset; a 9-bit mask per row says which taps fall inside the image (zero padding, rows beyond M: out of window).
-    unsigned x_off[4], x_mask[4];
+    // X source offsets.  LIN: row * row stride + chunk for the lane's first row, the other three a scalar displacement further; rows
+    // beyond M fall out of the descriptor window (the range check covers the vector offset; the K position rides in the scalar
+    // offset, outside it).  Conv: the PIXEL under tap (0, 0) of the lane's four rows (tile rows xb + r8 + {0, 16, 64, 80}), relative to
+    // a descriptor based pad rows + pad pixels BEFORE the tile's first image, so that it is never negative (times the source's row
+    // stride at issue: one 24-bit multiply-add); the tap's displacement (ky Ws + kx) x stride rides in the scalar offset; a 9-bit
+    // mask per row says which taps fall inside the image (zero padding, rows beyond M: out of window).
+    constexpr int NXO = LIN ? 1 : 4;
+    unsigned x_off[NXO];                                     // conv: pixel index (20 bits) | tap mask << 20
     const int hw_out = p.Ho * p.Wo, hw_in = p.Hs * p.Ws;
     const int img0 = LIN ? 0 : (bm * BM) / hw_out;
     const __bf16* const a0 = reinterpret_cast<const __bf16*>(p.a0);
@@ -108,53 +109,54 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
     const int xrows = min(BM, p.M - bm * BM);                // valid rows of this tile
     int k_src = 0, k_chunk = 0, k_tap = 0;                   // issue side: source, 64-channel chunk within it, tap
     unsigned ld2 = (unsigned)p.lda0 * 2u;
+    const unsigned x_kcb = (unsigned)((pp ^ (((xb + r8) >> 1) & 7)) * 16);
     auto x_setup = [&](const unsigned l2) {
+        if constexpr (LIN) {
+            x_off[0] = (unsigned)(xb + r8) * l2 + x_kcb;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = xb + (j & 1) * 8 + (j >> 1) * 64 + r8;
-            const unsigned kcb = (unsigned)((pp ^ ((r >> 1) & 7)) * 16);
-            if constexpr (LIN) {
-                x_off[j] = (unsigned)r * l2 + kcb;
-                x_mask[j] = 1u;
-            } else {
+            for (int j = 0; j < 4; ++j) {
+                const int r = xb + (j & 1) * 16 + (j >> 1) * 64 + r8;
                 const int m = bm * BM + r;
                 unsigned mask = 0, off = 0;
                 if (m < p.M) {
                     const int img = m / hw_out;
                     const int rem = m - img * hw_out;
                     const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                    off = (unsigned)(((img - img0) * p.Hs + oy * p.stride) * p.Ws + ox * p.stride) * l2 + kcb;
+                    off = (unsigned)(((img - img0) * p.Hs + oy * p.stride) * p.Ws + ox * p.stride);      // a PIXEL index: x row stride at issue
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
                         const int iy = oy * p.stride - p.pad + t / 3, ix = ox * p.stride - p.pad + t % 3;
                         mask |= ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) ? (1u << t) : 0u;
                     }
                 }
-                x_off[j] = off;
-                x_mask[j] = mask;
+                x_off[j] = off | (mask << 20);
             }
         }
     };
     x_setup(ld2);
+    bool x_live = true;
     auto x_rsrc = [&]() {
         const __bf16* base = (k_src ? a1 : a0) + xrow0 * (long)(k_src ? p.lda1 : p.lda0);
-        return t256_rsrc(base, LIN ? (int)((unsigned)xrows * ld2) : 0x7FFFFFF0);
+        return t256_rsrc(base, !x_live ? 0 : LIN ? (int)((unsigned)xrows * ld2) : 0x7FFFFFF0);
     };
     __amdgpu_buffer_rsrc_t rx = x_rsrc();
 
     // One unit of a K step into buffer `buf`.  Units are issued in the order q0, n1, q1, n0 of a K step (X's position advances behind
-    // q1, W's behind n0); a unit past the last K step is issued all the same, out of window (it writes zeros where nothing
-    // reads any more): every phase then has the same number of DMA instructions in front of the counted waits.
-    bool x_live = true;
+    // q1, W's behind n0); a unit past the last K step is issued all the same, against a zero-record descriptor (it writes zeros where
+    // nothing reads any more): every phase then has the same number of DMA instructions in front of the counted waits.
     unsigned x_so = 0;                                       // scalar offset of the K step being fetched from X
-    auto issue_x = [&](const int half, char* buf) {          // half 0: unit q0, 1: unit q1
+    auto issue_x = [&](const int half, const int b) {          // half 0: unit q0, 1: unit q1
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int j = half * 2 + i;
-            unsigned off = x_off[j];
-            if constexpr (!LIN) off = ((x_mask[j] >> k_tap) & 1u) ? off : T256_OOB;
-            if (!x_live) off = T256_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(buf + (xb + half * 64 + i * 8) * ROWB), 16, off, x_so, 0, 0);
+            unsigned off;
+            if constexpr (LIN) {
+                off = x_off[0] + (unsigned)(16 * i + 64 * half) * ld2;
+            } else {
+                off = ((x_off[j] >> (20 + k_tap)) & 1u) ? __umul24(x_off[j] & 0xFFFFFu, ld2) + x_kcb : T256_OOB;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(smem + b * XBYTES + (xb + 16 * i + 64 * half) * ROWB), 16, off, x_so, 0, 0);
         }
     };
     auto advance_x = [&]() {                                 // to the next K step: tap fastest, then chunk, then source
@@ -166,29 +168,29 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
                 if (k_src == 0 && steps1 > 0) {
                     k_src = 1;
                     ld2 = (unsigned)p.lda1 * 2u;
-                    x_setup(ld2);
-                    rx = x_rsrc();
+                    if constexpr (LIN) x_setup(ld2);         // (conv: the pixel indices and masks do not depend on the source)
                 } else {
                     x_live = false;
                 }
+                rx = x_rsrc();
             }
         }
         const int dy = LIN ? 0 : k_tap / 3, dx = LIN ? 0 : k_tap - 3 * dy;
         x_so = (unsigned)k_chunk * 128u + (unsigned)(dy * p.Ws + dx) * ld2;
     };
     int w_kt = 0;                                            // K step the W units fetch next (n1 first, n0 advances it)
-    auto issue_w = [&](const int grp, char* buf) {
+    auto issue_w = [&](const int grp, const int b) {
+        const __amdgpu_buffer_rsrc_t rw = w_kt < nk ? rw_on : r_off;
         const unsigned so = (unsigned)w_kt * 128u;
-        const bool live = w_kt < nk;
         if (grp == 0) {
 #pragma unroll
-            for (int j = 0; j < PW0; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(buf + XBYTES + (wb0 + 8 * j) * ROWB), 16, live ? w_off[j] : T256_OOB, so, 0, 0);
+            for (int i = 0; i < N0; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + WREG + b * WBYTES + (wb + 16 * i) * ROWB), 16, w_off, so + (unsigned)(16 * i) * ldw2, 0, 0);
             ++w_kt;
         } else {
 #pragma unroll
-            for (int j = 0; j < PW1; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(buf + XBYTES + (wb1 + 8 * j) * ROWB), 16, live ? w_off[PW0 + j] : T256_OOB, so, 0, 0);
+            for (int i = N0; i < NT; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + WREG + b * WBYTES + (wb + 16 * i) * ROWB), 16, w_off, so + (unsigned)(16 * i) * ldw2, 0, 0);
         }
     };
 
@@ -197,8 +199,19 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
     const int fl = lane & 15, fq = lane >> 4;
     const int fsw = (fl >> 1) & 7;                           // tiles start at multiples of 16 rows: they do not enter (row >> 1) & 7
     const unsigned fo0 = (unsigned)(((0 + fq) ^ fsw) * 16), fo1 = (unsigned)(((4 + fq) ^ fsw) * 16);
-    const char* const xfr = smem + (wr * 128 + fl) * ROWB;
-    const char* const wfr = smem + XBYTES + (wc * WN + fl) * ROWB;
+    // LDS addresses of the fragment reads: per (buffer, 32-deep k step) ONE base register for X and one for W, every tile an immediate
+    // offset below 64 KB.  (Made opaque to the compiler: with the second buffer beyond the 16-bit offset field it otherwise
+    // materialises one address per read, parks them in scratch and reloads them -- behind vmcnt(0) -- in the loop.)
+    typedef __attribute__((address_space(3))) const bf16x8* lds_frag;
+    typedef __attribute__((address_space(3))) const char* lds_cptr;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_cptr)smem;
+    unsigned xa[2], wa[2];
+    xa[0] = lds0 + (wr * 128 + fl) * ROWB + fo0;
+    xa[1] = lds0 + (wr * 128 + fl) * ROWB + fo1;
+    wa[0] = lds0 + WREG + (wc * WN + fl) * ROWB + fo0;
+    wa[1] = lds0 + WREG + (wc * WN + fl) * ROWB + fo1;
+    asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(wa[0]), "+v"(wa[1]));
+    auto ldsf = [](const unsigned addr) { return *(lds_frag)(lds_cptr)(unsigned long long)addr; };
     bf16x8 xf[4][2], wf0[N0][2], wf1[N1][2];
     f32x4v acc[2][4][NT];
 #pragma unroll
@@ -208,25 +221,25 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[h][mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-    auto read_x = [&](const int bufo, const int half) {
+    auto read_x = [&](const int b, const int half) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            xf[mt][0] = *reinterpret_cast<const bf16x8*>(xfr + bufo + (half * 64 + mt * 16) * ROWB + fo0);
-            xf[mt][1] = *reinterpret_cast<const bf16x8*>(xfr + bufo + (half * 64 + mt * 16) * ROWB + fo1);
+            xf[mt][0] = ldsf(xa[0] + b * XBYTES + (half * 64 + mt * 16) * ROWB);
+            xf[mt][1] = ldsf(xa[1] + b * XBYTES + (half * 64 + mt * 16) * ROWB);
         }
     };
-    auto read_w0 = [&](const int bufo) {
+    auto read_w0 = [&](const int b) {
 #pragma unroll
         for (int nt = 0; nt < N0; ++nt) {
-            wf0[nt][0] = *reinterpret_cast<const bf16x8*>(wfr + bufo + nt * 16 * ROWB + fo0);
-            wf0[nt][1] = *reinterpret_cast<const bf16x8*>(wfr + bufo + nt * 16 * ROWB + fo1);
+            wf0[nt][0] = ldsf(wa[0] + b * WBYTES + nt * 16 * ROWB);
+            wf0[nt][1] = ldsf(wa[1] + b * WBYTES + nt * 16 * ROWB);
         }
     };
-    auto read_w1 = [&](const int bufo) {
+    auto read_w1 = [&](const int b) {
 #pragma unroll
         for (int nt = 0; nt < N1; ++nt) {
-            wf1[nt][0] = *reinterpret_cast<const bf16x8*>(wfr + bufo + (N0 + nt) * 16 * ROWB + fo0);
-            wf1[nt][1] = *reinterpret_cast<const bf16x8*>(wfr + bufo + (N0 + nt) * 16 * ROWB + fo1);
+            wf1[nt][0] = ldsf(wa[0] + b * WBYTES + (N0 + nt) * 16 * ROWB);
+            wf1[nt][1] = ldsf(wa[1] + b * WBYTES + (N0 + nt) * 16 * ROWB);
         }
     };
     auto mma0 = [&](const int half) {                        // quadrant (half, first column group)
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
     // the two halves of a phase: [reads + DMA of this wave] | barrier | [MFMAs of this wave] | barrier; the fragment reads are
     // retired in front of the first barrier (WAR, see the header), the compiler may move nothing across either
     auto phase_sync_a = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0) alone (vmcnt / expcnt fields at their maxima)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -266,50 +279,46 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
     };
 
     // ---- prologue: K step 0 whole, three units (q0, n1, q1) of K step 1
-    char* const buf0 = smem;
-    char* const buf1 = smem + KT;
-    issue_x(0, buf0);                                        // (the X position starts at source 0, chunk 0, tap 0: scalar offset 0)
-    issue_w(1, buf0);
-    issue_x(1, buf0);
+    issue_x(0, 0);                                           // (the X position starts at source 0, chunk 0, tap 0: scalar offset 0)
+    issue_w(1, 0);
+    issue_x(1, 0);
     advance_x();
-    issue_w(0, buf0);
-    issue_x(0, buf1);
-    issue_w(1, buf1);
-    issue_x(1, buf1);
+    issue_w(0, 0);
+    issue_x(0, 1);
+    issue_w(1, 1);
+    issue_x(1, 1);
     advance_x();
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
     __builtin_amdgcn_s_barrier();                            // K step 0 has landed for every wave
     __builtin_amdgcn_sched_barrier(0);
     if (wr == 1) __builtin_amdgcn_s_barrier();               // the second wave row runs one barrier behind the first
 
-    // K step t in buffer B (byte offset BO): phases 0..3.  DMA issued meanwhile: n0 of step t + 1 (other buffer), then q0, n1, q1 of
+    // K step t in buffer B: phases 0..3.  DMA issued meanwhile: n0 of step t + 1 (other buffer), then q0, n1, q1 of
     // step t + 2 (THIS buffer, each one phase behind its last readers).
     auto kstep = [&](auto Bc) {
         constexpr int B = decltype(Bc)::value;
-        constexpr int BO = B * KT;
-        char* const mine = smem + BO;
-        char* const other = smem + (KT - BO);
+        constexpr int mine = B, other = 1 - B;
         // phase 0: quadrant (rows 0-63, first column group)
-        read_w0(BO);
-        read_x(BO, 0);
+        read_w0(B);
+        read_x(B, 0);
         issue_w(0, other);                                   // n0 of the next K step (the other buffer's was read for the last time in its phase 3)
         phase_sync_a();
         mma0(0);
         phase_sync_b();
         // phase 1: (rows 0-63, second column group)
-        read_w1(BO);
+        read_w1(B);
         issue_x(0, mine);                                    // q0 of the step after next: rows 0-63 were read for the last time in phase 0
         phase_sync_a();
         mma1(0);
         phase_sync_b();
         // phase 2: (rows 64-127, second column group)
-        read_x(BO, 1);
+        read_x(B, 1);
         issue_w(1, mine);                                    // n1: read for the last time in phase 1
         phase_sync_a();
         mma1(1);
         phase_sync_b();
         // phase 3: (rows 64-127, first column group); the K-step boundary
-        read_w0(BO);
+        read_w0(B);
         issue_x(1, mine);                                    // q1: rows 64-127 were read for the last time in phase 2
         advance_x();
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // the next K step has landed; q0, n1, q1 of the one after stay in flight

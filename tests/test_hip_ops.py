@@ -443,3 +443,65 @@ def test_linear_width_not_multiple_of_four(eng, m, k, n):
     """N % 4 != 0 takes the scalar epilogue (no 16-byte accesses) of the tiles."""
     x, w, b = rnd(m, k, seed=70), rnd(n, k, seed=71, scale=0.05), rnd(n, seed=72)
     close(eng.op_linear(x.cuda(), w.cuda(), b.cuda()), F.linear(x, w, b))
+
+
+# ------------------------------------------------------------------ bf16 mode: the 256-row deep-pipelined tiles (bgemm256.hip) -------
+# Layers with whole 64-deep K steps, K >= 640 and N a multiple of 320 (256 x 320 tiles) or 256 (GEGLU, the VAE's widths) take
+# bgemm_t256_kernel: v_mfma_f32_16x16x32_bf16, two K-step buffers restaged piecewise, staggered wave rows.  Same contract as the
+# tiles of bgemm.hip, so: the same tight comparison with the op on bf16-rounded operands (summation order only), on shapes that
+# cover ragged row blocks, several images under one tile, the concat seam, stride 2 with both paddings, odd / even K-step
+# counts, one K step less than the pipeline depth... and, with E2V_BGEMM_T256 = 0, closeness to the other kernels.
+@pytest.mark.parametrize("m,k,n,resid", [(240, 1280, 1280, True), (1000, 640, 320, True), (4097, 704, 640, False), (256, 640, 512, True),
+                                         (777, 1920, 256, False), (513, 2560, 320, True), (64, 640, 960, False)])
+def test_bf16_t256_linear(bf, m, k, n, resid):
+    x, w, b = rnd(m, k, seed=120), rnd(n, k, seed=121, scale=0.05), rnd(n, seed=122)
+    r = rnd(m, n, seed=123) if resid else None
+    y = bf.op_linear(x.cuda(), w.cuda(), b.cuda(), r.cuda() if resid else None)
+    ref = F.linear(rb(x), rb(w), b) + (r if resid else 0)
+    close(y, ref, rtol=1e-4, atol=1e-4)
+    bf.set_knob("E2V_BGEMM_T256", 0)
+    try:
+        y0 = bf.op_linear(x.cuda(), w.cuda(), b.cuda(), r.cuda() if resid else None)
+    finally:
+        bf.set_knob("E2V_BGEMM_T256", 1)
+    close(y, y0, rtol=1e-4, atol=1e-4)
+    print(f"T256 vs bgemm.hip tiles (m={m}, k={k}, n={n}): bit-identical = {torch.equal(y, y0)}, max |diff| = {(y - y0).abs().max().item():.3e}")
+
+
+@pytest.mark.parametrize("m,k,n", [(300, 640, 512), (1000, 1280, 2560), (130, 704, 5120)])
+def test_bf16_t256_geglu(bf, m, k, n):
+    """GEGLU projection (attention.py:189): packed width n = 2 x out, value / gate interleaved per 64 columns -> 256 x 256 tiles."""
+    x, w, b = rnd(m, k, seed=130), rnd(n, k, seed=131, scale=0.05), rnd(n, seed=132)
+    hh, gg = F.linear(rb(x), rb(w), b).chunk(2, dim=-1)
+    close(bf.op_linear(x.cuda(), w.cuda(), b.cuda(), geglu=True), hh * F.gelu(gg), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w,stride", [(128, 320, 3, 9, 16, 1), (64, 640, 2, 18, 32, 1), (192, 320, 7, 5, 8, 1), (128, 256, 1, 36, 64, 1),
+                                                   (128, 320, 2, 17, 12, 2), (320, 320, 2, 36, 64, 1), (64, 512, 1, 9, 16, 1)])
+def test_bf16_t256_conv3x3(bf, cin, cout, n, h, w, stride):
+    """3x3 convs on the 256-row tiles: images of 144 / 576 / 40 / 2304 pixels (a tile spans several images or a fraction of one, the
+    last tile is ragged), 9 x (cin / 64) K steps, stride 2 (Downsample3D)."""
+    x, wt, b = rnd(n, cin, h, w, seed=140), rnd(cout, cin, 3, 3, seed=141, scale=0.05), rnd(cout, seed=142)
+    ref = F.conv2d(rb(x), rb(wt), b, padding=1, stride=stride)
+    y = bf.op_conv3x3(to_cl(x).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=h, Ws=w, stride=stride)
+    close(from_cl(y, n, ref.shape[2], ref.shape[3]), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_bf16_t256_conv3x3_geometries(bf):
+    """The VAE encoder's stride-2 conv with (0, 1) padding, and the resnet's second conv at the up-blocks: channel concat with the
+    time-embedding row and the residual (two X sources with different row strides, the K loop crossing the seam)."""
+    n, c, cout = 2, 128, 256
+    wt, b = rnd(cout, c, 3, 3, seed=150, scale=0.05), rnd(cout, seed=151)
+    x2 = rnd(n, c, 8, 12, seed=152)
+    ref2 = F.conv2d(F.pad(rb(x2), (0, 1, 0, 1)), rb(wt), b, stride=2)
+    y2 = bf.op_conv3x3(to_cl(x2).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=8, Ws=12, stride=2, pad_lo=0, pad_hi=1)
+    close(from_cl(y2, n, ref2.shape[2], ref2.shape[3]), ref2, rtol=1e-4, atol=1e-4)
+    n_s, f, c0, c1, cout, h, w = 2, 3, 128, 64, 320, 9, 16
+    nn = n_s * f
+    a, s = rnd(nn, c0, h, w, seed=153), rnd(nn, c1, h, w, seed=154)
+    wc, bc = rnd(cout, c0 + c1, 3, 3, seed=155, scale=0.05), rnd(cout, seed=156)
+    temb, res = rnd(n_s, cout, seed=157), rnd(nn, cout, h, w, seed=158)
+    refc = F.conv2d(torch.cat([rb(a), rb(s)], 1), rb(wc), bc, padding=1) + temb.repeat_interleave(f, 0)[:, :, None, None] + res
+    yc = bf.op_conv3x3(to_cl(a).cuda(), wc.cuda(), bc.cuda(), x1=to_cl(s).cuda(), n_img=nn, Hs=h, Ws=w,
+                       rowbias=temb.cuda().contiguous(), rows_per_sample=f * h * w, resid=to_cl(res).cuda())
+    close(from_cl(yc, nn, h, w), refc, rtol=1e-4, atol=1e-4)
