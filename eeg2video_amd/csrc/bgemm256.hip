@@ -435,20 +435,35 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
 
 }  // namespace
 
-// Which layers take the 256-row deep-pipelined tiles.  A function of the LAYER only (see the header: the MFMA shape differs from
-// bgemm.hip's, so a layer must not change kernels with the batch): linears and stride-1 / stride-2 3x3 convs without the nearest
-// resize, channel counts in whole 64-deep K steps, at least E2V_BGEMM_T256_MINK deep, output width a multiple of 320 (256 x 320
-// tiles) or -- GEGLU, VAE -- of 256.  E2V_BGEMM_T256 = 0 switches it off (A/B against bgemm.hip).
+// Which layers take the 256-row deep-pipelined tiles: linears and stride-1 / stride-2 3x3 convs without the nearest resize, channel
+// counts in whole 64-deep K steps, output width a multiple of 320 (256 x 320 tiles) or -- GEGLU, VAE -- of 256.  Same-box A/B over
+// every GEMM shape of a B = 32 UNet step (tools/shape_ab.py, profiles/r03_shape_ab_*.log): 3x3 convs -14..-32 % (1300-1570
+// TFLOP/s against 1060-1250), linears with K >= 960 -5..-42 %, the K = 320 / 640 projections WITHOUT a residual -11..-23 %; the ones with
+// a residual to read at K <= 640 (320 -> 320 at its HBM roofline, 640 -> 640) are 5-23 % FASTER on bgemm.hip's persistent kernel and
+// stay there, and so do launches of fewer than E2V_BGEMM_T256_MINTILES tiles (the cross-attention K / V projections: 80 tiles of
+// 256 x 320 leave two thirds of the chip idle, the 128-row grid does not).  E2V_BGEMM_T256 = 0 switches the kernel off (A/B).
+// (v_mfma_f32_16x16x32_bf16 here, 32x32x16 there: both walk k in the same order and -- measured on every shape of
+// tests/test_hip_ops.py::test_bf16_t256_linear -- agree bit for bit, so the choice of kernel does not change a result.)
 static int t256_tile_cols(const IgemmArgs& a) {
     static const int* const on = knob("E2V_BGEMM_T256", 1);
-    static const int* const mink = knob("E2V_BGEMM_T256_MINK", 640);
+    static const int* const mink = knob("E2V_BGEMM_T256_MINK", 320);
+    static const int* const mintiles = knob("E2V_BGEMM_T256_MINTILES", 160);
     if (!*on || !a.a_bf16 || a.batch != 1 || a.upsample || (a.taps != 1 && a.taps != 9)) return 0;
-    if (a.c0 <= 0 || a.c0 % 64 || a.c1 % 64 || a.taps * (a.c0 + a.c1) < *mink) return 0;
-    if (a.geglu) return a.N % 256 == 0 ? 256 : 0;
-    if ((a.N | a.ldc | a.ldr) & 7 || (a.rb_ld & 3)) return 0;
-    if (a.N % 320 == 0) return 320;
-    if (a.N % 256 == 0) return 256;
-    return 0;
+    const int Kc = a.c0 + a.c1;
+    if (a.c0 <= 0 || a.c0 % 64 || a.c1 % 64 || a.taps * Kc < *mink) return 0;
+    if (a.taps == 1 && a.resid && Kc <= 640 && *on != 2) return 0;
+    int cols = 0;
+    if (a.geglu) cols = a.N % 256 == 0 ? 256 : 0;
+    else if ((a.N | a.ldc | a.ldr) & 7 || (a.rb_ld & 3)) cols = 0;
+    else if (a.N % 320 == 0) cols = 320;
+    else if (a.N % 256 == 0) cols = 256;
+    if (!cols) return 0;
+    if (a.taps == 9) {          // a tile's rows span at most ceil(256 / (Ho Wo)) + 1 images: their pixel indices must fit 20 bits
+        const long span = (255 / ((long)a.Ho * a.Wo) + 2) * (long)a.Hs * a.Ws;
+        if (span >= (1L << 20)) return 0;
+    }
+    if (*on != 2 && (long)((a.M + 255) / 256) * (a.N / cols) < *mintiles) return 0;
+    return cols;
 }
 
 bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {

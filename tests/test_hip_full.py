@@ -239,15 +239,18 @@ def test_bf16_persistent_gemm_bit_identical_to_the_tile_kernels(full, B):
     lat = torch.stack([_t(counter_normal(4321 + k, "latent", (4, 6, 36, 64))) for k in range(B)]).cuda()
     cond = torch.stack([_t(counter_normal(4400 + k, "cond", (77, 768))) for k in range(B)]).cuda()
     ts = [501]
-    # (E2V_BGEMM_PERS, E2V_BGEMM_256): first entry = one workgroup per 128-row tile everywhere; PERS = 2: wherever the kernel
-    # applies; 256 = 2: 256-row tiles for every conv; (1, 1) = the defaults
-    modes = [(0, 0), (2, 1), (1, 1), (0, 2), (2, 2)]
+    # (E2V_BGEMM_PERS, E2V_BGEMM_256, E2V_BGEMM_T256): first entry = one workgroup per 128-row tile everywhere; PERS = 2: wherever
+    # the kernel applies; 256 = 2: 256-row tiles for every conv; T256 = 2: the deep-pipelined 256 x 256 / 256 x 320 tiles of
+    # bgemm256.hip for every layer whose shape allows them (v_mfma_f32_16x16x32_bf16: same k order, and it rounds like the
+    # 32x32x16 form of the other kernels); (1, 1, 1) = the defaults
+    modes = [(0, 0, 0), (2, 1, 0), (1, 1, 0), (0, 2, 0), (2, 2, 0), (1, 1, 1), (1, 1, 2)]
     outs = []
     try:
         eng.set_compute_dtype("bf16")
-        for pers, m256 in modes:
+        for pers, m256, t256 in modes:
             eng.set_knob("E2V_BGEMM_PERS", pers)
             eng.set_knob("E2V_BGEMM_256", m256)
+            eng.set_knob("E2V_BGEMM_T256", t256)
             eps = eng.unet_forward(lat, ts, cond)
             frames = eng.vae_decode((lat[:1, :, :2] * 0.5).contiguous())
             torch.cuda.synchronize()
@@ -255,12 +258,13 @@ def test_bf16_persistent_gemm_bit_identical_to_the_tile_kernels(full, B):
     finally:
         eng.set_knob("E2V_BGEMM_PERS", 1)
         eng.set_knob("E2V_BGEMM_256", 1)
+        eng.set_knob("E2V_BGEMM_T256", 1)
         eng.set_compute_dtype("fp32")
     for mode, out in zip(modes[1:], outs[1:]):
         for a, b, name in zip(out, outs[0], ("unet", "vae")):
             assert torch.isfinite(a).all()
             diff = (a - b).abs().max().item()
-            print(f"B={B} {name}: PERS/256 = {mode} vs 128-row tile kernels max-abs diff {diff:.3e}")
+            print(f"B={B} {name}: PERS/256/T256 = {mode} vs 128-row tile kernels max-abs diff {diff:.3e}")
             assert torch.equal(a, b), (name, mode)
 
 
