@@ -346,7 +346,9 @@ def test_configs4_sweep_full_size_one_concept_bf16(full, capsys):
     finally:
         eng.set_compute_dtype("fp32")
     assert tuple(a.shape) == (5, 3, 6, 288, 512) and a.dtype == torch.uint8
-    assert rec["clips"] == 5 and rec["clips_per_s"] > 0 and 0 <= rec["host_model_share"] < 1 and rec["generate_share"] > 0.5
+    assert rec["clips"] == 5 and rec["clips_per_s"] > 0 and 0 <= rec["host_model_share"] < 1 and 0 < rec["generate_share"] < 1
+    # (a 5-clip, 4-step first call: the host torch models' first-use initialisation dominates the wall time; the shares of the real
+    # sweep are in profiles/r0x_sweep_*.json)
     diff = (a.int() - b.int()).abs().max().item()
     print(f"configs[4] full size: batch of 5 vs batches of 2+2+1: max uint8 difference {diff}; {rec['clips_per_s']:.3f} clips/s at 4 steps")
     assert diff <= 2
