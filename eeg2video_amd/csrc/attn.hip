@@ -1028,6 +1028,161 @@ __global__ __launch_bounds__(128) void temporal_attn_lds_kernel(const T* __restr
     }
 }
 
+// One pixel per heads x LH lanes, no LDS: lane (head, c) owns the 8 channels c of its head in every frame -- 16-byte loads (bf16; two for
+// fp32 rows) that cover a pixel's row contiguously, every byte of q, k, v read once and all 3 F rows of a wave in flight together --,
+// the F x F scores are partial dot products over those 8 channels all-reduced over the head's LH
+// lanes with DPP adds (quad_perm, row_half_mirror, row_mirror: no LDS, no ds_bpermute below 32 lanes), every lane then runs the
+// softmax of its head and the P V product of its own 8 channels.  LH = lanes per head = D / 8 rounded up to a power of two (D = 40:
+// 5 of 8 lanes carry data, the loads of the other 3 are masked); the staged kernel below spent its time alternating a load phase
+// and a compute phase in which 24 of a block's 128 threads worked (1.6 TB/s at level 0).
+template <int LH>
+__device__ __forceinline__ float head_allreduce(float x) {
+    auto dpp = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    x += dpp(x, std::integral_constant<int, 0xB1>{});                       // quad_perm [1,0,3,2]
+    x += dpp(x, std::integral_constant<int, 0x4E>{});                       // quad_perm [2,3,0,1]
+    if constexpr (LH >= 8) x += dpp(x, std::integral_constant<int, 0x141>{});   // row_half_mirror: the other quad of the 8
+    if constexpr (LH >= 16) x += dpp(x, std::integral_constant<int, 0x140>{});  // row_mirror: the other 8 of the 16
+    if constexpr (LH >= 32) x += __shfl_xor(x, 16);
+    return x;
+}
+
+template <typename T, int F, int D>
+__global__ __launch_bounds__(256) void temporal_attn_wave_kernel(const T* __restrict__ qkv, int ld, T* __restrict__ out, int ldo, int HW,
+                                                                 long npix, int heads, float scale) {
+    constexpr int CH = D / 8;
+    constexpr int LH = CH <= 4 ? 4 : CH <= 8 ? 8 : CH <= 16 ? 16 : 32;
+    constexpr bool B16 = std::is_same<T, __bf16>::value;
+    const int lpp = heads * LH;                                  // lanes per pixel (divides 256: launcher)
+    const int t = threadIdx.x;
+    const int lp = t % lpp;
+    const int head = lp / LH, c = lp % LH;
+    const long g = (long)blockIdx.x * (256 / lpp) + t / lpp;
+    const bool on = c < CH && g < npix;
+    const long gg = g < npix ? g : npix - 1;
+    const long smp = gg / HW;
+    const int pix = (int)(gg - smp * HW);
+    const int C = heads * D;
+    const T* base = qkv + ((size_t)(smp * F) * HW + pix) * ld + head * D + (c < CH ? c : 0) * 8;
+    const size_t fs = (size_t)HW * ld;
+    typedef float f8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    auto ld16 = [&](const T* p) -> u4 { return on ? *reinterpret_cast<const u4*>(p) : u4{0u, 0u, 0u, 0u}; };
+    auto ld8f = [&](const T* p) -> f8 {
+        f8 r = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (on) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + 4);
+            r = f8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        }
+        return r;
+    };
+    float s[F][F];
+    if constexpr (B16) {
+        u4 q[F], k[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) { q[f] = ld16(base + f * fs); k[f] = ld16(base + f * fs + C); }
+        // (bf16 -> fp32 is a shift: the element is the high half of the float.  v_dot2c_f32_bf16 would take the packed pairs as they
+        // are, but its result feeding a DPP add came out wrong on gfx950 / ROCm 7.2 -- tools/micro/dot2_check.hip shows the
+        // instruction itself is right -- and the kernel is bound by its loads either way)
+        auto lo = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
+        auto hi = [](unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); };
+#pragma unroll
+        for (int i = 0; i < F; ++i)
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a = __builtin_fmaf(lo(q[i][e]), lo(k[j][e]), a);
+                    a = __builtin_fmaf(hi(q[i][e]), hi(k[j][e]), a);
+                }
+                s[i][j] = a;
+            }
+    } else {
+        f8 q[F], k[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) { q[f] = ld8f(base + f * fs); k[f] = ld8f(base + f * fs + C); }
+#pragma unroll
+        for (int i = 0; i < F; ++i)
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a = __builtin_fmaf(q[i][e], k[j][e], a);
+                s[i][j] = a;
+            }
+    }
+    // the value rows: in flight under the reduction and the softmax
+    u4 v16[B16 ? F : 1];
+    f8 v32[B16 ? 1 : F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        if constexpr (B16) v16[f] = ld16(base + f * fs + 2 * C); else v32[f] = ld8f(base + f * fs + 2 * C);
+    }
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            s[i][j] = head_allreduce<LH>(s[i][j]) * scale;
+            m = fmaxf(m, s[i][j]);
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            s[i][j] = __expf(s[i][j] - m);
+            l += s[i][j];
+        }
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int j = 0; j < F; ++j) s[i][j] *= inv;
+    }
+    T* ob = out + ((size_t)(smp * F) * HW + pix) * ldo + head * D + (c < CH ? c : 0) * 8;
+    const size_t ofs = (size_t)HW * ldo;
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        f8 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            if constexpr (B16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                    // bf16 -> fp32: the element IS the high half of the float
+                    o[2 * e] = __builtin_fmaf(s[i][j], __builtin_bit_cast(float, v16[j][e] << 16), o[2 * e]);
+                    o[2 * e + 1] = __builtin_fmaf(s[i][j], __builtin_bit_cast(float, v16[j][e] & 0xFFFF0000u), o[2 * e + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(s[i][j], v32[j][e], o[e]);
+            }
+        }
+        if (on) {
+            if constexpr (B16) {
+                abf16x8 ob8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ob8[e] = (__bf16)o[e];
+                *reinterpret_cast<abf16x8*>(ob + i * ofs) = ob8;
+            } else {
+                *reinterpret_cast<f32x4*>(ob + i * ofs) = f32x4{o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ob + i * ofs) + 4) = f32x4{o[4], o[5], o[6], o[7]};
+            }
+        }
+    }
+}
+
+template <typename T, int D>
+static bool temporal_wave_launch(const T* qkv, int ld, T* out, int ldo, int n, int F, int HW, int heads, float scale, hipStream_t s) {
+    constexpr int CH = D / 8, LH = CH <= 4 ? 4 : CH <= 8 ? 8 : CH <= 16 ? 16 : 32;
+    const int lpp = heads * LH;
+    if (F != 6 || lpp > 256 || 256 % lpp || (ld % 8) || (ldo % 8)) return false;
+    const long npix = (long)n * HW;
+    const int ppb = 256 / lpp;
+    hipLaunchKernelGGL((temporal_attn_wave_kernel<T, 6, D>), dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, s, qkv, ld, out, ldo, HW, npix, heads,
+                       scale);
+    return true;
+}
+
 template <typename T>
 static void temporal_attention_launch(const T* qkv, int ld, T* out, int ldo, int n, int F, int HW, int heads, int D, float scale,
                                       hipStream_t s);
@@ -1048,6 +1203,21 @@ static void temporal_attention_launch(const T* qkv, int ld, T* out, int ldo, int
                                       hipStream_t s) {
     const size_t total = (size_t)n * HW * heads * F;
     const int C = heads * D;
+    static const bool wave_on = [] { const char* e = std::getenv("E2V_TATTN_WAVE"); return !e || std::atoi(e) != 0; }();
+    if (wave_on) {
+        bool done = false;
+        switch (D) {
+            case 8: done = temporal_wave_launch<T, 8>(qkv, ld, out, ldo, n, F, HW, heads, scale, s); break;
+            case 16: done = temporal_wave_launch<T, 16>(qkv, ld, out, ldo, n, F, HW, heads, scale, s); break;
+            case 32: done = temporal_wave_launch<T, 32>(qkv, ld, out, ldo, n, F, HW, heads, scale, s); break;
+            case 40: done = temporal_wave_launch<T, 40>(qkv, ld, out, ldo, n, F, HW, heads, scale, s); break;
+            case 64: done = temporal_wave_launch<T, 64>(qkv, ld, out, ldo, n, F, HW, heads, scale, s); break;
+            case 80: done = temporal_wave_launch<T, 80>(qkv, ld, out, ldo, n, F, HW, heads, scale, s); break;
+            case 160: done = temporal_wave_launch<T, 160>(qkv, ld, out, ldo, n, F, HW, heads, scale, s); break;
+            default: break;
+        }
+        if (done) return;
+    }
     // slab of whole heads and pixel count such that the staged q/k/v (fp32 in LDS whatever the storage type) fit 16 KB: with
     // 48 KB (3 blocks of 2 waves per CU) the load phase had too little in flight -- 0.60 -> 0.33 ms at level 0
     static const size_t budget = [] { const char* e = std::getenv("E2V_TATTN_LDS_KB"); return (size_t)(e ? std::atoi(e) : 16) * 1024; }();
