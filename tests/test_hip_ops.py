@@ -460,7 +460,7 @@ def bf256(bf):
     bf.set_knob("E2V_BGEMM_T256", 1)
 
 
-@pytest.mark.parametrize("m,k,n,resid", [(240, 1280, 1280, True), (300, 320, 960, False), (1000, 320, 320, True), (1000, 640, 320, True), (4097, 704, 640, False), (256, 640, 512, True),
+@pytest.mark.parametrize("m,k,n,resid", [(240, 1280, 1280, True), (300, 320, 960, False), (1000, 320, 320, True), (70001, 320, 960, True), (1000, 640, 320, True), (4097, 704, 640, False), (256, 640, 512, True),
                                          (777, 1920, 256, False), (513, 2560, 320, True), (64, 640, 960, False)])
 def test_bf16_t256_linear(bf256, m, k, n, resid):
     bf = bf256
@@ -475,16 +475,35 @@ def test_bf16_t256_linear(bf256, m, k, n, resid):
     finally:
         bf.set_knob("E2V_BGEMM_T256", 2)
     assert torch.equal(y, y0)           # same k order, and the two MFMA shapes round alike: the dispatcher's choice never changes a result
+    # the persistent form (workgroups walk a tile list, the DMA stream runs on across tile boundaries, register epilogue) against the
+    # one-tile-per-workgroup form: P = 2 forces it on every linear, P = 0 switches it off
+    outs = []
+    for pers in (2, 0):
+        bf.set_knob("E2V_BGEMM_T256P", pers)
+        try:
+            outs.append(bf.op_linear(x.cuda(), w.cuda(), b.cuda(), r.cuda() if resid else None))
+        finally:
+            bf.set_knob("E2V_BGEMM_T256P", 1)
+    close(outs[0], ref, rtol=1e-4, atol=1e-4)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], y0)
     print(f"T256 vs bgemm.hip tiles (m={m}, k={k}, n={n}): bit-identical = {torch.equal(y, y0)}, max |diff| = {(y - y0).abs().max().item():.3e}")
 
 
-@pytest.mark.parametrize("m,k,n", [(300, 640, 512), (1000, 1280, 2560), (130, 704, 5120)])
+@pytest.mark.parametrize("m,k,n", [(300, 640, 512), (1000, 1280, 2560), (130, 704, 5120), (70000, 320, 512)])
 def test_bf16_t256_geglu(bf256, m, k, n):
     bf = bf256
     """GEGLU projection (attention.py:189): packed width n = 2 x out, value / gate interleaved per 64 columns -> 256 x 256 tiles."""
     x, w, b = rnd(m, k, seed=130), rnd(n, k, seed=131, scale=0.05), rnd(n, seed=132)
     hh, gg = F.linear(rb(x), rb(w), b).chunk(2, dim=-1)
-    close(bf.op_linear(x.cuda(), w.cuda(), b.cuda(), geglu=True), hh * F.gelu(gg), rtol=1e-4, atol=1e-4)
+    outs = []
+    for pers in (2, 0):
+        bf.set_knob("E2V_BGEMM_T256P", pers)
+        try:
+            outs.append(bf.op_linear(x.cuda(), w.cuda(), b.cuda(), geglu=True))
+        finally:
+            bf.set_knob("E2V_BGEMM_T256P", 1)
+    close(outs[0], hh * F.gelu(gg), rtol=1e-4, atol=1e-4)
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("cin,cout,n,h,w,stride", [(128, 320, 3, 9, 16, 1), (64, 640, 2, 18, 32, 1), (192, 320, 7, 5, 8, 1), (128, 256, 1, 36, 64, 1),
