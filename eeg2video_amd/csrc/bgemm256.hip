@@ -823,14 +823,18 @@ bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, a);
     };
-    // linears: the persistent form (E2V_BGEMM_T256P: 0 never, 1 linears up to E2V_BGEMM_T256P_MAXK deep with at least two tiles per
-    // workgroup, 2 every linear)
+    // linears: the persistent form (E2V_BGEMM_T256P: 0 never, 2 every linear, 1 where it measured faster in a same-box A/B over the
+    // linears of a B = 32 UNet step, profiles/r03_shape_ab_t256p.log: the GEGLU projections -9..-23 % (their erf epilogue runs with the
+    // next tile's K steps in flight) and the projections with a residual at K >= 1280 -3..-13 %; the wide residual-free ones (QKV,
+    // concat shortcuts) are 3-11 % SLOWER -- 8-byte stores from the accumulator layout against the staged epilogue's 16-byte row
+    // segments -- and stay on one tile per workgroup), with at least two tiles per workgroup
     static const int* const persp = knob("E2V_BGEMM_T256P", 1);
     static const int* const pmaxk = knob("E2V_BGEMM_T256P_MAXK", 1 << 30);
     const long ntiles = (long)a.nbm * nct;
+    const bool pays = a.geglu || (a.resid && a.c0 + a.c1 >= 1280);
     // (the epilogue reads the residual in the output's type: fp32 with fp32 at the test entry points, bf16 with bf16 in the graph)
     const bool io_ok = !a.resid || (a.out_f32 ? !a.resid_bf16 : a.resid_bf16 != 0);
-    if (lin && io_ok && *persp && (*persp == 2 || (a.c0 + a.c1 <= *pmaxk && ntiles >= 512))) {
+    if (lin && io_ok && *persp && (*persp == 2 || (pays && a.c0 + a.c1 <= *pmaxk && ntiles >= 512))) {
         auto gop = [&](auto kern) {
             static bool cfg = false;
             if (!cfg) {
