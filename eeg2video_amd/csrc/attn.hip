@@ -272,14 +272,23 @@ typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
 // through the transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads 4 keys x 16 value columns and gets them
 // column-major), so there is no transposed staging.  The softmax scale rides in the exponent's FMA instead of being
 // multiplied into a bf16 Q.  Scores, softmax and the O accumulator are fp32.
-template <int D>
+// FOLD: the running maximum is subtracted by the MATRIX pipe -- Q is pre-multiplied by scale * log2(e) (rounded to bf16 once), and the
+// score chain K Q^T starts from an accumulator block that holds -m (16 registers, rewritten only when a row's maximum moves), so
+// that the scores come out of the MFMA as exponents: the 16 fused multiply-adds per key tile of the plain form disappear from a loop
+// that is bound by its vector instructions (16 v_exp_f32 + 8 conversions + the maximum are what is left).
+// KT: keys per LDS stage (32 or 64: one barrier per 64 keys -- the four waves of a workgroup sit on four SIMDs, each shared with
+// three other workgroups, and every barrier couples them).
+template <int D, bool FOLD, int KT>
 __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p) {
     constexpr int DP = (D + 15) / 16 * 16;      // head dim padded to the 16-deep MFMA step
     constexpr int KS = DP / 16;
     constexpr int T = (D + 31) / 32;            // 32-row tiles of O^T
     constexpr int KROW = DP * 2 + 16;           // bytes per K row: conflict-free ds_read_b128 of 16 rows
-    constexpr int VROW = T * 64 + 16;           // bytes per V row (the tr reads of the last tile may run past D: they stay inside the row)
-    constexpr int KBYTES = 32 * KROW, VBYTES = 32 * VROW;
+    // bytes per V row: T * 64 of data (the tr reads of the last tile may run past D: they stay inside the row), and a row stride of
+    // 16 or 48 dwords mod 64, so that the four rows a half-wave's transposing read touches (2 x 8 dwords each) tile the 64 banks exactly;
+    // with the former T * 64 + 16 the reads of rows q and q + 2 met on 8 banks (SQ_LDS_BANK_CONFLICT: 40 % of the LDS cycles)
+    constexpr int VROW = ((T * 16) % 32 == 16) ? T * 64 : T * 64 + 64;
+    constexpr int KBYTES = KT * KROW, VBYTES = KT * VROW;
     constexpr int STAGE = (KBYTES + VBYTES + 15) / 16 * 16;
     // Row sums on the matrix pipe: when D is not a multiple of 32 the last 32-row tile of O^T has spare rows, and a value
     // column of ONES at index D makes row D of O^T the softmax denominator (rescaled with the accumulator, summed over the
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
     constexpr bool SUMV = (D % 32) != 0;
     constexpr int LROW = D % 32, LREG = 4 * (LROW / 8) + (LROW & 3), LHALF = (LROW >> 2) & 1;
     constexpr int C8 = D / 8;                   // 16-byte pieces per row
-    constexpr int NP = 32 * C8;
+    constexpr int NP = KT * C8;
     constexpr int LPT = (NP + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem_h[];      // [2][K rows | V rows]
 
@@ -312,15 +321,15 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
     } else {
         kvbase[0] = kvbase[1] = (size_t)smp * p.Nk;
     }
-    const int tps = (p.Nk + 31) / 32;
+    const int tps = (p.Nk + KT - 1) / KT;
     const int ntiles = nseg * tps;
 
     for (int i = tid * 16; i < 2 * STAGE; i += 256 * 16)                // pad columns are never rewritten: keep them finite
         *reinterpret_cast<f32x4*>(smem_h + i) = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (SUMV) {
         __syncthreads();
-        if (tid < 64)                                                       // value column D of every key row, both stages: 1.0
-            *reinterpret_cast<__bf16*>(smem_h + (tid >> 5) * STAGE + KBYTES + (tid & 31) * VROW + D * 2) = (__bf16)1.0f;
+        if (tid < 2 * KT)                                                   // value column D of every key row, both stages: 1.0
+            *reinterpret_cast<__bf16*>(smem_h + (tid / KT) * STAGE + KBYTES + (tid % KT) * VROW + D * 2) = (__bf16)1.0f;
     }
 
     abf16x8 qf[KS];
@@ -334,6 +343,11 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] = (__bf16)0.f;
             if (k0 < D) a = *reinterpret_cast<const abf16x8*>(qp + k0);
+            if constexpr (FOLD) {
+                const float qs = p.scale * 1.44269504088896340736f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = (__bf16)((float)a[e] * qs);
+            }
             qf[s] = a;
         }
     }
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
 #pragma unroll
         for (int e = 0; e < LPT; ++e) {
             unsigned off = ld_off[e];
-            if (left < 32) off = ld_row[e] < left ? off : OOB;  // ragged last tile of a segment only
+            if (left < KT) off = ld_row[e] < left ? off : OOB;  // ragged last tile of a segment only
             kreg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
             vreg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
         }
@@ -388,6 +402,9 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float m_i = -INFINITY, l_i = 0.f;
+    f32x16 negm;                                 // FOLD: -(running maximum) of the lane's query, in every register of the block
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 
     load_tile(0, 0);
     store_tile(0);
@@ -404,45 +421,81 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
         const int buf = tt & 1;
         if (tt == tps) key0 = 0;                                  // second key segment
         if (tt + 1 < ntiles) {
-            if (tt + 1 == tps) load_tile(1, 0); else load_tile(tt + 1 > tps ? 1 : 0, key0 + 32);
+            if (tt + 1 == tps) load_tile(1, 0); else load_tile(tt + 1 > tps ? 1 : 0, key0 + KT);
         }
-        if (active) {
-            const char* Kl = smem_h + buf * STAGE;
-            const char* Vl = Kl + KBYTES;
+#pragma unroll
+        for (int sub = 0; sub < KT / 32; ++sub) {
+        const int keyb = key0 + 32 * sub;                           // first key of this 32-key block
+        if (active && keyb < p.Nk) {
+            const char* Kl = smem_h + buf * STAGE + sub * 32 * KROW;
+            const char* Vl = smem_h + buf * STAGE + KBYTES + sub * 32 * VROW;
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             f32x16 st;
             const char* kp = Kl + j * KROW + h * 16;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const abf16x8 kf = *reinterpret_cast<const abf16x8*>(kp + s * 32);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? zero16 : st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? (FOLD ? negm : zero16) : st, 0, 0, 0);
             }
-            if (key0 + 32 > p.Nk) {
+            if (keyb + 32 > p.Nk) {
+                asm volatile("" ::: "memory");                  // (rare path: keep it a branch -- if-converted, its 48 selects run on every tile)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int key = keyb + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (key >= p.Nk) st[r] = -INFINITY;
                 }
             }
             float mt = st[0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mt = __builtin_fmaxf(mt, st[r]);
-            mt = __builtin_fmaxf(mt, __shfl_xor(mt, 32)) * sc;             // sc > 0: max commutes with the scaling
-            const float m_new = __builtin_fmaxf(m_i, mt);
-            const bool moved = __any(m_new > m_i);
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                st[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc, -m_new));
-                if constexpr (!SUMV) ps += st[r];
-            }
+            for (int r = 1; r < 16; ++r) mt = __builtin_fmaxf(mt, st[r]);      // (a chain of v_max3_f32)
             float alpha = 1.0f;
-            if (moved) {
-                alpha = __builtin_amdgcn_exp2f(m_i - m_new);
-                if constexpr (!SUMV) l_i *= alpha;
+            bool moved;
+            if constexpr (FOLD) {
+                // st = scaled score - m_i: a positive entry is a new maximum.  (First tile: m_i = 0 stands in for "no maximum yet";
+                // the row takes the tile's true maximum whatever its sign.)  The other half-wave's maximum of the same query comes
+                // through v_permlane32_swap (one instruction; __shfl_xor is a ds_bpermute with seven instructions of address arithmetic)
+                {
+                    // v_permlane32_swap a, b: lanes 32-63 of a <-> lanes 0-31 of b.  From two copies of mt: a = the lower half's value in
+                    // both halves, b = the upper half's.  (Inline asm: given through the builtin, hipcc of ROCm 7.2 drops the second
+                    // result.  The two wait states a VALU-written operand needs in front of a permlane are inside the string.)
+                    float a = mt, b = mt;
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+                    mt = __builtin_fmaxf(a, b);
+                }
+                const bool first = tt == 0 && sub == 0;
+                const float d = first ? mt : __builtin_fmaxf(mt, 0.f);
+                moved = __any(d != 0.f);
+                if (moved) {
+                    asm volatile("" ::: "memory");              // (rare after the first tiles: a branch, not 32 subtractions of zero per tile)
+                    alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);       // (first tile: nothing accumulated yet, and -d may be large)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { st[r] -= d; negm[r] -= d; }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r]);
+            } else {
+                mt = __builtin_fmaxf(mt, __shfl_xor(mt, 32)) * sc;             // sc > 0: max commutes with the scaling
+                const float m_new = __builtin_fmaxf(m_i, mt);
+                moved = __any(m_new > m_i);
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc, -m_new));
+                    if constexpr (!SUMV) ps += st[r];
+                }
+                if (moved) {
+                    alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+                    if constexpr (!SUMV) l_i *= alpha;
+                }
+                if constexpr (!SUMV) l_i += ps;
+                m_i = m_new;
             }
-            if constexpr (!SUMV) l_i += ps;
-            m_i = m_new;
+            if constexpr (FOLD && !SUMV) {
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ps += st[r];
+                l_i = l_i * alpha + ps;
+            }
             abf16x8 pf[2];                       // P^T fragments: registers 8s..8s+7 are k-step s as they stand
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -451,6 +504,7 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 if (moved) {
+                    asm volatile("" ::: "memory");
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
                 }
@@ -464,9 +518,10 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
                 }
             }
         }
+        }
         if (tt + 1 < ntiles) store_tile(buf ^ 1);
         __syncthreads();
-        key0 += 32;
+        key0 += KT;
     }
 
     float l_tot;
@@ -492,21 +547,28 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
 
 template <int D>
 static void launch_flash_b16io(const AttnArgs& a, hipStream_t s) {
-    static bool configured = false;
     constexpr int DP = (D + 15) / 16 * 16, T = (D + 31) / 32;
-    constexpr size_t stage = ((size_t)32 * (DP * 2 + 16) + (size_t)32 * (T * 64 + 16) + 15) / 16 * 16;
-    constexpr size_t smem = 2 * stage;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_b16io_kernel<D>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        configured = true;
-    }
+    constexpr int VROW = ((T * 16) % 32 == 16) ? T * 64 : T * 64 + 64;      // as in the kernel
+    auto stage_bytes = [](const int kt) { return ((size_t)kt * (DP * 2 + 16) + (size_t)kt * VROW + 15) / 16 * 16; };
+    static const int* const fold = knob("E2V_ATTN_FOLD", 1);     // 0: the plain form (scale and maximum applied by vector FMAs)
+    static const int* const kt64 = knob("E2V_ATTN_KT64", 1);     // 0: 32-key stages (one barrier per 32 keys)
     dim3 grid((a.Nq + 127) / 128, a.heads, a.n * a.F);
     const double nk = a.mode == 0 ? 2.0 * a.Nk : (double)a.Nk;
     const double probs = (double)a.n * a.F * a.heads;
     ProfScope ps(a.mode == 0 ? "flash_attn_bf16_sparse_causal" : "flash_attn_bf16_cross", 4.0 * probs * a.Nq * nk * D,
                  2.0 * probs * D * (2.0 * a.Nq + 2.0 * (a.mode == 0 ? a.Nk : (double)a.Nk / a.F)), s);
-    hipLaunchKernelGGL((flash_attn_b16io_kernel<D>), grid, dim3(256), smem, s, a);
+    auto go = [&](auto kern, const int kt) {
+        static bool configured = false;
+        const size_t smem = 2 * stage_bytes(kt);
+        if (!configured) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * stage_bytes(64)));
+            configured = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+    };
+    const bool wide = *kt64 && a.Nk > 32;
+    if (*fold) { if (wide) go(flash_attn_b16io_kernel<D, true, 64>, 64); else go(flash_attn_b16io_kernel<D, true, 32>, 32); }
+    else       { if (wide) go(flash_attn_b16io_kernel<D, false, 64>, 64); else go(flash_attn_b16io_kernel<D, false, 32>, 32); }
 }
 
 // =====================================================================================================

@@ -1,18 +1,31 @@
-"""Micro-benchmark of the sparse-causal attention kernel at the UNet's level-0..2 shapes (B = 8 -> 16 samples)."""
-import os, sys, time
+"""Micro-benchmark of the sparse-causal attention kernel at the UNet's level-0..2 shapes: fp32 (B = 8 -> 16 samples) and bf16 rows
+(B = 32 -> 64 samples), HIP-event kernel time; the bf16 variants (E2V_ATTN_FOLD, E2V_ATTN_KT64) A/B'd in one process, interleaved."""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from eeg2video_amd.engine import Engine
 from eeg2video_amd.weights import TINY_UNET, TINY_VAE
 eng = Engine(TINY_UNET, TINY_VAE, 0)
-reps = int(os.environ.get("REPS", "3"))
-for name, n, f, nq, d in [("L0 d40", 16, 6, 2304, 40), ("L1 d80", 16, 6, 576, 80), ("L2 d160", 16, 6, 144, 160)]:
-    heads = 8; c = heads * d
-    qkv = torch.randn(n * f * nq, 3 * c, device="cuda")
-    fn = lambda: eng.op_attention(qkv[:, :c], qkv[:, c:2*c], qkv[:, 2*c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5)
-    fn(); torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
-        torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-    alg = 4.0 * n * f * heads * nq * (2 * nq) * d
-    print(f"{name}: {min(ts)*1e3:.3f} ms  {alg/min(ts)/1e12:.1f} TF algorithmic")
+reps = int(os.environ.get("REPS", "4"))
+shapes = [("L0 d40", 6, 2304, 40), ("L1 d80", 6, 576, 80), ("L2 d160", 6, 144, 160)]
+def run(mode, n, variants):
+    eng.set_compute_dtype(mode)
+    for name, f, nq, d in shapes:
+        heads = 8; c = heads * d
+        qkv = torch.randn(n * f * nq, 3 * c, device="cuda")
+        best = {v: 1e9 for v in variants}
+        for _ in range(reps):
+            for v in variants:
+                for kv in v.split(","):
+                    if kv:
+                        k, val = kv.split("="); eng.set_knob(k, int(val))
+                eng.profile_begin()
+                eng.op_attention(qkv[:, :c], qkv[:, c:2*c], qkv[:, 2*c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5)
+                pr = eng.profile_end()
+                ms = [x["ms"] for kx, x in pr.items() if kx.startswith("flash_attn")][0]
+                best[v] = min(best[v], ms)
+        alg = 4.0 * n * f * heads * nq * (2 * nq) * d
+        print(f"{mode} {name} n={n}: " + "  ".join(f"[{v or 'default'}] {best[v]:.3f} ms {alg/best[v]/1e9:.0f} TF" for v in variants))
+run("fp32", 16, [""])
+run("bf16", 64, ["E2V_ATTN_FOLD=0,E2V_ATTN_KT64=0", "E2V_ATTN_FOLD=1,E2V_ATTN_KT64=0", "E2V_ATTN_FOLD=0,E2V_ATTN_KT64=1", "E2V_ATTN_FOLD=1,E2V_ATTN_KT64=1"])
+eng.set_compute_dtype("fp32")

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 run() {   # name, counters
-    rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/$1 -o p -- python3 $R/tools/igemm_micro.py > $OUT/$1.log 2>&1 || echo "pass $1 failed"
+    rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/$1 -o p -- python3 $R/${MICRO:-tools/igemm_micro.py} > $OUT/$1.log 2>&1 || echo "pass $1 failed"
 }
 run a "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INSTS_VALU"
 run b "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAVES"
