@@ -543,3 +543,35 @@ def test_bf16_t256_conv3x3_geometries(bf256):
     yc = bf.op_conv3x3(to_cl(a).cuda(), wc.cuda(), bc.cuda(), x1=to_cl(s).cuda(), n_img=nn, Hs=h, Ws=w,
                        rowbias=temb.cuda().contiguous(), rows_per_sample=f * h * w, resid=to_cl(res).cuda())
     close(from_cl(yc, nn, h, w), refc, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("boost", [3.0, 25.0])
+def test_bf16_attention_deferred_maximum_branches(eng, boost):
+    """bf16 attention keeps a row's reference maximum until a score exceeds it by more than 2^8 (the rescale of the accumulators is
+    a wave-level branch that would otherwise run on most key tiles).  Both sides of that threshold against a FULL fp32 reference on
+    the bf16-rounded inputs: late keys (3rd and 5th 32-key tile, second key segment too) boosted 3x -- their scores top the running
+    maximum by LESS than the threshold: the deferred path, probabilities above 1 -- and 25x: far above it, the rescale branch.  Rows
+    come out wrong by O(0.1) if either path scales the accumulator, the pending probabilities or the normaliser inconsistently."""
+    heads, d, n, f, nq = 8, 40, 1, 3, 200
+    c = heads * d
+    qkv = rnd(n * f * nq, 3 * c, seed=153)
+    for key in (70, 150, 2 * nq + 130, nq + 190):
+        qkv[key, c:2 * c] *= boost
+    qb = qkv.to(torch.bfloat16).float()
+    q, k, v = (qb[:, i * c:(i + 1) * c].reshape(n * f, nq, c) for i in range(3))
+    former = torch.arange(f) - 1
+    former[0] = 0
+    gather = lambda t: torch.cat([t.reshape(n, f, nq, c)[:, [0] * f], t.reshape(n, f, nq, c)[:, former]], dim=2).reshape(n * f, 2 * nq, c)
+    ref = _unheads(_ref_attn(_heads(q, heads), _heads(gather(k), heads), _heads(gather(v), heads), d ** -0.5), heads)
+    try:
+        eng.set_compute_dtype("bf16")
+        g = qkv.cuda()
+        outs = []
+        for fold in (1, 0):
+            eng.set_knob("E2V_ATTN_FOLD", fold)
+            outs.append(eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5))
+    finally:
+        eng.set_knob("E2V_ATTN_FOLD", 1)
+        eng.set_compute_dtype("fp32")
+    for y in outs:
+        close(y.reshape(n * f, nq, c), ref, rtol=2e-2, atol=2e-2)
