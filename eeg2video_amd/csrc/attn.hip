@@ -607,7 +607,9 @@ static void launch_flash_b16io(const AttnArgs& a, hipStream_t s) {
         }
         hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
     };
-    const bool wide = *kt64 && a.Nk > 32;
+    // 64-key stages halve the barriers per key, but at D = 160 two such stages are 84 KB and only one block fits a CU (measured: 224 vs
+    // 344 TFLOP/s at the 12x12 level) -- keep them to the head sizes where three blocks still fit
+    const bool wide = *kt64 && a.Nk > 32 && 2 * stage_bytes(64) <= 52 * 1024;
     if (*fold) { if (wide) go(flash_attn_b16io_kernel<D, true, 64>, 64); else go(flash_attn_b16io_kernel<D, true, 32>, 32); }
     else       { if (wide) go(flash_attn_b16io_kernel<D, false, 64>, 64); else go(flash_attn_b16io_kernel<D, false, 32>, 32); }
 }

@@ -11,6 +11,7 @@
 #include "kernels.h"
 #include "prof.h"
 #include "act_io.h"
+#include <type_traits>
 
 namespace e2v {
 
@@ -259,6 +260,54 @@ __global__ __launch_bounds__(256) void gn_apply8_kernel(const __bf16* __restrict
     }
 }
 
+// Row-tiled form of the pass above: grid (chunks, slabs) like the statistics pass, thread -> (row r of R at a time, octet q of OT side by
+// side), the scale / shift pairs of the thread's eight channels held in registers over the rows of the chunk, four rows in flight
+// per thread.  No index division (the flat form above spent more vector instructions on a 64-bit i / CO than on the affine),
+// and SiLU as x * rcp(1 + exp2(-x log2 e)): two transcendentals and three plain instructions per value.
+__device__ __forceinline__ float silu_fast(float v) {
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+}
+template <bool ACT>
+__global__ __launch_bounds__(256) void gn_apply8_rows_kernel(const __bf16* __restrict__ x0, const __bf16* __restrict__ x1, int c0, int c1,
+                                                             int ld0, int ld1, const float* __restrict__ scsh, __bf16* __restrict__ out,
+                                                             int ldo, int P, int OT) {
+    const int chunk = blockIdx.x, slab = blockIdx.y;
+    const int R = 256 / OT;
+    const int q = threadIdx.x % OT, r = threadIdx.x / OT;
+    if (r >= R) return;
+    const int p0 = chunk * GN_ROWS_PER_CHUNK;
+    const int p1 = min(P, p0 + GN_ROWS_PER_CHUNK);
+    const int Ctot = c0 + c1;
+    const size_t row0 = (size_t)slab * P;
+    const float* scb = scsh + (size_t)slab * Ctot * 2;
+    for (int q0 = 0; q0 < Ctot / 8; q0 += OT) {             // (OT divides c0 / 8 and c1 / 8: a column tile has one source)
+        const int c = (q0 + q) * 8;
+        const __bf16* col = c < c0 ? x0 + row0 * ld0 + c : x1 + row0 * ld1 + (c - c0);
+        const int ld = c < c0 ? ld0 : ld1;
+        __bf16* dst = out + row0 * ldo + c;
+        const float* sc = scb + (size_t)c * 2;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sc), b = *reinterpret_cast<const f32x4*>(sc + 4);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(sc + 8), e = *reinterpret_cast<const f32x4*>(sc + 12);
+        auto fin = [&](const F8& v, const int pr) {
+            f32x4 lo, hi;
+            lo[0] = v.lo[0] * a[0] + a[1]; lo[1] = v.lo[1] * a[2] + a[3]; lo[2] = v.lo[2] * b[0] + b[1]; lo[3] = v.lo[3] * b[2] + b[3];
+            hi[0] = v.hi[0] * d[0] + d[1]; hi[1] = v.hi[1] * d[2] + d[3]; hi[2] = v.hi[2] * e[0] + e[1]; hi[3] = v.hi[3] * e[2] + e[3];
+            if constexpr (ACT) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { lo[k] = silu_fast(lo[k]); hi[k] = silu_fast(hi[k]); }
+            }
+            st8(dst + (size_t)pr * ldo, lo, hi);
+        };
+        int pr = p0 + r;
+        for (; pr + 3 * R < p1; pr += 4 * R) {
+            const F8 v0 = ld8(col + (size_t)pr * ld), v1 = ld8(col + (size_t)(pr + R) * ld);
+            const F8 v2 = ld8(col + (size_t)(pr + 2 * R) * ld), v3 = ld8(col + (size_t)(pr + 3 * R) * ld);
+            fin(v0, pr); fin(v1, pr + R); fin(v2, pr + 2 * R); fin(v3, pr + 3 * R);
+        }
+        for (; pr < p1; pr += R) fin(ld8(col + (size_t)pr * ld), pr);
+    }
+}
+
 static int oct_tile(int co) {
     int best = 1;
     for (int d = 1; d <= 64 && d <= co; ++d)
@@ -293,21 +342,69 @@ void groupnorm_stats(const GroupNormArgs& a, hipStream_t s) {
     groupnorm_stats_launch(a, s);
 }
 
+static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+// bf16 rows, 16-byte accesses: statistics and apply of one run of samples
+static void groupnorm_bf16_launch(const GroupNormArgs& a, hipStream_t s) {
+    static const int* const rowsp = knob("E2V_GN_ROWS", 1);        // 0: the flat-index apply pass
+    groupnorm_stats_launch(a, s);
+    const int Ctot = a.c0 + a.c1;
+    const size_t rows = (size_t)a.samples * a.P;
+    if (*rowsp) {
+        const int ot = oct_tile(a.c1 > 0 ? gcd_int(a.c0 / 8, a.c1 / 8) : a.c0 / 8);
+        const dim3 grid(groupnorm_chunks(a.P), a.samples);
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0), reinterpret_cast<const __bf16*>(a.x1), a.c0,
+                               a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<__bf16*>(a.out), a.ldo, a.P, ot);
+        };
+        if (a.silu) go(gn_apply8_rows_kernel<true>); else go(gn_apply8_rows_kernel<false>);
+        return;
+    }
+    const size_t tot8 = rows * (Ctot / 8);
+    const int blk8 = (int)((tot8 + 255) / 256 < 16384 ? (tot8 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(gn_apply8_kernel, dim3(blk8), dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0),
+                       reinterpret_cast<const __bf16*>(a.x1), a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<__bf16*>(a.out), a.ldo,
+                       a.P, rows, a.silu);
+}
+
 void groupnorm(const GroupNormArgs& a, hipStream_t s) {
     const int Ctot = a.c0 + a.c1;
     const double elems = (double)a.samples * a.P * Ctot;
     ProfScope ps(a.silu ? "groupnorm_silu" : "groupnorm", 8.0 * elems, 2.0 * (a.bf16 ? 2.0 : 4.0) * elems, s);   // algorithmic: read + write
-    groupnorm_stats_launch(a, s);
     const size_t rows = (size_t)a.samples * a.P;
     const size_t total = rows * (Ctot / 4);
     const int blocks = (int)((total + 511) / 512 < 16384 ? (total + 511) / 512 : 16384);
     if (a.bf16 && a.c0 % 8 == 0 && a.c1 % 8 == 0 && ((a.ld0 | a.ld1 | a.ldo) & 7) == 0) {
-        const size_t tot8 = rows * (Ctot / 8);
-        const int blk8 = (int)((tot8 + 255) / 256 < 16384 ? (tot8 + 255) / 256 : 16384);
-        hipLaunchKernelGGL(gn_apply8_kernel, dim3(blk8), dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0),
-                           reinterpret_cast<const __bf16*>(a.x1), a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<__bf16*>(a.out), a.ldo,
-                           a.P, rows, a.silu);
-    } else if (a.bf16)
+        // The tensor is read twice (statistics, then the affine), and a B = 32 pass normalises 566 MB .. 1.7 GB tensors: the second
+        // read finds nothing in the 256 MiB Infinity Cache.  E2V_GN_GROUP_MB > 0 sends runs of samples of that size through
+        // statistics -> apply one after the other, so that a run's apply pass re-reads what its statistics pass has just brought
+        // on-die.  MEASURED SLOWER at every level (tools/norm_micro.py, 64 samples: 0.32 ms as one run, 0.56 ms in runs of 64 MB,
+        // 0.98 ms in runs of 32 MB at 13824 x 320): a run of 7 samples is 378 workgroups per launch and three dependent launches, the
+        // chip is never full and the launch gaps cost more than the cache returns.  Default 0 = one run; the switch stays for the
+        // measurement.
+        static const int* const group_mb = knob("E2V_GN_GROUP_MB", 0);
+        const double sample_bytes = 2.0 * a.P * Ctot;
+        int per = a.samples;
+        if (*group_mb > 0 && sample_bytes * a.samples > 1.5e6 * *group_mb) {
+            per = (int)(1.0e6 * *group_mb / sample_bytes);
+            if (per < 1) per = 1;
+        }
+        const int chunks = groupnorm_chunks(a.P);
+        for (int g0 = 0; g0 < a.samples; g0 += per) {
+            GroupNormArgs b = a;
+            b.samples = g0 + per <= a.samples ? per : a.samples - g0;
+            const size_t r0 = (size_t)g0 * a.P;
+            b.x0 = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x0) + r0 * a.ld0);
+            if (a.c1 > 0) b.x1 = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x1) + r0 * a.ld1);
+            b.out = reinterpret_cast<float*>(reinterpret_cast<__bf16*>(a.out) + r0 * a.ldo);
+            b.ws_part = a.ws_part + (size_t)g0 * chunks * Ctot * 2;
+            b.ws_scale = a.ws_scale + (size_t)g0 * Ctot * 2;
+            groupnorm_bf16_launch(b, s);
+        }
+        return;
+    }
+    groupnorm_stats_launch(a, s);
+    if (a.bf16)
         hipLaunchKernelGGL(gn_apply_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0),
                            reinterpret_cast<const __bf16*>(a.x1), a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<__bf16*>(a.out), a.ldo,
                            a.P, rows, a.silu);
@@ -450,6 +547,80 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const __bf16* __res
     }
 }
 
+// Sub-wave rows: C = 320 / 640 / 1280 are 40 / 80 / 160 octets -- LPR = 8 / 16 / 32 lanes share a row (five 16-byte octets each, at a lane
+// stride of LPR octets: every load instruction of the wave covers 128 contiguous bytes of 64 / LPR rows), all 64 lanes carry data
+// (the wave-per-row form above: 40 of 64 at C = 320), the two reductions are 3-5 DPP adds inside the row's lanes instead of six
+// wave-wide shuffles, and a wave keeps G row groups in flight.
+template <int LPR>
+__device__ __forceinline__ float rowlanes_allreduce(float x) {
+    auto dpp = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    x += dpp(x, std::integral_constant<int, 0xB1>{});                       // quad_perm [1,0,3,2]
+    x += dpp(x, std::integral_constant<int, 0x4E>{});                       // quad_perm [2,3,0,1]
+    x += dpp(x, std::integral_constant<int, 0x141>{});                      // row_half_mirror: the other quad of the 8
+    if constexpr (LPR >= 16) x += dpp(x, std::integral_constant<int, 0x140>{});  // row_mirror: the other 8 of the 16
+    if constexpr (LPR >= 32) x += __shfl_xor(x, 16);
+    return x;
+}
+template <int LPR, int G>
+__global__ __launch_bounds__(256) void layernorm_bf16_rows_kernel(const __bf16* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, __bf16* __restrict__ out, int ldo,
+                                                                  int rows, float eps) {
+    constexpr int NV = 5, RW = 64 / LPR, C = LPR * NV * 8;
+    const int lane = threadIdx.x & 63;
+    const int c = lane % LPR, rl = lane / LPR;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (RW * G) + rl;
+    if (row0 - rl >= rows) return;
+    F8 v[G][NV];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int row = min(row0 + g * RW, rows - 1);
+        const __bf16* xr = x + (size_t)row * ldx + c * 8;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[g][k] = ld8(xr + k * LPR * 8);
+    }
+    float mean[G], rstd[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            t += ((v[g][k].lo[0] + v[g][k].lo[1]) + (v[g][k].lo[2] + v[g][k].lo[3])) + ((v[g][k].hi[0] + v[g][k].hi[1]) + (v[g][k].hi[2] + v[g][k].hi[3]));
+        mean[g] = rowlanes_allreduce<LPR>(t) * (1.0f / (float)C);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d0 = v[g][k].lo[e] - mean[g], d1 = v[g][k].hi[e] - mean[g];
+                t += d0 * d0 + d1 * d1;
+            }
+        rstd[g] = rsqrtf(rowlanes_allreduce<LPR>(t) * (1.0f / (float)C) + eps);
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int ch = (c + k * LPR) * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch), g1 = *reinterpret_cast<const f32x4*>(gamma + ch + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch), b1 = *reinterpret_cast<const f32x4*>(beta + ch + 4);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (row0 + g * RW < rows) {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = (v[g][k].lo[e] - mean[g]) * rstd[g] * g0[e] + b0[e];
+                    hi[e] = (v[g][k].hi[e] - mean[g]) * rstd[g] * g1[e] + b1[e];
+                }
+                st8(out + (size_t)(row0 + g * RW) * ldo + ch, lo, hi);
+            }
+        }
+    }
+}
+
 template <typename T>
 static void layernorm_launch(const T* x, int ldx, const float* gamma, const float* beta, T* out, int ldo, int rows, int C, float eps,
                              hipStream_t s) {
@@ -465,7 +636,18 @@ static void layernorm_launch(const T* x, int ldx, const float* gamma, const floa
 void layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* out, int ldo, int rows, int C,
                float eps, hipStream_t s, int bf16) {
     ProfScope ps("layernorm", 8.0 * rows * C, 2.0 * (bf16 ? 2.0 : 4.0) * rows * C, s);
-    if (bf16 && C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && C <= 1536) {
+    static const int* const rowsp = knob("E2V_LN_ROWS", 1);         // 0: one wave per row group of four rows
+    if (bf16 && *rowsp && (C == 320 || C == 640 || C == 1280) && ldx % 8 == 0 && ldo % 8 == 0) {
+        const __bf16* xi = reinterpret_cast<const __bf16*>(x);
+        __bf16* xo = reinterpret_cast<__bf16*>(out);
+        auto go = [&](auto kern, const int rows_per_wave) {
+            const int blocks = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, eps);
+        };
+        if (C == 320) go(layernorm_bf16_rows_kernel<8, 2>, 16);
+        else if (C == 640) go(layernorm_bf16_rows_kernel<16, 2>, 8);
+        else go(layernorm_bf16_rows_kernel<32, 2>, 4);
+    } else if (bf16 && C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && C <= 1536) {
         constexpr int R = 4;
         const int blocks = (rows + 4 * R - 1) / (4 * R);
         const __bf16* xi = reinterpret_cast<const __bf16*>(x);

@@ -378,6 +378,53 @@ def test_bf16_norms_and_temporal_attention(bf):
     close(y, ref, rtol=8e-3, atol=8e-3)
 
 
+@pytest.mark.parametrize("c,rows", [(320, 77), (320, 16), (640, 45), (1280, 13), (1280, 4)])
+def test_bf16_layernorm_sub_wave_rows(bf, c, rows):
+    """The LayerNorm whose rows share a wave (8 / 16 / 32 lanes per row at C = 320 / 640 / 1280, E2V_LN_ROWS), ragged last row group:
+    against torch on bf16-rounded input, and against the wave-per-row-group kernel (same arithmetic, other summation order)."""
+    x = rnd(rows, c, seed=140)
+    gl, bl = rnd(c, seed=141), rnd(c, seed=142)
+    ref = F.layer_norm(rb(x), (c,), gl, bl)
+    try:
+        bf.set_knob("E2V_LN_ROWS", 1)
+        y = bf.op_layernorm(x.cuda(), gl.cuda(), bl.cuda())
+        bf.set_knob("E2V_LN_ROWS", 0)
+        y0 = bf.op_layernorm(x.cuda(), gl.cuda(), bl.cuda())
+    finally:
+        bf.set_knob("E2V_LN_ROWS", 1)
+    close(y, ref, rtol=8e-3, atol=8e-3)
+    close(y, y0, rtol=8e-3, atol=8e-3)
+
+
+@pytest.mark.parametrize("c0,c1,groups,silu", [(320, 0, 32, True), (320, 320, 32, True), (640, 320, 32, True), (1280, 640, 32, False), (128, 0, 32, True)])
+def test_bf16_groupnorm_row_tiled_and_sample_runs(bf, c0, c1, groups, silu):
+    """The row-tiled apply pass (E2V_GN_ROWS) and the statistics -> apply runs of samples sized for the Infinity Cache (E2V_GN_GROUP_MB):
+    5 samples x 700 rows (a ragged last row chunk), one or two sources.  Runs of samples change the launch order only: bit-identical
+    to the whole-tensor launch; the row-tiled pass against the flat one: the same affine, SiLU through exp2 / rcp instead of
+    expf / division -> one bf16 rounding; both against torch on bf16-rounded inputs."""
+    samples, P = 5, 700
+    a = rnd(samples * P, c0, seed=130)
+    s = rnd(samples * P, c1, seed=131) if c1 else None
+    g, be = rnd(c0 + c1, seed=132), rnd(c0 + c1, seed=133)
+    xin = (torch.cat([rb(a), rb(s)], 1) if c1 else rb(a)).reshape(samples, P, c0 + c1).permute(0, 2, 1)
+    ref = F.group_norm(xin, groups, g, be, 1e-5)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1).reshape(samples * P, c0 + c1)
+    run = lambda: bf.op_groupnorm(a.cuda(), g.cuda(), be.cuda(), samples=samples, P=P, groups=groups, eps=1e-5, silu=silu,
+                                  x1=s.cuda() if c1 else None)
+    try:
+        bf.set_knob("E2V_GN_ROWS", 1); bf.set_knob("E2V_GN_GROUP_MB", 0)
+        whole = run()
+        bf.set_knob("E2V_GN_GROUP_MB", 1)                     # 0.45 .. 2.7 MB per sample -> runs of one or two samples
+        runs = run()
+        bf.set_knob("E2V_GN_ROWS", 0)
+        flat = run()
+    finally:
+        bf.set_knob("E2V_GN_ROWS", 1); bf.set_knob("E2V_GN_GROUP_MB", 0)
+    assert torch.equal(whole, runs)
+    close(whole, ref, rtol=8e-3, atol=8e-3)
+    close(whole, flat, rtol=8e-3, atol=8e-3)
+
+
 @pytest.mark.parametrize("d,nq,f,n,mode", [(8, 108, 3, 2, 0), (16, 30, 4, 1, 0), (32, 9, 3, 2, 0), (40, 200, 6, 1, 0), (80, 144, 3, 1, 0),
                                            (160, 40, 6, 2, 0), (64, 70, 2, 1, 0), (40, 300, 3, 2, 1), (160, 40, 3, 2, 1)])
 def test_bf16_attention(eng, d, nq, f, n, mode):
