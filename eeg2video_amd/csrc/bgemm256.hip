@@ -23,8 +23,10 @@
 // that reads it.  WAR: every phase's fragment reads are retired (`lgkmcnt(0)`) in front of the barrier that precedes the
 // earliest refill of what they read.  (cdna_hip_programming.md, "The 256^2 8-phase template"; the schedule here is this file's.)
 //
-// The arithmetic is v_mfma_f32_16x16x32_bf16 (bgemm.hip: 32x32x16): the two round differently inside a K = 32 / K = 16 block, so a
-// layer must take the same kernel whatever the batch -- eligibility below depends on the LAYER (N, K, taps), never on M.
+// The arithmetic is v_mfma_f32_16x16x32_bf16 (bgemm.hip: 32x32x16).  Both walk k in the same order with one fp32 accumulator per
+// output, and they agree BIT FOR BIT on every shape of tests/test_hip_ops.py::test_bf16_t256_* and on the whole UNet + VAE decode
+// (tests/test_hip_full.py::test_bf16_persistent_gemm_bit_identical_to_the_tile_kernels), so which kernel a layer takes may depend on
+// M (few-tile launches stay on the 128-row grid) without a clip's result depending on its batch.
 #include "igemm_epi.h"
 #include "prof.h"
 
