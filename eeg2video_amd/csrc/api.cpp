@@ -634,6 +634,15 @@ e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, 
             g.Ho = Ho; g.Wo = Wo; g.Hi = Hi; g.Wi = Wi; g.Hs = Hs; g.Ws = Ws; g.stride = stride; g.pad = pad_lo;
             if (Hi != Hs || Wi != Ws) { g.upsample = 1; g.ups_h = (float)Hs / (float)Hi; g.ups_w = (float)Ws / (float)Wi; }
             g.a_bf16 = 1; g.out_f32 = 1;
+            if (c1 == 0 && c0p == c0 && bgemm_up2x_applies(g)) {   // exact 2x resize: the sub-pixel form the graph runner takes
+                const size_t n = 4 * (size_t)cout * conv_up2x_packed_ld(cin);
+                Act u32(c->pool, (int64_t)((n + 1023) / 1024), 1024), u16(c->pool, (int64_t)((n + 2047) / 2048), 1024);
+                pack_conv_up2x(w_oihw, u32.p, cout, cin, s);
+                to_bf16(u32.p, u16.p, n, s);
+                bgemm_up2x_launch(g, u16.p, s);
+                E2V_HIP(hipGetLastError());
+                return;
+            }
             igemm(g, s);
             E2V_HIP(hipGetLastError());
             return;

@@ -29,6 +29,7 @@
 // M (few-tile launches stay on the 128-row grid) without a clip's result depending on its batch.
 #include "igemm_epi.h"
 #include "prof.h"
+#include "runtime.h"
 
 #include <string>
 
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
     const int img0 = LIN ? 0 : (bm * BM) / hw_out;
     const __bf16* const a0 = reinterpret_cast<const __bf16*>(p.a0);
     const __bf16* const a1 = reinterpret_cast<const __bf16*>(p.a1);
-    const long xrow0 = LIN ? (long)bm * BM : (long)img0 * hw_in - (long)(p.pad * p.Ws + p.pad);
+    const int kw = p.kw, pad_x = p.pad_x < 0 ? p.pad : p.pad_x;       // (3x3: kw = 3, pad_x = pad; the sub-pixel 2x2 kernels: see bgemm_up2x)
+    const long xrow0 = LIN ? (long)bm * BM : (long)img0 * hw_in - (long)(p.pad * p.Ws + pad_x);
     const int xrows = min(BM, p.M - bm * BM);                // valid rows of this tile
     int k_src = 0, k_chunk = 0, k_tap = 0;                   // issue side: source, 64-channel chunk within it, tap
     unsigned ld2 = (unsigned)p.lda0 * 2u;
@@ -128,8 +130,9 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
                     off = (unsigned)(((img - img0) * p.Hs + oy * p.stride) * p.Ws + ox * p.stride);      // a PIXEL index: x row stride at issue
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
-                        const int iy = oy * p.stride - p.pad + t / 3, ix = ox * p.stride - p.pad + t % 3;
-                        mask |= ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) ? (1u << t) : 0u;
+                        const int ky = kw == 2 ? t >> 1 : t / 3, kx = t - kw * ky;
+                        const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - pad_x + kx;
+                        mask |= (t < p.taps && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) ? (1u << t) : 0u;
                     }
                 }
                 x_off[j] = off | (mask << 20);
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
                 rx = x_rsrc();
             }
         }
-        const int dy = LIN ? 0 : k_tap / 3, dx = LIN ? 0 : k_tap - 3 * dy;
+        const int dy = LIN ? 0 : kw == 2 ? k_tap >> 1 : k_tap / 3, dx = LIN ? 0 : k_tap - kw * dy;
         x_so = (unsigned)k_chunk * 128u + (unsigned)(dy * p.Ws + dx) * ld2;
     };
     int w_kt = 0;                                            // K step the W units fetch next (n1 first, n0 advances it)
@@ -395,6 +398,14 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
             for (int r = orow; r < 32; r += rpi) {
                 const int m = bm * BM + wr * 128 + h * 64 + pr * 32 + r;
                 if (!lane_on || m >= p.M) continue;
+                size_t orw = (size_t)m;                      // output row (the sub-pixel kernels scatter their pixels over the 2x map)
+                if constexpr (!LIN) {
+                    if (p.osy) {
+                        const int img = m / hw_out, rem = m - img * hw_out;
+                        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                        orw = ((size_t)img * p.Ho * p.osy + (size_t)(oy * p.osy + p.ooy)) * (size_t)(p.Wo * p.osx) + (size_t)(ox * p.osx + p.oox);
+                    }
+                }
                 f32x4 y0 = *reinterpret_cast<const f32x4*>(st + r * SLD + ocol);
                 f32x4 y1 = *reinterpret_cast<const f32x4*>(st + r * SLD + ocol + 4);
                 if (!geglu) {
@@ -407,12 +418,12 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
                     }
                     if (p.resid) {
                         if (p.resid_bf16) {
-                            const bf16x8 rr = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.resid) + (size_t)m * p.ldr + nn);
+                            const bf16x8 rr = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.resid) + orw * p.ldr + nn);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { y0[e] += (float)rr[e]; y1[e] += (float)rr[4 + e]; }
                         } else {
-                            y0 += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + nn);
-                            y1 += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + nn + 4);
+                            y0 += *reinterpret_cast<const f32x4*>(p.resid + orw * p.ldr + nn);
+                            y1 += *reinterpret_cast<const f32x4*>(p.resid + orw * p.ldr + nn + 4);
                         }
                     }
                     if (p.relu) {
@@ -421,14 +432,14 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
                     }
                 }
                 if (p.out_f32) {
-                    float* o = p.out + (size_t)m * p.ldc + nn;
+                    float* o = p.out + orw * p.ldc + nn;
                     *reinterpret_cast<f32x4*>(o) = y0;
                     *reinterpret_cast<f32x4*>(o + 4) = y1;
                 } else {
                     bf16x8 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y0[e]; o[4 + e] = (__bf16)y1[e]; }
-                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + (size_t)m * p.ldc + nn) = o;
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + orw * p.ldc + nn) = o;
                 }
             }
         }
@@ -772,13 +783,15 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
 // 256 x 320 leave two thirds of the chip idle, the 128-row grid does not).  E2V_BGEMM_T256 = 0 switches the kernel off (A/B).
 // (v_mfma_f32_16x16x32_bf16 here, 32x32x16 there: both walk k in the same order and -- measured on every shape of
 // tests/test_hip_ops.py::test_bf16_t256_linear -- agree bit for bit, so the choice of kernel does not change a result.)
-static int t256_tile_cols(const IgemmArgs& a) {
+static int t256_tile_cols(const IgemmArgs& a, const bool force = false) {      // force: the sub-pixel convs (their arithmetic differs from the
+                                                                              // gather path's, so the choice must not depend on M or on a switch of the 3x3 path)
     static const int* const on = knob("E2V_BGEMM_T256", 1);
     static const int* const mink = knob("E2V_BGEMM_T256_MINK", 320);
     static const int* const mintiles = knob("E2V_BGEMM_T256_MINTILES", 160);
-    if (!*on || !a.a_bf16 || a.batch != 1 || a.upsample || (a.taps != 1 && a.taps != 9)) return 0;
+    if ((!*on && !force) || !a.a_bf16 || a.batch != 1 || a.upsample || (a.taps != 1 && a.taps != 9 && !(a.taps == 4 && a.kw == 2))) return 0;
+    if (a.taps != 4 && (a.kw != 3 || a.pad_x >= 0 || a.osy)) return 0;        // (kernel width / split pad / scatter: the sub-pixel kernels only)
     const int Kc = a.c0 + a.c1;
-    if (a.c0 <= 0 || a.c0 % 64 || a.c1 % 64 || a.taps * Kc < *mink) return 0;
+    if (a.c0 <= 0 || a.c0 % 64 || a.c1 % 64 || (!force && a.taps * Kc < *mink)) return 0;
     if (a.taps == 1 && a.resid && Kc <= 640 && *on != 2) return 0;
     int cols = 0;
     if (a.geglu) cols = a.N % 256 == 0 ? 256 : 0;
@@ -786,16 +799,16 @@ static int t256_tile_cols(const IgemmArgs& a) {
     else if (a.N % 320 == 0) cols = 320;
     else if (a.N % 256 == 0) cols = 256;
     if (!cols) return 0;
-    if (a.taps == 9) {          // a tile's rows span at most ceil(256 / (Ho Wo)) + 1 images: their pixel indices must fit 20 bits
+    if (a.taps != 1) {          // a tile's rows span at most ceil(256 / (Ho Wo)) + 1 images: their pixel indices must fit 20 bits
         const long span = (255 / ((long)a.Ho * a.Wo) + 2) * (long)a.Hs * a.Ws;
         if (span >= (1L << 20)) return 0;
     }
-    if (*on != 2 && (long)((a.M + 255) / 256) * (a.N / cols) < *mintiles) return 0;
+    if (!force && *on != 2 && (long)((a.M + 255) / 256) * (a.N / cols) < *mintiles) return 0;
     return cols;
 }
 
 bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
-    const int cols = t256_tile_cols(a_in);
+    const int cols = t256_tile_cols(a_in, a_in.osy != 0);
     if (!cols) return false;
     IgemmArgs a = a_in;
     a.nbm = (a.M + 255) / 256;
@@ -856,6 +869,73 @@ bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
     if (cols == 320) { if (lin) go(bgemm_t256_kernel<5, true>); else go(bgemm_t256_kernel<5, false>); }
     else             { if (lin) go(bgemm_t256_kernel<4, true>); else go(bgemm_t256_kernel<4, false>); }
     return true;
+}
+
+// ---- sub-pixel form of `Upsample3D` (resnet.py:30-62: F.interpolate(scale_factor = [1, 2, 2], mode = "nearest") + 3x3 conv) -----------
+// With an exact 2x nearest resize, output pixel (2y + a, 2x + b) reads source rows {y - 1, y} (a = 0) or {y, y + 1} (a = 1) and
+// likewise columns: taps ky = {0 | 1, 2} (a = 0) or {0, 1 | 2} (a = 1) fall on the same source pixel.  So the layer is four 2x2
+// convs on the SOURCE map, one per output parity (a, b), whose weights are the sums over those tap sets (summed in fp32, rounded to
+// bf16 once), with top / left pad 1 - a / 1 - b and zero padding of the source map exactly where the resized map was padded;
+// each writes the output pixels of its parity.  4 / 9 of the multiplies, no resize arithmetic in the gather.
+__global__ void pack_conv_up2x_kernel(const float* __restrict__ w, float* __restrict__ o, int cout, int cin) {
+    const int nq = (cin + 63) / 64;
+    const size_t per = (size_t)nq * 4 * 64;
+    const size_t total = 4 * (size_t)cout * per;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int par = (int)(i / ((size_t)cout * per));
+        const size_t r0 = i - (size_t)par * cout * per;
+        const int oc = (int)(r0 / per);
+        const size_t r = r0 - (size_t)oc * per;
+        const int e = (int)(r % 64), t = (int)((r / 64) % 4), q = (int)(r / 256);
+        const int c = q * 64 + e;
+        const int a = par >> 1, b = par & 1, ty = t >> 1, tx = t & 1;
+        // tap sets: parity 0: {0} | {1, 2}; parity 1: {0, 1} | {2}
+        const int ky0 = a == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = a == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+        const int kx0 = b == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = b == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+        float sum = 0.f;
+        if (c < cin) {
+            const float* wp = w + ((size_t)oc * cin + c) * 9;
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) sum += wp[ky * 3 + kx];
+        }
+        o[i] = sum;
+    }
+}
+int conv_up2x_packed_ld(int cin) { return (cin + 63) / 64 * 4 * 64; }
+void pack_conv_up2x(const float* w, float* o, int cout, int cin, hipStream_t s) {
+    const size_t total = 4 * (size_t)cout * conv_up2x_packed_ld(cin);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_conv_up2x_kernel, dim3(blocks), dim3(256), 0, s, w, o, cout, cin);
+}
+
+static IgemmArgs up2x_parity_args(const IgemmArgs& g, const int a, const int b) {
+    IgemmArgs q = g;
+    q.upsample = 0; q.ups_h = q.ups_w = 1.f;
+    q.taps = 4; q.kw = 2; q.pad = 1 - a; q.pad_x = 1 - b;
+    q.Hi = g.Hs; q.Wi = g.Ws; q.Ho = g.Hs; q.Wo = g.Ws;
+    q.M = g.M / 4;
+    q.osy = 2; q.osx = 2; q.ooy = a; q.oox = b;
+    q.ldw16 = conv_up2x_packed_ld(g.c0);
+    q.ldw = q.ldw16;
+    return q;
+}
+
+bool bgemm_up2x_applies(const IgemmArgs& g) {
+    static const int* const on = knob("E2V_BGEMM_UP2X", 1);
+    if (!*on || !g.a_bf16 || !g.upsample || g.taps != 9 || g.stride != 1 || g.pad != 1 || g.c1 != 0 || g.batch != 1) return false;
+    if (g.Hi != 2 * g.Hs || g.Wi != 2 * g.Ws || g.Ho != g.Hi || g.Wo != g.Wi || g.resid || g.rowbias || g.geglu) return false;
+    if (g.M != (g.M / (g.Ho * g.Wo)) * g.Ho * g.Wo) return false;
+    return t256_tile_cols(up2x_parity_args(g, 0, 0), true) != 0;
+}
+
+void bgemm_up2x_launch(const IgemmArgs& g, const void* w16_up2, hipStream_t s) {
+    const size_t per = (size_t)g.N * conv_up2x_packed_ld(g.c0);
+    for (int par = 0; par < 4; ++par) {
+        IgemmArgs q = up2x_parity_args(g, par >> 1, par & 1);
+        q.w16 = static_cast<const __bf16*>(w16_up2) + (size_t)par * per;
+        q.w = nullptr;
+        if (!bgemm_t256_launch(q, s)) throw Error(E2V_EINVAL, "bgemm_up2x_launch: the layer is not eligible (bgemm_up2x_applies first)");
+    }
 }
 
 }  // namespace e2v

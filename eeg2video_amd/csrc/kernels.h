@@ -33,6 +33,11 @@ struct IgemmArgs {
     int Hi = 1, Wi = 1;            // logical input map (after nearest resize)
     int Hs = 1, Ws = 1;            // physical source map
     int stride = 1, pad = 0;       // pad = rows/cols of zeros above/left (below/right is implied by Hi/Wi)
+    // bgemm256.hip only (the sub-pixel form of a 2x nearest resize + 3x3 conv, bgemm_up2x): kernel width (taps = kh x kw, tap t =
+    // (t / kw, t % kw)), the left pad if it differs from the top pad `pad` (-1: the same), and an output scatter -- output pixel
+    // (oy, ox) of image i is written to row ((i Ho osy + oy osy + ooy) Wo osx + ox osx + oox) instead of row m (osy = 0: off)
+    int kw = 3, pad_x = -1;
+    int osy = 0, osx = 0, ooy = 0, oox = 0;
     int upsample = 0; float ups_h = 1.f, ups_w = 1.f;
     float alpha = 1.f;
     int relu = 0;                  // out = max(out, 0) after bias (semantic-predictor MLP)
@@ -59,6 +64,12 @@ bool set_knob(const char* name, int value);      // false: no kernel has asked f
 void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s);
 bool bgemm_all_n64(const IgemmArgs& a);
 bool bgemm_t256_launch(const IgemmArgs& a, hipStream_t s);                 // bgemm256.hip: true = the layer was eligible and has been launched
+// Exact 2x nearest resize in front of a stride-1, pad-1 3x3 conv as four 2x2 convs on the SOURCE map (one per output parity; weights
+// summed over the taps that read the same source pixel: 4 / 9 of the multiplies).  `g` describes the conv as igemm() takes it.
+bool bgemm_up2x_applies(const IgemmArgs& g);
+int conv_up2x_packed_ld(int cin);                                        // row length of one parity's [O][chunk64][4 taps][64] layout
+void pack_conv_up2x(const float* w_oihw, float* w_packed, int cout, int cin, hipStream_t s);    // [4 parities][O][ld], fp32
+void bgemm_up2x_launch(const IgemmArgs& g, const void* w16_up2, hipStream_t s);                // w16_up2: the packed layout as bf16
 bool bgemm_use_256(const IgemmArgs& a);                                  // schedule hint: 256-row tiles pay for this launch
 
 // weight re-layout helpers (one-off, at finalize)

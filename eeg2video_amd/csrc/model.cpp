@@ -193,6 +193,16 @@ void e2v_ctx::conv_form(const ConvW& w, ConvForm f, hipStream_t s) {
                 w.w16 = d16;
             }
             break;
+        case FORM_BF16_UP2:
+            if (!w.w16_up2) {
+                const size_t n = 4 * (size_t)w.cout * conv_up2x_packed_ld(w.cin);
+                Act tmp(pool, (int64_t)((n + 1023) / 1024), 1024);            // fp32 staging: the tap sums are formed in fp32, rounded once
+                pack_conv_up2x(w.raw, tmp.p, w.cout, w.cin, s);
+                float* d16 = dev_alloc((n + 1) / 2);
+                to_bf16(tmp.p, d16, n, s);
+                w.w16_up2 = d16;
+            }
+            break;
         case FORM_WINO2:
         case FORM_WINO4: {
             const int m = f == FORM_WINO4 ? 4 : 2;
@@ -614,12 +624,10 @@ struct Runner {
         IgemmArgs g;
         g.a0 = x0; g.c0 = c0; g.lda0 = c0; g.a1 = x1; g.c1 = c1; g.lda1 = c1;
         E2V_REQUIRE(c1 == 0 || c0 % 32 == 0, E2V_ESHAPE, "conv: the concat seam must be a multiple of 32 channels");
-        c->conv_form(w, bf() ? e2v_ctx::FORM_BF16 : e2v_ctx::FORM_DIRECT32, s);
-        g.w = w.w; g.ldw = w.ldw; g.ldw16 = w.ldw16; g.out = out.p; g.ldc = w.cout; g.bias = w.b;
+        g.ldw = w.ldw; g.ldw16 = w.ldw16; g.out = out.p; g.ldc = w.cout; g.bias = w.b;
         g.rowbias = rowbias; g.rb_ld = rb_ld; g.rows_per_sample = rows_per_sample;
         g.resid = resid; g.ldr = w.cout;
         g.M = (int)out.rows; g.N = w.cout; g.taps = 9;
-        g.w16 = w.w16;
         if (bf()) { g.a_bf16 = 1; g.out_f32 = out_f32 ? 1 : 0; g.resid_bf16 = resid ? 1 : 0; }
         g.Ho = Ho; g.Wo = Wo; g.Hi = Hi; g.Wi = Wi; g.Hs = geo.H; g.Ws = geo.W; g.stride = stride; g.pad = pad;
         if (Hi != geo.H || Wi != geo.W) {
@@ -627,6 +635,13 @@ struct Runner {
             g.ups_h = (float)geo.H / (float)Hi;        // torch: scale = (float)input_size / output_size
             g.ups_w = (float)geo.W / (float)Wi;
         }
+        if (bf() && c0 == w.cin && bgemm_up2x_applies(g)) {       // exact 2x resize (Upsample3D): four 2x2 convs on the source map
+            c->conv_form(w, e2v_ctx::FORM_BF16_UP2, s);
+            bgemm_up2x_launch(g, w.w16_up2, s);
+            return out;
+        }
+        c->conv_form(w, bf() ? e2v_ctx::FORM_BF16 : e2v_ctx::FORM_DIRECT32, s);
+        g.w = w.w; g.w16 = w.w16;
         igemm(g, s);
         return out;
     }

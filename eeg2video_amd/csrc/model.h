@@ -29,6 +29,7 @@ struct ConvW {
     int part = 0;                                // 0 UNet, 1 VAE: which finalize() group owns the lazily built forms
     mutable const float* w = nullptr;            // [O][chunk32][tap][32]
     mutable const void* w16 = nullptr;           // [O][chunk64][tap][64] bf16
+    mutable const void* w16_up2 = nullptr;       // [4 parities][O][chunk64][4 taps][64] bf16: the sub-pixel form of resize + conv (bgemm_up2x)
     mutable const float* wino = nullptr;         // [16][O][I]
     mutable const float* wino4 = nullptr;        // [36][O][I]
     mutable const void* wino_x3 = nullptr; mutable const void* wino4_x3 = nullptr;   // three-plane bf16 splits (f32x3 mode)
@@ -131,7 +132,7 @@ struct e2v_ctx {
     void free_part(int part);
 
     float* dev_alloc(size_t floats);
-    enum ConvForm { FORM_DIRECT32, FORM_BF16, FORM_WINO2, FORM_WINO4 };
+    enum ConvForm { FORM_DIRECT32, FORM_BF16, FORM_WINO2, FORM_WINO4, FORM_BF16_UP2 };
     void conv_form(const e2v::ConvW& w, ConvForm f, hipStream_t s);     // build the layout if this is its first use
     bool conv_has_wino(const e2v::ConvW& w, int m) const;               // would the policy allow the F(m x m) form for this layer?
     void expected_keys();

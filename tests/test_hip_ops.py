@@ -592,6 +592,43 @@ def test_bf16_t256_conv3x3_geometries(bf256):
     close(from_cl(yc, nn, h, w), refc, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("n,c,cout,hs,ws", [(12, 320, 320, 18, 32), (5, 256, 256, 9, 16), (3, 640, 640, 5, 8), (2, 128, 512, 7, 6)])
+def test_bf16_upsample_conv_sub_pixel_form(bf256, n, c, cout, hs, ws):
+    """`Upsample3D` (resnet.py:30-62: nearest 2x + 3x3 conv) as four 2x2 convs on the source map, one per output parity, weights summed
+    over the taps that read the same source pixel (bgemm_up2x: 4 / 9 of the multiplies).  (1) the identity itself, pure torch in
+    fp64; (2) the HIP result against that parity form with the kernel's operand rounding (x and the SUMMED weights rounded to
+    bf16): summation order only, 1e-4; (3) against the resize-then-conv on the old gather path (E2V_BGEMM_UP2X = 0), which rounds the
+    nine weights separately: one bf16 rounding of a weight apart."""
+    bf = bf256
+    x, wt, b = rnd(n, c, hs, ws, seed=170), rnd(cout, c, 3, 3, seed=171, scale=0.05), rnd(cout, seed=172)
+    sets = {0: ([0], [1, 2]), 1: ([0, 1], [2])}          # parity -> taps of the 3-wide kernel that fall on source offset 0 / 1
+
+    def parity_form(xx, ww, bb, round_w):
+        out = torch.zeros(n, cout, 2 * hs, 2 * ws, dtype=xx.dtype)
+        for a in (0, 1):
+            for bq in (0, 1):
+                w2 = torch.stack([torch.stack([ww[:, :, sets[a][ty]][:, :, :, sets[bq][tx]].sum((2, 3)) for tx in (0, 1)], -1) for ty in (0, 1)], -2)
+                if round_w:
+                    w2 = rb(w2)
+                out[:, :, a::2, bq::2] = F.conv2d(F.pad(xx, (1 - bq, bq, 1 - a, a)), w2, bb)
+        return out
+
+    direct = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), wt.double(), b.double(), padding=1)
+    assert (parity_form(x.double(), wt.double(), b.double(), False) - direct).abs().max() < 1e-10
+    ref = parity_form(rb(x), wt, b, True)
+    try:
+        bf.set_knob("E2V_BGEMM_UP2X", 1)
+        y = bf.op_conv3x3(to_cl(x).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=hs, Ws=ws, Hi=2 * hs, Wi=2 * ws)
+        bf.set_knob("E2V_BGEMM_UP2X", 0)
+        y0 = bf.op_conv3x3(to_cl(x).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=hs, Ws=ws, Hi=2 * hs, Wi=2 * ws)
+    finally:
+        bf.set_knob("E2V_BGEMM_UP2X", 1)
+    close(from_cl(y, n, 2 * hs, 2 * ws), ref, rtol=1e-4, atol=1e-4)
+    close(from_cl(y0, n, 2 * hs, 2 * ws), F.conv2d(F.interpolate(rb(x), scale_factor=2, mode="nearest"), rb(wt), b, padding=1), rtol=1e-4, atol=1e-4)
+    assert not torch.equal(y, y0)                          # (the sub-pixel form did run: its weight rounding differs)
+    close(y, y0, rtol=4e-3, atol=4e-3)
+
+
 @pytest.mark.parametrize("boost", [3.0, 25.0])
 def test_bf16_attention_deferred_maximum_branches(eng, boost):
     """bf16 attention keeps a row's reference maximum until a score exceeds it by more than 2^8 (the rescale of the accumulators is

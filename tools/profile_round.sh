@@ -15,12 +15,12 @@ export PYTHONFAULTHANDLER=1
 OUT=$R/gpurun_out/prof_$TAG
 if [ "${SKIP_STATS:-0}" != "1" ]; then rm -rf $OUT; fi
 mkdir -p $OUT
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-configs2 $*"
 if [ "${SKIP_STATS:-0}" != "1" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $R/bench.py $ARGS --kernel-table $OUT/kernel_classes_hip_events.json > $OUT/stats_bench.json 2> $OUT/stats.err
 echo "stats pass rc=$?"
 fi
-PARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-roofline $*"
+PARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-configs2 $*"
 export E2V_LOG_MAPS=1
 # SYNC=1: drain the stream after every DDIM step in the counter passes (see the header)
 if [ "${SYNC:-0}" = "1" ]; then export E2V_SYNC_EACH_STEP=1; fi
