@@ -688,6 +688,23 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
             bias[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)(n0 + wc * WN + nt * 16 + 4 * fq) * 4u, 0, 0));
+        // Two adjacent 16-column tiles leave the wave as 16-byte stores: a lane holds channels 4 fq .. + 3 of BOTH tiles; after
+        // v_permlane16_swap (odd 16-lane rows of the first operand <-> even rows of the second) an even-fq lane holds channels
+        // 8 (fq >> 1) .. + 7 of the first tile and an odd-fq lane the same channels of the second one -- every row of the wave's 16
+        // then gets 64 contiguous bytes per instruction instead of 2 x 32 (the 8-byte stores of the accumulator layout moved 32 bytes
+        // per cache line touched).  (Inline asm with the two wait states a VALU-written operand needs in front of a permlane.)
+        const unsigned vop0 = ((unsigned)(wr * 128 + fl) * p.ldc + ocol0 + (fq & 1) * 16 + (fq >> 1) * 8) * 2u;
+        const unsigned vrp0 = ((unsigned)(wr * 128 + fl) * p.ldr + n0 + wc * WN + (fq & 1) * 16 + (fq >> 1) * 8) * 2u;      // the residual, paired likewise
+        auto store_pair = [&](const f32x4 ya, const f32x4 yb, const unsigned vop, const int nt) {      // tiles nt, nt + 1 (bf16 output)
+            bf16x4 oa, ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { oa[e] = (__bf16)ya[e]; ob[e] = (__bf16)yb[e]; }
+            u32x2 a = __builtin_bit_cast(u32x2, oa), b = __builtin_bit_cast(u32x2, ob);
+            unsigned a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+            const u32x4 o = {a0, a1, b0, b1};
+            __builtin_amdgcn_raw_buffer_store_b128(o, ro, vop, (unsigned)(nt * 16) * 2u, 0);
+        };
         auto store4 = [&](const f32x4 y, const unsigned vo, const int nt) {
             if constexpr (F32IO) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, vo, (unsigned)(nt * 16) * 4u, 0);
@@ -698,51 +715,102 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ro, vo, (unsigned)(nt * 16) * 2u, 0);
             }
         };
+        if constexpr (GEGLU) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const unsigned vo = vo0 + (unsigned)(h * 64 + mt * 16) * p.ldc * osz;
-                const unsigned vr = vr0 + (unsigned)(h * 64 + mt * 16) * p.ldr * osz;
-                if constexpr (GEGLU) {                       // value tiles 0, 1 | gate tiles 2, 3 of the wave's 64 packed columns
-                    static_assert(!GEGLU || NT == 4, "GEGLU: 256 x 256 tiles");
+                for (int mt = 0; mt < 4; ++mt) {
+                    const unsigned vo = vo0 + (unsigned)(h * 64 + mt * 16) * p.ldc * osz;
+                    static_assert(!GEGLU || NT == 4, "GEGLU: 256 x 256 tiles");      // value tiles 0, 1 | gate tiles 2, 3 of the wave's 64 packed columns
+                    f32x4 yg[2];
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        f32x4 y;
+                    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            y[e] = (acc[h][mt][nt][e] * p.alpha + bias[nt][e]) * gelu_erf(acc[h][mt][nt + 2][e] * p.alpha + bias[nt + 2][e]);
-                        store4(y, vo, nt);
-                    }
-                } else {
-                    f32x4 res[NT];
+                            yg[nt][e] = (acc[h][mt][nt][e] * p.alpha + bias[nt][e]) * gelu_erf(acc[h][mt][nt + 2][e] * p.alpha + bias[nt + 2][e]);
+                    if constexpr (F32IO) { store4(yg[0], vo, 0); store4(yg[1], vo, 1); }
+                    else store_pair(yg[0], yg[1], vop0 + (unsigned)(h * 64 + mt * 16) * p.ldc * 2u, 0);
+                    __builtin_amdgcn_sched_barrier(0);       // one (half, row tile) at a time
+                }
+        } else {
+            // The residual of a whole half (64 rows of the wave: 4 x NT loads) is requested before the first of its values is needed:
+            // the K loop's fragment registers are dead here, which is room for 40 dwords of bf16 residual -- one exposed memory
+            // latency per half instead of one per 16-row tile (eight per tile; measured on 640 -> 640 at M = 221 184: 40 us per tile
+            // against 14 us of MFMAs and a 23 us HBM floor).
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 res[4][NT];
+                bf16x4 rb4[4][NT];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const unsigned vr = vr0 + (unsigned)(h * 64 + mt * 16) * p.ldr * osz;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        if constexpr (F32IO) {
-                            res[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, vr, (unsigned)(nt * 16) * 4u, 0));
-                        } else {
-                            const bf16x4 rb4 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rr, vr, (unsigned)(nt * 16) * 2u, 0));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) res[nt][e] = (float)rb4[e];
+                        if constexpr (F32IO) res[mt][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, vr, (unsigned)(nt * 16) * 4u, 0));
+                        else if ((nt & 1) == 0 && nt + 1 < NT) {      // two adjacent tiles: 16 bytes per lane (channels 8 (fq >> 1) .. + 7 of tile nt + (fq & 1)), un-paired below
+                            const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(rr, vrp0 + (unsigned)(h * 64 + mt * 16) * p.ldr * 2u, (unsigned)(nt * 16) * 2u, 0);
+                            rb4[mt][nt] = __builtin_bit_cast(bf16x4, u32x2{l[0], l[1]});
+                            rb4[mt][nt + 1] = __builtin_bit_cast(bf16x4, u32x2{l[2], l[3]});
+                        } else if (nt == NT - 1 && (NT & 1)) {
+                            rb4[mt][nt] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rr, vr, (unsigned)(nt * 16) * 2u, 0));
                         }
                     }
+                    if constexpr (F32IO) __builtin_amdgcn_sched_barrier(0);      // (fp32 residual, test entry points: 16 dwords per row tile, one row tile at a time)
+                    if constexpr (F32IO) {
+                        const unsigned vo = vo0 + (unsigned)(h * 64 + mt * 16) * p.ldc * osz;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        f32x4 y;
+                        for (int nt = 0; nt < NT; ++nt) {
+                            f32x4 y;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = acc[h][mt][nt][e];
-                        if (p.alpha != 1.0f) y *= p.alpha;
-                        y += bias[nt];
-                        y += res[nt];
-                        if (p.relu) {
+                            for (int e = 0; e < 4; ++e) y[e] = acc[h][mt][nt][e];
+                            if (p.alpha != 1.0f) y *= p.alpha;
+                            y += bias[nt];
+                            y += res[mt][nt];
+                            if (p.relu) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+                                for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+                            }
+                            store4(y, vo, nt);
                         }
-                        store4(y, vo, nt);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);           // one (half, row tile) at a time: the scheduler otherwise hoists every load of the tile
+                if constexpr (!F32IO) {
+                    __builtin_amdgcn_sched_barrier(0);       // every load of the half is in flight before the first conversion
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const unsigned vo = vo0 + (unsigned)(h * 64 + mt * 16) * p.ldc * osz;
+                        const unsigned vop = vop0 + (unsigned)(h * 64 + mt * 16) * p.ldc * 2u;
+#pragma unroll
+                        for (int nt = 0; nt + 1 < NT; nt += 2) {     // (swap of the first dwords, then of the second ones: see store_pair)
+                            u32x2 a = __builtin_bit_cast(u32x2, rb4[mt][nt]), b = __builtin_bit_cast(u32x2, rb4[mt][nt + 1]);
+                            unsigned l0 = a[0], l1 = a[1], l2 = b[0], l3 = b[1];
+                            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(l0), "+v"(l2), "+v"(l1), "+v"(l3));
+                            rb4[mt][nt] = __builtin_bit_cast(bf16x4, u32x2{l0, l1});
+                            rb4[mt][nt + 1] = __builtin_bit_cast(bf16x4, u32x2{l2, l3});
+                        }
+                        f32x4 y[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[nt][e] = acc[h][mt][nt][e];
+                            if (p.alpha != 1.0f) y[nt] *= p.alpha;
+                            y[nt] += bias[nt];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[nt][e] += (float)rb4[mt][nt][e];
+                            if (p.relu) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) y[nt][e] = fmaxf(y[nt][e], 0.f);
+                            }
+                        }
+#pragma unroll
+                        for (int nt = 0; nt + 1 < NT; nt += 2) store_pair(y[nt], y[nt + 1], vop, nt);
+                        if constexpr (NT & 1) store4(y[NT - 1], vo, NT - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
+        }
     };
 
     // ---- prologue: K step 0 of the first tile whole, q0, n1, q1 of the K step after it (the next tile's first one if nk = 1)
@@ -778,9 +846,9 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
 // counts in whole 64-deep K steps, output width a multiple of 320 (256 x 320 tiles) or -- GEGLU, VAE -- of 256.  Same-box A/B over
 // every GEMM shape of a B = 32 UNet step (tools/shape_ab.py, profiles/r03_shape_ab_*.log): 3x3 convs -14..-32 % (1300-1570
 // TFLOP/s against 1060-1250), linears with K >= 960 -5..-42 %, the K = 320 / 640 projections WITHOUT a residual -11..-23 %; the ones with
-// a residual to read at K <= 640 (320 -> 320 at its HBM roofline, 640 -> 640) are 5-23 % FASTER on bgemm.hip's persistent kernel and
-// stay there, and so do launches of fewer than E2V_BGEMM_T256_MINTILES tiles (the cross-attention K / V projections: 80 tiles of
-// 256 x 320 leave two thirds of the chip idle, the 128-row grid does not).  E2V_BGEMM_T256 = 0 switches the kernel off (A/B).
+// a residual to read at K <= 640 were 5-23 % faster on bgemm.hip's persistent kernel until the persistent form below got its
+// second epilogue (now -3..-10 % here); launches of fewer than E2V_BGEMM_T256_MINTILES tiles stay on the 128-row grid (the
+// cross-attention K / V projections: 80 tiles of 256 x 320 leave two thirds of the chip idle).  E2V_BGEMM_T256 = 0: off (A/B).
 // (v_mfma_f32_16x16x32_bf16 here, 32x32x16 there: both walk k in the same order and -- measured on every shape of
 // tests/test_hip_ops.py::test_bf16_t256_linear -- agree bit for bit, so the choice of kernel does not change a result.)
 static int t256_tile_cols(const IgemmArgs& a, const bool force = false) {      // force: the sub-pixel convs (their arithmetic differs from the
@@ -792,7 +860,6 @@ static int t256_tile_cols(const IgemmArgs& a, const bool force = false) {      /
     if (a.taps != 4 && (a.kw != 3 || a.pad_x >= 0 || a.osy)) return 0;        // (kernel width / split pad / scatter: the sub-pixel kernels only)
     const int Kc = a.c0 + a.c1;
     if (a.c0 <= 0 || a.c0 % 64 || a.c1 % 64 || (!force && a.taps * Kc < *mink)) return 0;
-    if (a.taps == 1 && a.resid && Kc <= 640 && *on != 2) return 0;
     int cols = 0;
     if (a.geglu) cols = a.N % 256 == 0 ? 256 : 0;
     else if ((a.N | a.ldc | a.ldr) & 7 || (a.rb_ld & 3)) cols = 0;
@@ -838,18 +905,19 @@ bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, a);
     };
-    // linears: the persistent form (E2V_BGEMM_T256P: 0 never, 2 every linear, 1 where it measured faster in a same-box A/B over the
-    // linears of a B = 32 UNet step, profiles/r03_shape_ab_t256p.log: the GEGLU projections -9..-23 % (their erf epilogue runs with the
-    // next tile's K steps in flight) and the projections with a residual at K >= 1280 -3..-13 %; the wide residual-free ones (QKV,
-    // concat shortcuts) are 3-11 % SLOWER -- 8-byte stores from the accumulator layout against the staged epilogue's 16-byte row
-    // segments -- and stay on one tile per workgroup), with at least two tiles per workgroup
+    // linears: the persistent form (E2V_BGEMM_T256P: 0 never, 2 every linear, 1 launches of at least E2V_BGEMM_T256P_MINTILES tiles).
+    // Same-box A/B over the linears of a B = 32 UNet step (tools/shape_ab.py): with the first register epilogue (8-byte stores, the
+    // residual fetched one 16-row tile at a time) only the GEGLU projections and the K >= 1280 ones with a residual gained
+    // (profiles/r03_shape_ab_t256p.log); with 16-byte paired stores and the residual of a half requested at once
+    // (profiles/r03_shape_ab_t256p_epilogue.log) every linear of >= 256 tiles does: 640 -> 640 with a residual -10 %, 320 -> 960 -6 %,
+    // 320 -> 320 -3 % against bgemm.hip's persistent 128-row kernel, which the K <= 640 projections with a residual used to stay on.
     static const int* const persp = knob("E2V_BGEMM_T256P", 1);
     static const int* const pmaxk = knob("E2V_BGEMM_T256P_MAXK", 1 << 30);
     const long ntiles = (long)a.nbm * nct;
-    const bool pays = a.geglu || (a.resid && a.c0 + a.c1 >= 1280);
+    static const int* const pmint = knob("E2V_BGEMM_T256P_MINTILES", 256);
     // (the epilogue reads the residual in the output's type: fp32 with fp32 at the test entry points, bf16 with bf16 in the graph)
     const bool io_ok = !a.resid || (a.out_f32 ? !a.resid_bf16 : a.resid_bf16 != 0);
-    if (lin && io_ok && *persp && (*persp == 2 || (pays && a.c0 + a.c1 <= *pmaxk && ntiles >= 512))) {
+    if (lin && io_ok && *persp && (*persp == 2 || (a.c0 + a.c1 <= *pmaxk && ntiles >= *pmint))) {
         auto gop = [&](auto kern) {
             static bool cfg = false;
             if (!cfg) {
