@@ -586,11 +586,208 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
     }
 }
 
+// ---- cross-attention with the keys RESIDENT in LDS (bf16 rows; mode 1, Nk <= 96: the 77 conditioning tokens) -----------------------
+// The K / V of a (sample, head) are the same 77 rows for every frame and every query of the sample, 6 KB at d = 40.  The kernel
+// above stages them per 128-query workgroup (two barriers, a 37 KB LDS clear, a prologue and an epilogue for 0.4 us of MFMAs:
+// 177 TFLOP/s, 2.4 TB/s of the Q / O rows it exists to stream).  Here a workgroup stages them ONCE and its four waves walk TPW
+// 32-query tiles each of the sample's F * Nq rows with no barrier in the loop: all scores of a query against the 96 (padded) keys
+// are in registers at once, so the softmax is one pass (no running maximum, no rescale), the next tile's Q rows are requested
+// before this tile is computed, and the denominator is again row D of O^T.  The maximum is subtracted only when a row needs it
+// (|max| > 8, wave-uniform branch): with scores pre-scaled into the exp2 domain by the bf16 Q, probabilities stay within
+// [2^-8, 2^8] otherwise and the normalised result is the same.
+template <int D>
+__global__ __launch_bounds__(256) void cross_attn_resident_kernel(const AttnArgs p, const int tpw, const int chunks) {
+    constexpr int DP = (D + 15) / 16 * 16;
+    constexpr int KS = DP / 16;
+    constexpr int T = (D + 31) / 32;
+    constexpr int KROW = DP * 2 + 16;
+    constexpr int VROW = ((T * 16) % 32 == 16) ? T * 64 : T * 64 + 64;
+    constexpr int NKT = 3, NKEY = 32 * NKT;
+    constexpr int KBYTES = NKEY * KROW;
+    constexpr bool SUMV = (D % 32) != 0;
+    constexpr int LROW = D % 32, LREG = 4 * (LROW / 8) + (LROW & 3), LHALF = (LROW >> 2) & 1;
+    constexpr int C8 = D / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];      // [K rows | V rows]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    // block -> (sample, head, chunk of the sample's rows); XCD b & 7 takes whole samples (the sample's K / V and its neighbours' Q lines in one L2)
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int per = p.heads * chunks;
+    const int ul = idx / per, w = idx - ul * per;
+    const int smp = ul * 8 + xcd;
+    if (smp >= p.n) return;
+    const int head = w / chunks, chunk = w - head * chunks;
+    const int rows = p.F * p.Nq;                                        // query rows of the sample
+    const __bf16* __restrict__ Q = reinterpret_cast<const __bf16*>(p.q) + (size_t)smp * rows * p.ldq + head * D;
+    const __bf16* __restrict__ K = reinterpret_cast<const __bf16*>(p.k) + (size_t)smp * p.Nk * p.ldkv + head * D;
+    const __bf16* __restrict__ V = reinterpret_cast<const __bf16*>(p.v) + (size_t)smp * p.Nk * p.ldkv + head * D;
+    __bf16* __restrict__ O = reinterpret_cast<__bf16*>(p.o) + (size_t)smp * rows * p.ldo + head * D;
+
+    for (int i = tid * 16; i < KBYTES + NKEY * VROW; i += 256 * 16)      // pad rows / columns: zeros
+        *reinterpret_cast<f32x4*>(smem_c + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int i = tid; i < p.Nk * C8; i += 256) {
+        const int row = i / C8, c8 = i - row * C8;
+        *reinterpret_cast<f32x4*>(smem_c + row * KROW + c8 * 16) = *reinterpret_cast<const f32x4*>(K + (size_t)row * p.ldkv + c8 * 8);
+        *reinterpret_cast<f32x4*>(smem_c + KBYTES + row * VROW + c8 * 16) = *reinterpret_cast<const f32x4*>(V + (size_t)row * p.ldkv + c8 * 8);
+    }
+    if constexpr (SUMV) {
+        if (tid < NKEY) *reinterpret_cast<__bf16*>(smem_c + KBYTES + tid * VROW + D * 2) = (__bf16)(tid < p.Nk ? 1.0f : 0.0f);
+    }
+    __syncthreads();
+
+    const float qs = p.scale * 1.44269504088896340736f;
+    auto load_q = [&](const int row0, abf16x8 (&qf)[KS]) {
+        const int qrow = min(row0 + j, rows - 1);
+        const __bf16* qp = Q + (size_t)qrow * p.ldq;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k0 = 16 * s + 8 * h;
+            abf16x8 a;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = (__bf16)0.f;
+            if (k0 < D) a = *reinterpret_cast<const abf16x8*>(qp + k0);
+            qf[s] = a;
+        }
+    };
+    const int ti = lane & 15;
+    const int tr_off = (4 * h + (ti >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (ti & 3)) * 2;
+    typedef __attribute__((address_space(3))) abf16x4* lds_b4;
+    const char* const Kl = smem_c;
+    const char* const Vl = smem_c + KBYTES;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    const int tile0 = chunk * 4 * tpw + wave;                            // this wave's tiles: tile0, tile0 + 4, ...
+    abf16x8 qn[KS];
+    if (tile0 * 32 < rows) load_q(tile0 * 32, qn);
+    for (int it = 0; it < tpw; ++it) {
+        const int row0 = (tile0 + 4 * it) * 32;
+        if (row0 >= rows) break;
+        abf16x8 qf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)((float)qn[s][e] * qs);
+        }
+        if (it + 1 < tpw && row0 + 128 < rows) load_q(row0 + 128, qn);      // the next tile's rows: in flight under this tile
+
+        f32x16 st[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const char* kp = Kl + (kt * 32 + j) * KROW + h * 16;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const abf16x8 kf = *reinterpret_cast<const abf16x8*>(kp + s * 32);
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? zero16 : st[kt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (key >= p.Nk) st[kt][r] = -INFINITY;
+            }
+        float mt = st[0][0];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = __builtin_fmaxf(mt, st[kt][r]);
+        {
+            float a = mt, bb = mt;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(bb));
+            mt = __builtin_fmaxf(a, bb);
+        }
+        if (__any(__builtin_fabsf(mt) > 8.0f)) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kt][r] -= mt;
+        }
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r]);
+                if constexpr (!SUMV) ps += st[kt][r];
+            }
+        f32x16 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                abf16x8 pf[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[s][e] = (__bf16)st[kt][8 * s + e];
+                const char* vb = Vl + kt * 32 * VROW + tr_off + t * 64;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const abf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s) * VROW));
+                    const abf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s + 8) * VROW));
+                    const abf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], (kt == 0 && s == 0) ? zero16 : acc[t], 0, 0, 0);
+                }
+            }
+        }
+        float l_tot;
+        if constexpr (SUMV) l_tot = __shfl(acc[T - 1][LREG], j + 32 * LHALF);
+        else l_tot = ps + __shfl_xor(ps, 32);
+        if (row0 + j < rows) {
+            const float inv = 1.0f / l_tot;
+            __bf16* op = O + (size_t)(row0 + j) * p.ldo;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int dv = t * 32 + 8 * rg + 4 * h;
+                    if (dv < D) {
+                        abf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[t][rg * 4 + e] * inv);
+                        *reinterpret_cast<abf16x4*>(op + dv) = o;
+                    }
+                }
+        }
+    }
+}
+
+template <int D>
+static bool launch_cross_resident(const AttnArgs& a, hipStream_t s) {
+    static const int* const on = knob("E2V_ATTN_CROSS_RESIDENT", 1);     // 0: cross-attention through the staged kernel
+    if (!*on || a.mode != 1 || a.Nk > 96 || a.Nk < 1) return false;
+    constexpr int DP = (D + 15) / 16 * 16, T = (D + 31) / 32;
+    constexpr int VROW = ((T * 16) % 32 == 16) ? T * 64 : T * 64 + 64;
+    const size_t smem = (size_t)96 * (DP * 2 + 16) + (size_t)96 * VROW;
+    const int rows = a.F * a.Nq;
+    const int tiles = (rows + 31) / 32;
+    // tiles per wave: enough workgroups to fill the chip a few times over (n * heads * chunks >= ~2048), at most 16 tiles per wave
+    int tpw = 16;
+    while (tpw > 1 && (long)a.n * a.heads * ((tiles + 4 * tpw - 1) / (4 * tpw)) < 2048) tpw >>= 1;
+    const int chunks = (tiles + 4 * tpw - 1) / (4 * tpw);
+    const unsigned grid = 8u * ((a.n + 7) / 8) * (unsigned)(a.heads * chunks);
+    const double probs = (double)a.n * a.F * a.heads;
+    ProfScope ps("flash_attn_bf16_cross", 4.0 * probs * a.Nq * a.Nk * D, 2.0 * probs * D * (2.0 * a.Nq + 2.0 * (double)a.Nk / a.F), s);
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_resident_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        configured = true;
+    }
+    hipLaunchKernelGGL(cross_attn_resident_kernel<D>, dim3(grid), dim3(256), smem, s, a, tpw, chunks);
+    return true;
+}
+
 template <int D>
 static void launch_flash_b16io(const AttnArgs& a, hipStream_t s) {
     constexpr int DP = (D + 15) / 16 * 16, T = (D + 31) / 32;
     constexpr int VROW = ((T * 16) % 32 == 16) ? T * 64 : T * 64 + 64;      // as in the kernel
     auto stage_bytes = [](const int kt) { return ((size_t)kt * (DP * 2 + 16) + (size_t)kt * VROW + 15) / 16 * 16; };
+    if (launch_cross_resident<D>(a, s)) return;
     static const int* const fold = knob("E2V_ATTN_FOLD", 1);     // 0: the plain form (scale and maximum applied by vector FMAs)
     static const int* const kt64 = knob("E2V_ATTN_KT64", 1);     // 0: 32-key stages (one barrier per 32 keys)
     dim3 grid(attn_grid(a), 1, 1);

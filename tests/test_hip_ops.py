@@ -456,6 +456,37 @@ def test_bf16_attention(eng, d, nq, f, n, mode):
         eng.set_compute_dtype("fp32")
 
 
+@pytest.mark.parametrize("d,nq,f,n,nk,qboost", [(40, 333, 6, 9, 77, 1.0), (80, 100, 3, 2, 77, 1.0), (160, 40, 3, 10, 77, 1.0), (40, 50, 2, 1, 96, 1.0),
+                                                 (40, 70, 2, 3, 33, 1.0), (40, 200, 2, 2, 77, 30.0), (8, 45, 2, 1, 5, 1.0)])
+def test_bf16_cross_attention_resident_keys(eng, d, nq, f, n, nk, qboost):
+    """Cross-attention with the conditioning's K / V resident in LDS (cross_attn_resident_kernel: one-pass softmax over <= 96 keys, no
+    barrier in the query loop): 77 keys and other counts (96 = all three key tiles full, 33, 5), >= 8 samples (whole samples per XCD)
+    and fewer, a last query tile that is ragged, several tiles per wave, and queries scaled 30x so that |max score| > 8 takes the
+    subtract-the-maximum branch.  Against the fp32 reference on bf16-rounded operands, and against the staged kernel."""
+    heads = 8 if d != 160 else 4
+    c = heads * d
+    q, kv = rnd(n * f * nq, c, seed=181) * qboost, rnd(n * nk, 2 * c, seed=182)
+    k, v = rb(kv[:, :c]).reshape(n, nk, c), rb(kv[:, c:]).reshape(n, nk, c)
+    rep = lambda t: t.repeat_interleave(f, 0)
+    qs = d ** -0.5 * 1.4426950408889634                   # the kernels fold scale * log2(e) into Q and round it to bf16 once: so does the reference
+    q_eff = rb(rb(q) * qs) / qs
+    ref = _unheads(_ref_attn(_heads(q_eff.reshape(n * f, nq, c), heads), _heads(rep(k), heads), _heads(rep(v), heads), d ** -0.5), heads)
+    gq, gkv = q.cuda(), kv.cuda()
+    run = lambda: eng.op_attention(gq, gkv[:, :c], gkv[:, c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nk, mode=1, scale=d ** -0.5)
+    try:
+        eng.set_compute_dtype("bf16")
+        eng.set_knob("E2V_ATTN_CROSS_RESIDENT", 1)
+        y = run()
+        eng.set_knob("E2V_ATTN_CROSS_RESIDENT", 0)
+        y0 = run()
+    finally:
+        eng.set_knob("E2V_ATTN_CROSS_RESIDENT", 1)
+        eng.set_compute_dtype("fp32")
+    close(y.reshape(n * f, nq, c), ref, rtol=2e-2, atol=2e-2)
+    close(y, y0, rtol=2e-2, atol=2e-2)
+    assert torch.isfinite(y).all()
+
+
 def test_linear_16k_and_32k_tiles_are_bit_identical(monkeypatch):
     """The taps == 1 layers run on the 16-k-stage tile (three workgroups per CU) by default; the 32-k tile (E2V_IGEMM_K16=0) walks
     k in the same order, so the two must agree bit for bit -- on plain, residual and GEGLU epilogues, ragged M / N included."""
