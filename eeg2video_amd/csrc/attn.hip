@@ -738,20 +738,31 @@ __global__ __launch_bounds__(256) void cross_attn_resident_kernel(const AttnArgs
         float l_tot;
         if constexpr (SUMV) l_tot = __shfl(acc[T - 1][LREG], j + 32 * LHALF);
         else l_tot = ps + __shfl_xor(ps, 32);
-        if (row0 + j < rows) {
+        {
+            // O rows leave as 16-byte pieces: a lane holds 4 consecutive value columns per register quad (8 rg + 4 h), the other half-wave
+            // the next 4; v_permlane32_swap on the packed pairs of two adjacent quads (rg = 2k, 2k + 1) leaves lane (j, h) with the 8
+            // columns 16 k + 8 h .. + 7 -- per row and instruction 32 contiguous bytes, half as many store instructions as 8-byte pieces
             const float inv = 1.0f / l_tot;
-            __bf16* op = O + (size_t)(row0 + j) * p.ldo;
+            const bool row_ok = row0 + j < rows;
+            __bf16* op = O + (size_t)min(row0 + j, rows - 1) * p.ldo;
+            typedef unsigned cu32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int dv = t * 32 + 8 * rg + 4 * h;
-                    if (dv < D) {
-                        abf16x4 o;
+                for (int k = 0; k < 2; ++k) {
+                    if (32 * t + 16 * k >= D) continue;               // (compile-time: the pair lies beyond the head)
+                    abf16x4 oa, ob;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[t][rg * 4 + e] * inv);
-                        *reinterpret_cast<abf16x4*>(op + dv) = o;
+                    for (int e = 0; e < 4; ++e) {
+                        oa[e] = (__bf16)(acc[t][(2 * k) * 4 + e] * inv);
+                        ob[e] = (__bf16)(acc[t][(2 * k + 1) * 4 + e] * inv);
                     }
+                    const cu32x2 a = __builtin_bit_cast(cu32x2, oa), bq = __builtin_bit_cast(cu32x2, ob);
+                    unsigned a0 = a[0], a1 = a[1], b0 = bq[0], b1 = bq[1];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+                    const int dv = 32 * t + 16 * k + 8 * h;
+                    if (row_ok && dv + 8 <= D) *reinterpret_cast<cu32x4*>(op + dv) = cu32x4{a0, a1, b0, b1};
                 }
         }
     }

@@ -10,7 +10,7 @@ summed over the SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs.
 import collections, csv, glob, json, os, sys
 
 CLASSES = [("bgemm", "igemm_bf16"), ("igemm_kernel", "igemm_f32"), ("igemm_k16_kernel", "igemm_f32"), ("igemm_x3_kernel", "igemm_f32x3"),
-           ("flash_attn_b16io", "flash_attn_bf16"), ("flash_attn", "flash_attn"), ("wino4_in", "wino_in"), ("wino_in", "wino_in"),
+           ("flash_attn_b16io", "flash_attn_bf16"), ("cross_attn_resident", "cross_attn_bf16"), ("flash_attn", "flash_attn"), ("wino4_in", "wino_in"), ("wino_in", "wino_in"),
            ("wino4_out", "wino_out"), ("wino_out", "wino_out"), ("gn_partial", "gn_partial"), ("gn_apply", "gn_apply"),
            ("layernorm", "layernorm"), ("temporal_attn", "temporal_attn")]
 
