@@ -17,7 +17,7 @@ namespace e2v {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static constexpr int GN_ROWS_PER_CHUNK = 256;
+static constexpr int GN_ROWS_PER_CHUNK = 64;      // granularity of the partial-sum slab (callers size it with groupnorm_chunks)
 
 int groupnorm_chunks(int P) { return (P + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK; }
 
@@ -32,13 +32,13 @@ static int quad_tile(int cq) {
 // grid (chunks, slabs); part[((slab*chunks + chunk)*Ctot + coff + c)*2 + {0,1}]
 template <typename T>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int ld, int C, int P, int chunks,
-                                                         float* __restrict__ part, int Ctot, int coff, int QT) {
+                                                         float* __restrict__ part, int Ctot, int coff, int QT, int chunk_rows) {
     __shared__ f32x4 red[2][256];
     const int chunk = blockIdx.x, slab = blockIdx.y;
     const int R = 256 / QT;
     const int q = threadIdx.x % QT, r = threadIdx.x / QT;
-    const int p0 = chunk * GN_ROWS_PER_CHUNK;
-    const int p1 = min(P, p0 + GN_ROWS_PER_CHUNK);
+    const int p0 = chunk * chunk_rows;
+    const int p1 = min(P, p0 + chunk_rows);
     const T* base = x + (size_t)slab * P * ld;
     float* dst = part + ((size_t)(slab * chunks + chunk) * Ctot + coff) * 2;
     const int CQ = C / 4;
@@ -185,13 +185,13 @@ __device__ __forceinline__ void st8(__bf16* p, const f32x4& lo, const f32x4& hi)
 
 // grid (chunks, slabs); same partial layout as gn_partial_kernel; OT = octets handled side by side (divides C / 8, <= 64)
 __global__ __launch_bounds__(256) void gn_partial8_kernel(const __bf16* __restrict__ x, int ld, int C, int P, int chunks,
-                                                          float* __restrict__ part, int Ctot, int coff, int OT) {
+                                                          float* __restrict__ part, int Ctot, int coff, int OT, int chunk_rows) {
     __shared__ f32x4 red[4][256];
     const int chunk = blockIdx.x, slab = blockIdx.y;
     const int R = 256 / OT;
     const int q = threadIdx.x % OT, r = threadIdx.x / OT;
-    const int p0 = chunk * GN_ROWS_PER_CHUNK;
-    const int p1 = min(P, p0 + GN_ROWS_PER_CHUNK);
+    const int p0 = chunk * chunk_rows;
+    const int p1 = min(P, p0 + chunk_rows);
     const __bf16* base = x + (size_t)slab * P * ld;
     float* dst = part + ((size_t)(slab * chunks + chunk) * Ctot + coff) * 2;
     const int CO = C / 8;
@@ -270,13 +270,13 @@ __device__ __forceinline__ float silu_fast(float v) {
 template <bool ACT>
 __global__ __launch_bounds__(256) void gn_apply8_rows_kernel(const __bf16* __restrict__ x0, const __bf16* __restrict__ x1, int c0, int c1,
                                                              int ld0, int ld1, const float* __restrict__ scsh, __bf16* __restrict__ out,
-                                                             int ldo, int P, int OT) {
+                                                             int ldo, int P, int OT, int chunk_rows) {
     const int chunk = blockIdx.x, slab = blockIdx.y;
     const int R = 256 / OT;
     const int q = threadIdx.x % OT, r = threadIdx.x / OT;
     if (r >= R) return;
-    const int p0 = chunk * GN_ROWS_PER_CHUNK;
-    const int p1 = min(P, p0 + GN_ROWS_PER_CHUNK);
+    const int p0 = chunk * chunk_rows;
+    const int p1 = min(P, p0 + chunk_rows);
     const int Ctot = c0 + c1;
     const size_t row0 = (size_t)slab * P;
     const float* scb = scsh + (size_t)slab * Ctot * 2;
@@ -315,20 +315,33 @@ static int oct_tile(int co) {
     return best;
 }
 
+// Rows per workgroup of the statistics / apply passes, a multiple of GN_ROWS_PER_CHUNK chosen from the SAMPLE's size only (never
+// from the batch: the grouping of the fp32 partial sums must not depend on how many clips run together).  Level 0 (13 824 rows per
+// sample) streams 256-row chunks; the deeper levels (3456 / 864 / 240 rows) get 64-row chunks -- at 256 they were 14 / 4 / 1
+// workgroups per sample and the chip ran a quarter full (tools/norm_micro.py: 1.7 TB/s at level 2).
+static int gn_chunk_rows(const int P) {
+    static const int* const big = knob("E2V_GN_CHUNK_ROWS", 256);
+    static const int* const small = knob("E2V_GN_CHUNK_ROWS_SMALL", 64);
+    const int want = P >= 8192 ? *big : *small;
+    const int v = want / GN_ROWS_PER_CHUNK * GN_ROWS_PER_CHUNK;
+    return v < GN_ROWS_PER_CHUNK ? GN_ROWS_PER_CHUNK : v;
+}
+
 static void groupnorm_stats_launch(const GroupNormArgs& a, hipStream_t s) {
     const int Ctot = a.c0 + a.c1;
-    const int chunks = groupnorm_chunks(a.P);
+    const int crows = gn_chunk_rows(a.P);
+    const int chunks = (a.P + crows - 1) / crows;
     auto part = [&](const float* x, int ld, int C, int coff) {
         const int qt = quad_tile(C / 4);
         if (a.bf16 && C % 8 == 0 && ld % 8 == 0)
             hipLaunchKernelGGL(gn_partial8_kernel, dim3(chunks, a.samples), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), ld, C, a.P,
-                               chunks, a.ws_part, Ctot, coff, oct_tile(C / 8));
+                               chunks, a.ws_part, Ctot, coff, oct_tile(C / 8), crows);
         else if (a.bf16)
             hipLaunchKernelGGL(gn_partial_kernel<__bf16>, dim3(chunks, a.samples), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), ld, C,
-                               a.P, chunks, a.ws_part, Ctot, coff, qt);
+                               a.P, chunks, a.ws_part, Ctot, coff, qt, crows);
         else
             hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(chunks, a.samples), dim3(256), 0, s, x, ld, C, a.P, chunks, a.ws_part, Ctot,
-                               coff, qt);
+                               coff, qt, crows);
     };
     part(a.x0, a.ld0, a.c0, 0);
     if (a.c1 > 0) part(a.x1, a.ld1, a.c1, a.c0);
@@ -352,10 +365,11 @@ static void groupnorm_bf16_launch(const GroupNormArgs& a, hipStream_t s) {
     const size_t rows = (size_t)a.samples * a.P;
     if (*rowsp) {
         const int ot = oct_tile(a.c1 > 0 ? gcd_int(a.c0 / 8, a.c1 / 8) : a.c0 / 8);
-        const dim3 grid(groupnorm_chunks(a.P), a.samples);
+        const int crows = gn_chunk_rows(a.P);
+        const dim3 grid((a.P + crows - 1) / crows, a.samples);
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0), reinterpret_cast<const __bf16*>(a.x1), a.c0,
-                               a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<__bf16*>(a.out), a.ldo, a.P, ot);
+                               a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<__bf16*>(a.out), a.ldo, a.P, ot, crows);
         };
         if (a.silu) go(gn_apply8_rows_kernel<true>); else go(gn_apply8_rows_kernel<false>);
         return;

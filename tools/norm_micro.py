@@ -1,6 +1,6 @@
 """Micro-benchmark of the bf16 GroupNorm(+SiLU) and LayerNorm passes at the UNet's B = 32 shapes (64 CFG samples): the flat-index apply
-pass against the row-tiled one (E2V_GN_ROWS) and whole-tensor launches against runs of samples sized for the Infinity Cache
-(E2V_GN_GROUP_MB), switched inside one process.  usage: python tools/norm_micro.py"""
+pass against the row-tiled one (E2V_GN_ROWS) and rows per workgroup of the two passes (E2V_GN_CHUNK_ROWS), switched inside one process.  (Runs of samples sized for the
+Infinity Cache, E2V_GN_GROUP_MB, measured slower: profiles/r03_norm_micro.log.)  usage: python tools/norm_micro.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,8 +9,9 @@ from eeg2video_amd.weights import TINY_UNET, TINY_VAE
 eng = Engine(TINY_UNET, TINY_VAE, 0)
 eng.set_compute_dtype("bf16")
 n = int(os.environ.get("N", "64"))
-variants = [{"E2V_GN_ROWS": 0, "E2V_GN_GROUP_MB": 0}, {"E2V_GN_ROWS": 1, "E2V_GN_GROUP_MB": 0}, {"E2V_GN_ROWS": 1, "E2V_GN_GROUP_MB": 32},
-            {"E2V_GN_ROWS": 1, "E2V_GN_GROUP_MB": 64}, {"E2V_GN_ROWS": 1, "E2V_GN_GROUP_MB": 96}]
+variants = [{"E2V_GN_ROWS": 1, "E2V_GN_CHUNK_ROWS": 256, "E2V_GN_CHUNK_ROWS_SMALL": 256}, {"E2V_GN_ROWS": 1, "E2V_GN_CHUNK_ROWS": 256, "E2V_GN_CHUNK_ROWS_SMALL": 128},
+            {"E2V_GN_ROWS": 1, "E2V_GN_CHUNK_ROWS": 256, "E2V_GN_CHUNK_ROWS_SMALL": 64}, {"E2V_GN_ROWS": 1, "E2V_GN_CHUNK_ROWS": 128, "E2V_GN_CHUNK_ROWS_SMALL": 64},
+            {"E2V_GN_ROWS": 0, "E2V_GN_CHUNK_ROWS": 256, "E2V_GN_CHUNK_ROWS_SMALL": 64}]
 shapes = [("L0 320", 6 * 2304, 320, 0), ("L0 320+320", 6 * 2304, 320, 320), ("L0 640+320", 6 * 2304, 640, 320), ("L1 640", 6 * 576, 640, 0),
           ("L1 1280+640", 6 * 576, 1280, 640), ("L2 1280", 6 * 144, 1280, 0), ("L2 1280+1280", 6 * 144, 1280, 1280)]
 for name, P, c0, c1 in shapes:
@@ -33,11 +34,11 @@ for name, P, c0, c1 in shapes:
             ref = y
         err = (y - ref).abs().max().item()
         byt = 2.0 * 2 * n * P * (c0 + c1)
-        line += f"  [{v['E2V_GN_ROWS']},{v['E2V_GN_GROUP_MB']:3d}] {best:.3f} ms {byt / best / 1e6:5.0f} GB/s (d {err:.1e})"
+        line += f"  [{v['E2V_GN_ROWS']},{v['E2V_GN_CHUNK_ROWS']:3d},{v['E2V_GN_CHUNK_ROWS_SMALL']:3d}] {best:.3f} ms {byt / best / 1e6:5.0f} GB/s (d {err:.1e})"
         del y
     print(line, flush=True)
     del x0, x1, ref
-eng.set_knob("E2V_GN_ROWS", 1); eng.set_knob("E2V_GN_GROUP_MB", 0)
+eng.set_knob("E2V_GN_ROWS", 1); eng.set_knob("E2V_GN_CHUNK_ROWS", 256); eng.set_knob("E2V_GN_CHUNK_ROWS_SMALL", 64)
 for name, rows, c in [("LN L0 320", n * 6 * 2304, 320), ("LN L1 640", n * 6 * 576, 640), ("LN L2 1280", n * 6 * 144, 1280)]:
     x = torch.randn(rows, c, device="cuda")
     g = torch.rand(c, device="cuda") + 0.5
