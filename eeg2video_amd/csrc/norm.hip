@@ -635,6 +635,69 @@ __global__ __launch_bounds__(256) void layernorm_bf16_rows_kernel(const __bf16* 
     }
 }
 
+// fp32 rows, same scheme: C = 320 / 640 / 1280 are 80 / 160 / 320 float4 quads = five per lane of 16 / 32 / 64 lanes
+template <int LPR, int G>
+__global__ __launch_bounds__(256) void layernorm_f32_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ out, int ldo,
+                                                                 int rows, float eps) {
+    constexpr int NV = 5, RW = 64 / LPR, C = LPR * NV * 4;
+    const int lane = threadIdx.x & 63;
+    const int c = lane % LPR, rl = lane / LPR;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (RW * G) + rl;
+    if (row0 - rl >= rows) return;
+    f32x4 v[G][NV];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int row = min(row0 + g * RW, rows - 1);
+        const float* xr = x + (size_t)row * ldx + c * 4;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[g][k] = *reinterpret_cast<const f32x4*>(xr + k * LPR * 4);
+    }
+    auto allreduce = [](float t) {
+        if constexpr (LPR == 64) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+            return t;
+        } else {
+            return rowlanes_allreduce<LPR>(t);
+        }
+    };
+    float mean[G], rstd[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) t += (v[g][k][0] + v[g][k][1]) + (v[g][k][2] + v[g][k][3]);
+        mean[g] = allreduce(t) * (1.0f / (float)C);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[g][k][e] - mean[g];
+                t += d * d;
+            }
+        rstd[g] = rsqrtf(allreduce(t) * (1.0f / (float)C) + eps);
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int ch = (c + k * LPR) * 4;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch), b0 = *reinterpret_cast<const f32x4*>(beta + ch);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (row0 + g * RW < rows) {
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (v[g][k][e] - mean[g]) * rstd[g] * g0[e] + b0[e];
+                *reinterpret_cast<f32x4*>(out + (size_t)(row0 + g * RW) * ldo + ch) = y;
+            }
+        }
+    }
+}
+
 template <typename T>
 static void layernorm_launch(const T* x, int ldx, const float* gamma, const float* beta, T* out, int ldo, int rows, int C, float eps,
                              hipStream_t s) {
@@ -671,7 +734,15 @@ void layernorm(const float* x, int ldx, const float* gamma, const float* beta, f
         else hipLaunchKernelGGL((layernorm_bf16_kernel<3, R>), dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, C, eps);
     } else if (bf16)
         layernorm_launch(reinterpret_cast<const __bf16*>(x), ldx, gamma, beta, reinterpret_cast<__bf16*>(out), ldo, rows, C, eps, s);
-    else
+    else if (*rowsp && (C == 320 || C == 640 || C == 1280) && ldx % 4 == 0 && ldo % 4 == 0) {
+        auto go = [&](auto kern, const int rows_per_wave) {
+            const int blocks = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, eps);
+        };
+        if (C == 320) go(layernorm_f32_rows_kernel<16, 2>, 8);
+        else if (C == 640) go(layernorm_f32_rows_kernel<32, 2>, 4);
+        else go(layernorm_f32_rows_kernel<64, 2>, 2);
+    } else
         layernorm_launch(x, ldx, gamma, beta, out, ldo, rows, C, eps, s);
 }
 

@@ -195,6 +195,13 @@ def test_groupnorm_concat_group_straddles_seam(eng):
 def test_layernorm(eng, c):
     x, g, b = rnd(777, c, seed=40) * 3 + 1, rnd(c, seed=41) * 0.2 + 1, rnd(c, seed=42) * 0.2
     close(eng.op_layernorm(x.cuda(), g.cuda(), b.cuda()), F.layer_norm(x, (c,), g, b, 1e-5))
+    try:                                                     # the wave-per-row kernel (C = 320 / 640 / 1280 take the shared-wave rows by default)
+        eng.set_knob("E2V_LN_ROWS", 0)
+        close(eng.op_layernorm(x.cuda(), g.cuda(), b.cuda()), F.layer_norm(x, (c,), g, b, 1e-5))
+    finally:
+        eng.set_knob("E2V_LN_ROWS", 1)
+    for rows in (1, 3, 9):                                   # ragged row groups
+        close(eng.op_layernorm(x[:rows].cuda().contiguous(), g.cuda(), b.cuda()), F.layer_norm(x[:rows], (c,), g, b, 1e-5))
 
 
 # ------------------------------------------------------------------ attention -----------------------
