@@ -49,7 +49,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t t256_rsrc(const void* ptr, con
 }
 
 template <int NT, bool LIN>
-__global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
+__device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, const int col_off) {
     constexpr int BM = 256, WN = 16 * NT, BN = 4 * WN;
     constexpr int N0 = (NT + 1) / 2, N1 = NT / 2;            // column tiles of a wave: first group (phases 0, 3), second group (phases 1, 2)
     constexpr int ROWB = 128;                                // bytes per LDS row = one 64-deep K step of bf16
@@ -68,12 +68,13 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
 
     // ---- tile of this workgroup: XCD x (= blockIdx % 8, blocks are dealt round-robin) owns a contiguous run of row blocks, column
     // tiles of one row block adjacent (they share the gathered X rows in that XCD's L2)
-    const int nct = (p.N + BN - 1) / BN;
-    const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    // (a partial launch -- the tail split of bgemm_t256_launch -- starts at row block rb0 and takes column tiles col_off + k col_stride)
+    const int nct = p.nct_l ? p.nct_l : (p.N + BN - 1) / BN;
+    const int x = vblock & 7, loc = vblock >> 3;
     const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
     if (loc >= (rb_hi - rb_lo) * nct) return;
-    const int bm = rb_lo + loc / nct;
-    const int n0 = (loc % nct) * BN;
+    const int bm = p.rb0 + rb_lo + loc / nct;
+    const int n0 = col_off + (loc % nct) * (p.col_stride ? p.col_stride : BN);
 
     const int steps0 = p.c0 >> 6, steps1 = p.c1 >> 6;        // channel counts are multiples of 64 (launcher)
     const int nk = p.taps * (steps0 + steps1);
@@ -444,6 +445,21 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
             }
         }
     }
+}
+
+template <int NT, bool LIN>
+__global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
+    t256_body<NT, LIN>(p, blockIdx.x, p.col_off);
+}
+
+// The tail split's two tile widths in ONE launch (two launches on a stream run one after the other, each a third of the chip):
+// groups of eight workgroups alternate between 256 x 192 tiles at column offset col_off and 256 x 128 tiles at col_off2; the low
+// three bits of the block index -- the XCD -- stay what they are.
+template <bool LIN>
+__global__ __launch_bounds__(512) void bgemm_t256_tail_kernel(const IgemmArgs p) {
+    const int vblock = (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7));
+    if ((blockIdx.x >> 3) & 1) t256_body<2, LIN>(p, vblock, p.col_off2);
+    else t256_body<3, LIN>(p, vblock, p.col_off);
 }
 
 // ---- persistent form for the linears (taps = 1) ----------------------------------------------------------------------------------
@@ -874,29 +890,20 @@ static int t256_tile_cols(const IgemmArgs& a, const bool force = false) {      /
     return cols;
 }
 
-bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
-    const int cols = t256_tile_cols(a_in, a_in.osy != 0);
-    if (!cols) return false;
-    IgemmArgs a = a_in;
-    a.nbm = (a.M + 255) / 256;
+// One launch of `nbm` row blocks from row block rb0 on (whole width unless a column tiling is given): the grid and the kernel instance
+static void t256_launch_part(IgemmArgs a, const int cols, const int rb0, const int nbm, const int col_off, const int col_stride, const int nct_l,
+                             const int nt, const bool allow_persistent, hipStream_t s) {
+    a.nbm = nbm; a.rb0 = rb0; a.col_off = col_off; a.col_stride = col_stride; a.nct_l = nct_l;
     int per_xcd = 0;
     for (int x = 0; x < 8; ++x) {
         const int nrb = (int)(((long)(x + 1) * a.nbm) >> 3) - (int)(((long)x * a.nbm) >> 3);
         per_xcd = nrb > per_xcd ? nrb : per_xcd;
     }
-    const int nct = a.N / cols;
-    const int grid = 8 * per_xcd * nct;
-    const size_t smem = (size_t)2 * (256 + cols) * 128;
+    const int nct = nct_l ? nct_l : a.N / cols;
+    const int grid = 8 * per_xcd * nct * (nt == 0 ? 2 : 1);
+    const size_t smem = (size_t)2 * (256 + 64 * (nt == 0 ? 3 : nt)) * 128;
     const bool lin = a.taps == 1;
-    const double K = (double)a.taps * (a.c0 + a.c1);
-    const double rows_in = lin ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
-    std::string pname = "igemm_bf16";
-    if (profiler().on && profiler().detail)
-        pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t" + std::to_string(a.taps) +
-                 (a.stride > 1 ? " s2" : "") + (a.c1 ? " cat" : "") + (a.geglu ? " geglu" : "") + " T" + std::to_string(cols);
-    const double out_b = a.out_f32 ? 4.0 : 2.0;
-    ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K,
-                 2.0 * rows_in * (a.c0 + a.c1) + 2.0 * a.N * K + out_b * a.M * (a.geglu ? a.N / 2 : a.N), s);
+    if (nt == 0) a.col_off2 = col_off + 192;
     auto go = [&](auto kern) {
         static bool cfg = false;
         if (!cfg) {
@@ -913,11 +920,11 @@ bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
     // 320 -> 320 -3 % against bgemm.hip's persistent 128-row kernel, which the K <= 640 projections with a residual used to stay on.
     static const int* const persp = knob("E2V_BGEMM_T256P", 1);
     static const int* const pmaxk = knob("E2V_BGEMM_T256P_MAXK", 1 << 30);
-    const long ntiles = (long)a.nbm * nct;
     static const int* const pmint = knob("E2V_BGEMM_T256P_MINTILES", 256);
+    const long ntiles = (long)a.nbm * nct;
     // (the epilogue reads the residual in the output's type: fp32 with fp32 at the test entry points, bf16 with bf16 in the graph)
     const bool io_ok = !a.resid || (a.out_f32 ? !a.resid_bf16 : a.resid_bf16 != 0);
-    if (lin && io_ok && *persp && (*persp == 2 || (a.c0 + a.c1 <= *pmaxk && ntiles >= *pmint))) {
+    if (allow_persistent && lin && io_ok && *persp && (*persp == 2 || (a.c0 + a.c1 <= *pmaxk && ntiles >= *pmint))) {
         auto gop = [&](auto kern) {
             static bool cfg = false;
             if (!cfg) {
@@ -932,10 +939,47 @@ bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
         if (cols == 320) { if (f32io) gop(bgemm_t256p_kernel<5, false, true>); else gop(bgemm_t256p_kernel<5, false, false>); }
         else if (a.geglu) { if (f32io) gop(bgemm_t256p_kernel<4, true, true>); else gop(bgemm_t256p_kernel<4, true, false>); }
         else { if (f32io) gop(bgemm_t256p_kernel<4, false, true>); else gop(bgemm_t256p_kernel<4, false, false>); }
+        return;
+    }
+    switch (nt) {
+        case 5: if (lin) go(bgemm_t256_kernel<5, true>); else go(bgemm_t256_kernel<5, false>); break;
+        case 4: if (lin) go(bgemm_t256_kernel<4, true>); else go(bgemm_t256_kernel<4, false>); break;
+        default: if (lin) go(bgemm_t256_tail_kernel<true>); else go(bgemm_t256_tail_kernel<false>); break;
+    }
+}
+
+bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
+    const int cols = t256_tile_cols(a_in, a_in.osy != 0);
+    if (!cols) return false;
+    const IgemmArgs& a = a_in;
+    const int nbm = (a.M + 255) / 256;
+    const int nct = a.N / cols;
+    const bool lin = a.taps == 1;
+    const double K = (double)a.taps * (a.c0 + a.c1);
+    const double rows_in = lin ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
+    std::string pname = "igemm_bf16";
+    if (profiler().on && profiler().detail)
+        pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t" + std::to_string(a.taps) +
+                 (a.stride > 1 ? " s2" : "") + (a.c1 ? " cat" : "") + (a.geglu ? " geglu" : "") + " T" + std::to_string(cols);
+    const double out_b = a.out_f32 ? 4.0 : 2.0;
+    ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K,
+                 2.0 * rows_in * (a.c0 + a.c1) + 2.0 * a.N * K + out_b * a.M * (a.geglu ? a.N / 2 : a.N), s);
+    // Tail split (E2V_BGEMM_T256_TAIL = 1; OFF by default).  256 CUs take whole tiles: a launch of 3.375 rounds (level 2 at B = 32: 216
+    // row blocks x 4 column tiles) runs four, the last one three eighths full.  With the switch on, when the last round would be at
+    // most half full its row blocks go into a second launch as 256 x 192 and 256 x 128 tiles (the same kernel body with NT = 3 / 2:
+    // two tiles per 320 columns, twice as many workgroups).  Same k order per output: bit-identical
+    // (tests/test_hip_ops.py::test_bf16_t256_tail_split).  MEASURED (same-process A/B over a B = 32 UNet step): the level-2 convs -3 %
+    // (not the -9 % of the round count: the narrow tiles' phases are 8-12 MFMAs long and run at half the efficiency), 320 -> 320 at
+    // level 0 +3 % (its persistent launch loses 128 tiles to a non-persistent one), 198.6 -> 198.4 ms per step: not worth a default.
+    static const int* const tailp = knob("E2V_BGEMM_T256_TAIL", 0);
+    const long T = (long)nbm * nct, full = T / 256, tail = T - 256 * full;
+    if (*tailp && cols == 320 && !a.geglu && full >= 1 && tail > 0 && 2 * tail <= 256 && (256 * full) % nct == 0) {
+        const int r1 = (int)(256 * full / nct);
+        t256_launch_part(a, cols, 0, r1, 0, 0, 0, 5, true, s);
+        t256_launch_part(a, cols, r1, nbm - r1, 0, 320, nct, 0, false, s);      // nt = 0: the tail kernel (192- and 128-column tiles)
         return true;
     }
-    if (cols == 320) { if (lin) go(bgemm_t256_kernel<5, true>); else go(bgemm_t256_kernel<5, false>); }
-    else             { if (lin) go(bgemm_t256_kernel<4, true>); else go(bgemm_t256_kernel<4, false>); }
+    t256_launch_part(a, cols, 0, nbm, 0, 0, 0, cols / 64, true, s);
     return true;
 }
 

@@ -55,6 +55,7 @@ struct IgemmArgs {
     int bm256 = 0;                 // filled by the launcher: 256-row tiles (bgemm256_kernel)
     int ablate = 0;                // timing experiments only (E2V_BGEMM_ABLATE): 1 = no output stores, 2 = A loads read zeros, 3 = both
     int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, nbm_per = 0, tail_rb = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
+    int rb0 = 0, col_off = 0, col_off2 = 0, col_stride = 0, nct_l = 0;   // filled by bgemm256.hip's launcher: first row block / column tiling of a partial launch (tail split)
 };
 void igemm(const IgemmArgs& a, hipStream_t s);
 // Run-time switches: an int per name, initialised from the environment variable of that name on first use

@@ -630,6 +630,32 @@ def test_bf16_t256_conv3x3_geometries(bf256):
     close(from_cl(yc, nn, h, w), refc, rtol=1e-4, atol=1e-4)
 
 
+def test_bf16_t256_tail_split(bf256):
+    """A launch whose last round of 256 workgroups would be at most half full sends the row blocks of that round through a second
+    launch of 256 x 192 and 256 x 128 tiles (bgemm_t256_tail_kernel).  Same k order per output: bit-identical to the unsplit launch.
+    Linear (persistent main part, residual) and 3x3 conv (time-embedding rows, residual, a ragged last row block)."""
+    bf = bf256
+    m, k, n = 256 * 66 + 40, 320, 1280                     # 67 row blocks x 4 column tiles = 268 tiles: one full round + 12
+    x, w, b, r = rnd(m, k, seed=190), rnd(n, k, seed=191, scale=0.05), rnd(n, seed=192), rnd(m, n, seed=193)
+    nimg, c, cout, h, wd = 118, 64, 1280, 9, 16             # M = 16 992 = 66.4 row blocks
+    xc, wc, bc = rnd(nimg, c, h, wd, seed=194), rnd(cout, c, 3, 3, seed=195, scale=0.05), rnd(cout, seed=196)
+    temb, res = rnd(2, cout, seed=197), rnd(nimg, cout, h, wd, seed=198)
+    outs = {}
+    try:
+        for tail in (1, 0):
+            bf.set_knob("E2V_BGEMM_T256_TAIL", tail)
+            y = bf.op_linear(x.cuda(), w.cuda(), b.cuda(), r.cuda())
+            yc = bf.op_conv3x3(to_cl(xc).cuda(), wc.cuda(), bc.cuda(), n_img=nimg, Hs=h, Ws=wd, rowbias=temb.cuda().contiguous(),
+                               rows_per_sample=59 * h * wd, resid=to_cl(res).cuda())
+            outs[tail] = (y, yc)
+    finally:
+        bf.set_knob("E2V_BGEMM_T256_TAIL", 0)                 # (the default: measured +-0 over a UNet step, DESIGN section 9)
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+    close(outs[1][0], F.linear(rb(x), rb(w), b) + r, rtol=1e-4, atol=1e-4)
+    refc = F.conv2d(rb(xc), rb(wc), bc, padding=1) + temb.repeat_interleave(59, 0)[:, :, None, None] + res
+    close(from_cl(outs[1][1], nimg, h, wd), refc, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("n,c,cout,hs,ws", [(12, 320, 320, 18, 32), (5, 256, 256, 9, 16), (3, 640, 640, 5, 8), (2, 128, 512, 7, 6)])
 def test_bf16_upsample_conv_sub_pixel_form(bf256, n, c, cout, hs, ws):
     """`Upsample3D` (resnet.py:30-62: nearest 2x + 3x3 conv) as four 2x2 convs on the source map, one per output parity, weights summed
