@@ -68,3 +68,30 @@ def test_gather_options_and_budget_guard_parse(bench):
     d = bench.parse_args([])
     assert d.gather == "fp32" and d.gather_impl == "torch" and not d.no_configs2 and 300 < d.configs2_budget_s < 600
     assert 0 <= bench.process_age_s() < 3600
+
+
+def test_committed_bench_lines_keep_the_contract_and_quote_the_committed_pmc_traffic():
+    """profiles/r03_bench_*.json are the lines `bench.py` printed on the GPU box: the driver's contract keys, the `roofline` and
+    `cpu_baseline` objects, the `configs2` leg in the default line -- and `roofline.traffic` must be the figure of
+    profiles/pmc_dominant_kernel.json for that batch / dtype (the PMC passes and the bench lines are regenerated together)."""
+    import json
+    prof = os.path.join(ROOT, "profiles")
+    pmc = json.load(open(os.path.join(prof, "pmc_dominant_kernel.json")))
+    d = json.load(open(os.path.join(prof, "r03_bench_default.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] and d["unit"] == "clips/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["kernel"] == "igemm_f32" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] == pmc["igemm_f32"]["hbm_bytes_per_launch"] and pmc["igemm_f32"]["batch"] == 8
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert d["parity"]["frames_max_abs"] < d["parity"]["tolerance_frames_max_abs"]
+    c2 = d["configs2"]
+    assert c2["dtype"] == "bf16" and c2["value"] > 0 and c2["roofline"]["kernel"] == "igemm_bf16"
+    assert c2["roofline"]["traffic"] == pmc["igemm_bf16"]["hbm_bytes_per_launch"] and pmc["igemm_bf16"]["batch"] == 32
+    b = json.load(open(os.path.join(prof, "r03_bench_bf16_b32.json")))
+    assert b["dtype"] == "bf16" and b["roofline"]["traffic"] == pmc["igemm_bf16"]["hbm_bytes_per_launch"]
+    wp = b["roofline"]["whole_path"]
+    assert abs(wp["achieved_tflops"] - b["value"] * wp["algorithmic_tflop_per_clip"]) < 1e-6 and abs(wp["frac"] - wp["achieved_tflops"] / wp["peak"]) < 1e-9
