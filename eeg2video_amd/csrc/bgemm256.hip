@@ -471,7 +471,11 @@ __global__ __launch_bounds__(512) void bgemm_t256_tail_kernel(const IgemmArgs p)
 // from the accumulator registers, no LDS: both K-step buffers are being refilled -- runs with two K steps of the next tile in
 // flight, and its stores are never waited for.  The two wave rows re-align for the epilogue (one barrier) and split again
 // behind it.  Same K loop, same k order, same arithmetic: bit-identical to the kernel above.
-template <int NT, bool GEGLU, bool F32IO>      // F32IO: fp32 output and residual (the op-level test entry points); else bf16 (the graph)
+// BLDS: the bias vector ([N] floats, at most the LDS the operand buffers leave free) is copied into LDS once per workgroup and the
+// epilogue reads it from there.  As buffer loads at the head of the epilogue the NT bias quads were the youngest entries of the wave's
+// in-order memory queue: waiting for them drained the DMA of the next tile's first K steps (~0.7 us per tile; the residual-free
+// K = 320 / 640 projections -- QKV, GEGLU -- have no other load there).
+template <int NT, bool GEGLU, bool F32IO, bool BLDS>      // F32IO: fp32 output and residual (the op-level test entry points); else bf16 (the graph)
 __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
     constexpr int BM = 256, WN = 16 * NT, BN = 4 * WN;
     constexpr int N0 = (NT + 1) / 2, N1 = NT / 2;
@@ -492,6 +496,12 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
     const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
     const int ntx = (rb_hi - rb_lo) * nct;                   // tiles of this XCD
     if (slot >= ntx) return;
+    float* const lds_bias = reinterpret_cast<float*>(smem + 2 * (XBYTES + WBYTES));      // behind the operand buffers
+    if constexpr (BLDS) {
+        for (int i = tid * 4; i < p.N; i += 512 * 4)         // (N is a multiple of 64)
+            *reinterpret_cast<f32x4*>(lds_bias + i) = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                                      // (vmcnt(0) + lgkmcnt(0) + barrier: nothing of this is pending when the DMA ring starts)
+    }
     const int steps0 = p.c0 >> 6, steps1 = p.c1 >> 6;
     const int nk = steps0 + steps1;
 
@@ -707,8 +717,10 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
         const unsigned vr0 = ((unsigned)(wr * 128 + fl) * p.ldr + n0 + wc * WN + 4 * fq) * osz;
         f32x4 bias[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            bias[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)(n0 + wc * WN + nt * 16 + 4 * fq) * 4u, 0, 0));
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (BLDS) bias[nt] = *reinterpret_cast<const f32x4*>(lds_bias + n0 + wc * WN + nt * 16 + 4 * fq);
+            else bias[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)(n0 + wc * WN + nt * 16 + 4 * fq) * 4u, 0, 0));
+        }
         // Two adjacent 16-column tiles leave the wave as 16-byte stores: a lane holds channels 4 fq .. + 3 of BOTH tiles; after
         // v_permlane16_swap (odd 16-lane rows of the first operand <-> even rows of the second) an even-fq lane holds channels
         // 8 (fq >> 1) .. + 7 of the first tile and an odd-fq lane the same channels of the second one -- every row of the wave's 16
@@ -767,7 +779,9 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
                     const unsigned vr = vr0 + (unsigned)(h * 64 + mt * 16) * p.ldr * osz;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        if constexpr (F32IO) res[mt][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, vr, (unsigned)(nt * 16) * 4u, 0));
+                        if constexpr (BLDS) {                        // (BLDS launches have no residual: nothing enters the memory queue here)
+                            res[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        } else if constexpr (F32IO) res[mt][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, vr, (unsigned)(nt * 16) * 4u, 0));
                         else if ((nt & 1) == 0 && nt + 1 < NT) {      // two adjacent tiles: 16 bytes per lane (channels 8 (fq >> 1) .. + 7 of tile nt + (fq & 1)), un-paired below
                             const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(rr, vrp0 + (unsigned)(h * 64 + mt * 16) * p.ldr * 2u, (unsigned)(nt * 16) * 2u, 0);
                             rb4[mt][nt] = __builtin_bit_cast(bf16x4, u32x2{l[0], l[1]});
@@ -786,7 +800,7 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
                             for (int e = 0; e < 4; ++e) y[e] = acc[h][mt][nt][e];
                             if (p.alpha != 1.0f) y *= p.alpha;
                             y += bias[nt];
-                            y += res[mt][nt];
+                            if constexpr (!BLDS) y += res[mt][nt];
                             if (p.relu) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
@@ -803,7 +817,7 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
                         const unsigned vo = vo0 + (unsigned)(h * 64 + mt * 16) * p.ldc * osz;
                         const unsigned vop = vop0 + (unsigned)(h * 64 + mt * 16) * p.ldc * 2u;
 #pragma unroll
-                        for (int nt = 0; nt + 1 < NT; nt += 2) {     // (swap of the first dwords, then of the second ones: see store_pair)
+                        for (int nt = 0; nt + 1 < NT && !BLDS; nt += 2) {     // (swap of the first dwords, then of the second ones: see store_pair)
                             u32x2 a = __builtin_bit_cast(u32x2, rb4[mt][nt]), b = __builtin_bit_cast(u32x2, rb4[mt][nt + 1]);
                             unsigned l0 = a[0], l1 = a[1], l2 = b[0], l3 = b[1];
                             asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(l0), "+v"(l2), "+v"(l1), "+v"(l3));
@@ -817,8 +831,10 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
                             for (int e = 0; e < 4; ++e) y[nt][e] = acc[h][mt][nt][e];
                             if (p.alpha != 1.0f) y[nt] *= p.alpha;
                             y[nt] += bias[nt];
+                            if constexpr (!BLDS) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[nt][e] += (float)rb4[mt][nt][e];
+                                for (int e = 0; e < 4; ++e) y[nt][e] += (float)rb4[mt][nt][e];
+                            }
                             if (p.relu) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) y[nt][e] = fmaxf(y[nt][e], 0.f);
@@ -931,20 +947,29 @@ static void t256_launch_part(IgemmArgs a, const int cols, const int rb0, const i
     // (the epilogue reads the residual in the output's type: fp32 with fp32 at the test entry points, bf16 with bf16 in the graph)
     const bool io_ok = !a.resid || (a.out_f32 ? !a.resid_bf16 : a.resid_bf16 != 0);
     if (allow_persistent && lin && io_ok && *persp && (*persp == 2 || (a.c0 + a.c1 <= *pmaxk && ntiles >= *pmint))) {
+        // bias in LDS where it fits behind the operand buffers (160 KB per CU) and the epilogue loads nothing else (no residual)
+        static const int* const bldsp = knob("E2V_BGEMM_T256P_BIAS_LDS", 1);
+        const bool blds = *bldsp && !a.resid && smem + (size_t)a.N * 4 <= (size_t)160 * 1024;      // (no bias: the LDS copy is zeros)
         auto gop = [&](auto kern) {
             static bool cfg = false;
             if (!cfg) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * (256 + 320) * 128));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 cfg = true;
             }
             const int per = per_xcd * nct;                   // tiles of the largest XCD share
             const int slots = per < 32 ? per : 32;
-            hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), smem, s, a);
+            hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), smem + (blds ? (size_t)a.N * 4 : (size_t)0), s, a);
         };
         const bool f32io = a.out_f32 != 0;
-        if (cols == 320) { if (f32io) gop(bgemm_t256p_kernel<5, false, true>); else gop(bgemm_t256p_kernel<5, false, false>); }
-        else if (a.geglu) { if (f32io) gop(bgemm_t256p_kernel<4, true, true>); else gop(bgemm_t256p_kernel<4, true, false>); }
-        else { if (f32io) gop(bgemm_t256p_kernel<4, false, true>); else gop(bgemm_t256p_kernel<4, false, false>); }
+        auto pick = [&](auto ntc, auto gc) {
+            constexpr int NTc = decltype(ntc)::value;
+            constexpr bool Gc = decltype(gc)::value;
+            if (f32io) { if (blds) gop(bgemm_t256p_kernel<NTc, Gc, true, true>); else gop(bgemm_t256p_kernel<NTc, Gc, true, false>); }
+            else       { if (blds) gop(bgemm_t256p_kernel<NTc, Gc, false, true>); else gop(bgemm_t256p_kernel<NTc, Gc, false, false>); }
+        };
+        if (cols == 320) pick(std::integral_constant<int, 5>{}, std::false_type{});
+        else if (a.geglu) pick(std::integral_constant<int, 4>{}, std::true_type{});
+        else pick(std::integral_constant<int, 4>{}, std::false_type{});
         return;
     }
     switch (nt) {
