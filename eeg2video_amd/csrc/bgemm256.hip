@@ -364,86 +364,143 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
         b0 = *reinterpret_cast<const f32x4*>(p.bias + nn);
         b1 = *reinterpret_cast<const f32x4*>(p.bias + nn + 4);
     }
+    // The rows a lane finishes in one 32-row chunk (orow, orow + rpi, ...: at most ITER_N of them) read the residual and / or the
+    // time-embedding row from global memory.  Inside the row loop each was a load -> wait -> store round of its own: 24 exposed memory
+    // latencies per wave and tile (the conv tiles ran 183 us for 129 us of MFMAs).  Now the bf16 residual rows of a chunk (16 bytes
+    // per row) are ALL requested before the chunk is staged, and the time-embedding row is read once per chunk when the chunk's rows
+    // belong to one sample (they nearly always do).  The fp32 residual of the test entry points stays in the loop.
+    constexpr int RPI_N = 64 / (2 * NT), ITER_N = (32 + RPI_N - 1) / RPI_N;      // (GEGLU: 16 rows per pass, 2 passes <= ITER_N)
+    const bool pf_resid = !geglu && p.resid != nullptr && p.resid_bf16;
+    auto out_row = [&](const int m) -> size_t {              // (the sub-pixel kernels scatter their pixels over the 2x map)
+        if constexpr (!LIN) {
+            if (p.osy) {
+                const int img = m / hw_out, rem = m - img * hw_out;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                return ((size_t)img * p.Ho * p.osy + (size_t)(oy * p.osy + p.ooy)) * (size_t)(p.Wo * p.osx) + (size_t)(ox * p.osx + p.oox);
+            }
+        }
+        return (size_t)m;
+    };
+    // Four 32-row chunks c = (half, pair of row tiles).  Order: stage(c) frees the chunk's 8 NT accumulator registers; the loads of
+    // chunk c + 1 are issued before the rows of chunk c are finished (two prefetch sets alternate), so that only the first chunk's
+    // loads are exposed -- and never while all accumulators are still live: requested in front of stage(0), the prefetch registers
+    // pushed the allocator into spilling accumulators INSIDE the K loop.
+    f32x4 pfr[2][ITER_N], rbc0[2], rbc1[2];
+    bool rb_one[2];
+    auto chunk_m0 = [&](const int c) { return bm * BM + wr * 128 + (c >> 1) * 64 + (c & 1) * 32; };
+    auto issue_loads = [&](const int c, const int set) {
+        const int m0 = chunk_m0(c);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+        for (int it = 0; it < ITER_N; ++it) {
+            const int r = orow + it * rpi;
+            pfr[set][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (pf_resid && lane_on && r < 32 && m0 + r < p.M)
+                pfr[set][it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(p.resid) + out_row(m0 + r) * p.ldr + nn);      // 8 bf16, raw
+        }
+        // one time-embedding row for the chunk if its first and last row belong to the same sample (wave-uniform test)
+        const int m_last = min(m0 + 31, p.M - 1);
+        rb_one[set] = !geglu && p.rowbias != nullptr && m0 < p.M && m0 / p.rows_per_sample == m_last / p.rows_per_sample;
+        rbc0[set] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rbc1[set] = rbc0[set];
+        if (rb_one[set] && lane_on) {
+            const float* rb = p.rowbias + (size_t)(m0 / p.rows_per_sample) * p.rb_ld + nn;
+            rbc0[set] = *reinterpret_cast<const f32x4*>(rb);
+            rbc1[set] = *reinterpret_cast<const f32x4*>(rb + 4);
+        }
+    };
+    auto stage = [&](const int c) {
+        const int h = c >> 1, pr = c & 1;
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {                     // 32 rows = two 16-row tiles
+        for (int t = 0; t < 2; ++t) {
+            const int mt = pr * 2 + t;
+            if (geglu) {
+                if constexpr (NT == 4) {                 // value tiles 0, 1 | gate tiles 2, 3 of the wave's 64 packed columns
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int mt = pr * 2 + t;
-                if (geglu) {
-                    if constexpr (NT == 4) {                 // value tiles 0, 1 | gate tiles 2, 3 of the wave's 64 packed columns
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            const int cb = n0 + wc * WN + nt * 16 + 4 * fq;
-                            const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
-                            const f32x4 bg = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + cb + 32) : f32x4{0.f, 0.f, 0.f, 0.f};
-                            f32x4 y;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                y[e] = (acc[h][mt][nt][e] * p.alpha + bv[e]) * gelu_erf(acc[h][mt][nt + 2][e] * p.alpha + bg[e]);
-                            *reinterpret_cast<f32x4*>(st + (t * 16 + fl) * SLD + nt * 16 + 4 * fq) = y;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int cb = n0 + wc * WN + nt * 16 + 4 * fq;
+                        const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        const f32x4 bg = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + cb + 32) : f32x4{0.f, 0.f, 0.f, 0.f};
                         f32x4 y;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = acc[h][mt][nt][e];
+                        for (int e = 0; e < 4; ++e)
+                            y[e] = (acc[h][mt][nt][e] * p.alpha + bv[e]) * gelu_erf(acc[h][mt][nt + 2][e] * p.alpha + bg[e]);
                         *reinterpret_cast<f32x4*>(st + (t * 16 + fl) * SLD + nt * 16 + 4 * fq) = y;
                     }
                 }
-            }
-            // (the staging block is private to the wave: its own LDS writes are in order with its own reads)
-            for (int r = orow; r < 32; r += rpi) {
-                const int m = bm * BM + wr * 128 + h * 64 + pr * 32 + r;
-                if (!lane_on || m >= p.M) continue;
-                size_t orw = (size_t)m;                      // output row (the sub-pixel kernels scatter their pixels over the 2x map)
-                if constexpr (!LIN) {
-                    if (p.osy) {
-                        const int img = m / hw_out, rem = m - img * hw_out;
-                        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                        orw = ((size_t)img * p.Ho * p.osy + (size_t)(oy * p.osy + p.ooy)) * (size_t)(p.Wo * p.osx) + (size_t)(ox * p.osx + p.oox);
-                    }
-                }
-                f32x4 y0 = *reinterpret_cast<const f32x4*>(st + r * SLD + ocol);
-                f32x4 y1 = *reinterpret_cast<const f32x4*>(st + r * SLD + ocol + 4);
-                if (!geglu) {
-                    if (p.alpha != 1.0f) { y0 *= p.alpha; y1 *= p.alpha; }
-                    y0 += b0; y1 += b1;
-                    if (p.rowbias) {
-                        const float* rb = p.rowbias + (size_t)(m / p.rows_per_sample) * p.rb_ld + nn;
-                        y0 += *reinterpret_cast<const f32x4*>(rb);
-                        y1 += *reinterpret_cast<const f32x4*>(rb + 4);
-                    }
-                    if (p.resid) {
-                        if (p.resid_bf16) {
-                            const bf16x8 rr = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.resid) + orw * p.ldr + nn);
+            } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { y0[e] += (float)rr[e]; y1[e] += (float)rr[4 + e]; }
-                        } else {
-                            y0 += *reinterpret_cast<const f32x4*>(p.resid + orw * p.ldr + nn);
-                            y1 += *reinterpret_cast<const f32x4*>(p.resid + orw * p.ldr + nn + 4);
-                        }
-                    }
-                    if (p.relu) {
+                for (int nt = 0; nt < NT; ++nt) {
+                    f32x4 y;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { y0[e] = fmaxf(y0[e], 0.f); y1[e] = fmaxf(y1[e], 0.f); }
-                    }
-                }
-                if (p.out_f32) {
-                    float* o = p.out + orw * p.ldc + nn;
-                    *reinterpret_cast<f32x4*>(o) = y0;
-                    *reinterpret_cast<f32x4*>(o + 4) = y1;
-                } else {
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y0[e]; o[4 + e] = (__bf16)y1[e]; }
-                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + orw * p.ldc + nn) = o;
+                    for (int e = 0; e < 4; ++e) y[e] = acc[h][mt][nt][e];
+                    *reinterpret_cast<f32x4*>(st + (t * 16 + fl) * SLD + nt * 16 + 4 * fq) = y;
                 }
             }
         }
+    };
+    // (the staging block is private to the wave: its own LDS writes are in order with its own reads)
+    auto rows = [&](const int c, const int set) {
+        const int m0 = chunk_m0(c);
+#pragma unroll
+        for (int it = 0; it < ITER_N; ++it) {
+            const int r = orow + it * rpi;
+            const int m = m0 + r;
+            if (!lane_on || r >= 32 || m >= p.M) continue;
+            const size_t orw = out_row(m);
+            f32x4 y0 = *reinterpret_cast<const f32x4*>(st + r * SLD + ocol);
+            f32x4 y1 = *reinterpret_cast<const f32x4*>(st + r * SLD + ocol + 4);
+            if (!geglu) {
+                if (p.alpha != 1.0f) { y0 *= p.alpha; y1 *= p.alpha; }
+                y0 += b0; y1 += b1;
+                if (rb_one[set]) {
+                    y0 += rbc0[set]; y1 += rbc1[set];
+                } else if (p.rowbias) {
+                    const float* rb = p.rowbias + (size_t)(m / p.rows_per_sample) * p.rb_ld + nn;
+                    y0 += *reinterpret_cast<const f32x4*>(rb);
+                    y1 += *reinterpret_cast<const f32x4*>(rb + 4);
+                }
+                if (pf_resid) {
+                    const bf16x8 rr = __builtin_bit_cast(bf16x8, pfr[set][it]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { y0[e] += (float)rr[e]; y1[e] += (float)rr[4 + e]; }
+                } else if (p.resid) {
+                    if (p.resid_bf16) {
+                        const bf16x8 rr = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.resid) + orw * p.ldr + nn);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { y0[e] += (float)rr[e]; y1[e] += (float)rr[4 + e]; }
+                    } else {
+                        y0 += *reinterpret_cast<const f32x4*>(p.resid + orw * p.ldr + nn);
+                        y1 += *reinterpret_cast<const f32x4*>(p.resid + orw * p.ldr + nn + 4);
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { y0[e] = fmaxf(y0[e], 0.f); y1[e] = fmaxf(y1[e], 0.f); }
+                }
+            }
+            if (p.out_f32) {
+                float* o = p.out + orw * p.ldc + nn;
+                *reinterpret_cast<f32x4*>(o) = y0;
+                *reinterpret_cast<f32x4*>(o + 4) = y1;
+            } else {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y0[e]; o[4 + e] = (__bf16)y1[e]; }
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + orw * p.ldc + nn) = o;
+            }
+        }
+    };
+    stage(0);
+    issue_loads(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c + 1 < 4) issue_loads(c + 1, (c + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        rows(c, c & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < 4) stage(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
