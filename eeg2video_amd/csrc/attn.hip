@@ -799,6 +799,7 @@ static void launch_flash_b16io(const AttnArgs& a, hipStream_t s) {
     constexpr int VROW = ((T * 16) % 32 == 16) ? T * 64 : T * 64 + 64;      // as in the kernel
     auto stage_bytes = [](const int kt) { return ((size_t)kt * (DP * 2 + 16) + (size_t)kt * VROW + 15) / 16 * 16; };
     if (launch_cross_resident<D>(a, s)) return;
+    if (flash_attention_q64(a, s)) return;               // 64 queries per wave (attn_q64.hip): d = 40 / 80 self-attention
     static const int* const fold = knob("E2V_ATTN_FOLD", 1);     // 0: the plain form (scale and maximum applied by vector FMAs)
     static const int* const kt64 = knob("E2V_ATTN_KT64", 1);     // 0: 32-key stages (one barrier per 32 keys)
     dim3 grid(attn_grid(a), 1, 1);

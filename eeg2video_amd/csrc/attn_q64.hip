@@ -1,0 +1,359 @@
+// Sparse-causal self-attention on bf16 rows, 64 queries per wave (round 4).
+//
+// Serves SparseCausalAttention (attention.py:272-328) in bf16 mode at the head sizes whose softmax denominator rides in O^T
+// (D % 32 != 0: 40 and 80, the UNet's levels 0 and 1).  Same arithmetic as flash_attn_b16io_kernel<D, true, 64> (attn.hip): S^T = K Q^T
+// with the query on the lane, Q pre-multiplied by scale * log2(e), the running maximum subtracted by the matrix pipe (the score chain
+// starts from an accumulator block that holds -m), a row's maximum moved only when a score tops it by more than 2^8, P^T registers as
+// the B operand of O^T = V^T P^T, the V^T fragment through the transposing LDS read, the denominator as row D of O^T.
+//
+// What is different is who shares what.  flash_attn_b16io_kernel gives a wave 32 queries: every K fragment (ds_read_b128) and every V^T
+// fragment (2 x ds_read_b64_tr_b16) feeds ONE MFMA, and the loop's fixed costs -- staging a 64-key stage through registers, the
+// stage's barrier, loop and address arithmetic -- are paid per 32 queries.  That kernel is bound by what its waves ISSUE (vector ALU
+// busy 0.69, matrix pipe 0.48, 9.1 vector instructions per MFMA at d = 40), so here a wave owns TWO 32-query blocks: a fragment read
+// feeds two MFMAs, staging / barrier / loop instructions per query halve, and the two blocks' chains (scores -> softmax -> PV) are
+// independent, so one block's MFMAs run under the other's softmax inside ONE wave.  Per 32 keys and 32 queries the vector work is
+// now 8 integer max3 (the deferred-maximum test needs no float maximum: a score above the 2^8 threshold is positive, and positive
+// floats order like their bit patterns, so v_max3_i32 on the raw MFMA output finds it without the canonicalising v_max the
+// compiler puts in front of every fmaxf of an MFMA result) + 1 compare + 16 v_exp_f32 + 8 v_cvt_pk_bf16_f32; the cross-half
+// exchange of the maximum happens only inside the (rare) branch that moves a maximum.
+#include "kernels.h"
+#include "prof.h"
+#include "runtime.h"
+
+#include <cstdlib>
+
+namespace e2v {
+
+namespace {
+
+typedef float qf32x16 __attribute__((ext_vector_type(16)));
+typedef float qf32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 qbf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 qbf16x8 __attribute__((ext_vector_type(8)));
+
+// Workgroup -> (query block, head, sample-frame), XCD-aware exactly as attn_block of attn.hip (XCD b & 7 takes whole samples and walks
+// them frame by frame, head by head: the K / V rows of a frame are fetched into ONE L2), for query blocks of QB rows.
+struct Q64Block { int qb, head, sf; bool valid; };
+__device__ __forceinline__ Q64Block q64_block(const AttnArgs& p, const int QB) {
+    const int nqb = (p.Nq + QB - 1) / QB;
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int S = p.n * p.F;
+    Q64Block r;
+    if (p.n >= 8) {
+        const int per = p.F * p.heads * nqb;
+        const int ul = idx / per, w = idx - ul * per;
+        const int smp = ul * 8 + xcd;
+        const int f = w / (p.heads * nqb), w2 = w - f * (p.heads * nqb);
+        r.sf = smp * p.F + f; r.head = w2 / nqb; r.qb = w2 - r.head * nqb; r.valid = smp < p.n;
+    } else {
+        const int per = p.heads * nqb;
+        const int ul = idx / per, w = idx - ul * per;
+        r.sf = ul * 8 + xcd; r.head = w / nqb; r.qb = w - r.head * nqb; r.valid = r.sf < S;
+    }
+    return r;
+}
+inline unsigned q64_grid(const AttnArgs& a, const int QB) {
+    const unsigned nqb = (a.Nq + QB - 1) / QB;
+    if (a.n >= 8) return 8u * ((a.n + 7) / 8) * (unsigned)(a.F * a.heads) * nqb;
+    return 8u * ((a.n * a.F + 7) / 8) * (unsigned)a.heads * nqb;
+}
+
+__device__ __forceinline__ int imax3(const int a, const int b, const int c) { return max(max(a, b), c); }
+
+template <int D>
+struct Q64Layout {
+    static constexpr int DP = (D + 15) / 16 * 16;     // head dim padded to the 16-deep MFMA step
+    static constexpr int KS = DP / 16;
+    static constexpr int T = (D + 31) / 32;           // 32-row tiles of O^T
+    static constexpr int KT = 64;                     // keys per LDS stage
+    static constexpr int KROW = DP * 2 + 16;          // bytes per K row: conflict-free ds_read_b128 of 16 rows
+    static constexpr int VROW = ((T * 16) % 32 == 16) ? T * 64 : T * 64 + 64;       // as in attn.hip: the four rows of a tr read tile the banks
+    static constexpr int KBYTES = KT * KROW, VBYTES = KT * VROW;
+    static constexpr int STAGE = (KBYTES + VBYTES + 15) / 16 * 16;
+};
+
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnArgs p) {
+    static_assert(D % 32 != 0 && D % 8 == 0, "the denominator rides in a spare row of the last O^T tile");
+    static_assert(NW >= 2 && NW <= 4, "");
+    typedef Q64Layout<D> L;
+    constexpr int NT = 64 * NW, QB = 64 * NW;
+    constexpr int KS = L::KS, T = L::T, KT = L::KT, KROW = L::KROW, VROW = L::VROW, KBYTES = L::KBYTES, STAGE = L::STAGE;
+    constexpr int LROW = D % 32, LREG = 4 * (LROW / 8) + (LROW & 3), LHALF = (LROW >> 2) & 1;      // where row D of O^T lives
+    constexpr int C8 = D / 8;                   // 16-byte pieces per row
+    constexpr int NP = KT * C8;
+    constexpr int LPT = (NP + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem_q[];      // [2][K rows | V rows]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const Q64Block blk = q64_block(p, QB);
+    if (!blk.valid) return;
+    const int sf = blk.sf;
+    const int smp = sf / p.F, f = sf - smp * p.F;
+    const int head = blk.head;
+    const int q0 = blk.qb * QB + wave * 64;
+    const bool active = q0 < p.Nq;
+    const __bf16* __restrict__ Q = reinterpret_cast<const __bf16*>(p.q);
+    const __bf16* __restrict__ K = reinterpret_cast<const __bf16*>(p.k);
+    const __bf16* __restrict__ V = reinterpret_cast<const __bf16*>(p.v);
+
+    int nseg = 1;
+    size_t kvbase[2];
+    kvbase[0] = (size_t)(smp * p.F) * p.Nk;
+    kvbase[1] = (size_t)(smp * p.F + (f > 0 ? f - 1 : 0)) * p.Nk;
+    nseg = f >= 2 ? 2 : 1;                      // frames 0 and 1 see [K0; K0]: softmax over a duplicated key set = softmax over the set
+    const int tps = (p.Nk + KT - 1) / KT;
+    const int ntiles = nseg * tps;
+
+    for (int i = tid * 16; i < 2 * STAGE; i += NT * 16)                  // pad columns are never rewritten: keep them finite
+        *reinterpret_cast<qf32x4*>(smem_q + i) = qf32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    if (tid < 2 * KT)                                                     // value column D of every key row, both stages: 1.0
+        *reinterpret_cast<__bf16*>(smem_q + (tid / KT) * STAGE + KBYTES + (tid % KT) * VROW + D * 2) = (__bf16)1.0f;
+
+    qbf16x8 qf[2][KS];
+    {
+        const float qs = p.scale * 1.44269504088896340736f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int qrow = min(q0 + 32 * b + j, p.Nq - 1);
+            const __bf16* qp = Q + ((size_t)sf * p.Nq + qrow) * p.ldq + head * D;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int k0 = 16 * s + 8 * h;
+                qbf16x8 a;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = (__bf16)0.f;
+                if (k0 < D) a = *reinterpret_cast<const qbf16x8*>(qp + k0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = (__bf16)((float)a[e] * qs);
+                qf[b][s] = a;
+            }
+        }
+    }
+    __syncthreads();
+
+    constexpr unsigned OOB = 0x80000000u;
+    auto rsrc_of = [](const void* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, 0x7FFFFFF0,
+                                                 0x00020000);
+    };
+    int ld_row[LPT], ld_c8[LPT];
+    unsigned ld_off[LPT];
+#pragma unroll
+    for (int e = 0; e < LPT; ++e) {
+        const int idx = tid + NT * e;
+        const int row = idx / C8, c8 = idx - row * C8;
+        ld_row[e] = row; ld_c8[e] = c8;
+        ld_off[e] = idx < NP ? (unsigned)(row * p.ldkv + c8 * 8) * 2u : OOB;
+    }
+    qf32x4 kreg[LPT], vreg[LPT];
+    auto load_tile = [&](const int seg, const int key0) {
+        const size_t first = (kvbase[seg] + key0) * p.ldkv + head * D;
+        const __amdgpu_buffer_rsrc_t rk = rsrc_of(K + first), rv = rsrc_of(V + first);
+        const int left = p.Nk - key0;                           // keys this tile really has (uniform)
+#pragma unroll
+        for (int e = 0; e < LPT; ++e) {
+            unsigned off = ld_off[e];
+            if (left < KT) off = ld_row[e] < left ? off : OOB;  // ragged last tile of a segment only
+            kreg[e] = __builtin_bit_cast(qf32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
+            vreg[e] = __builtin_bit_cast(qf32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* Kl = smem_q + buf * STAGE;
+        char* Vl = Kl + KBYTES;
+#pragma unroll
+        for (int e = 0; e < LPT; ++e) {
+            if (tid + NT * e < NP) {
+                *reinterpret_cast<qf32x4*>(Kl + ld_row[e] * KROW + ld_c8[e] * 16) = kreg[e];
+                *reinterpret_cast<qf32x4*>(Vl + ld_row[e] * VROW + ld_c8[e] * 16) = vreg[e];
+            }
+        }
+    };
+
+    qf32x16 acc[2][T];
+    qf32x16 negm[2];                              // -(reference maximum) of the lane's query, in every register of the block
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][t][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[b][r] = 0.f;
+    }
+
+    load_tile(0, 0);
+    store_tile(0);
+    __syncthreads();
+
+    // transposing read of the V^T fragment (as in attn.hip): 16-lane group g = lane >> 4 covers value columns 16 (g & 1) .. + 15 of the
+    // tile and keys 4 (g >> 1) .. + 3 of each 8-key half of the k-step; lane 4 q + p of the group supplies row q, columns 4 p ..
+    const int ti = lane & 15;
+    const int tr_off = (4 * h + (ti >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (ti & 3)) * 2;
+    typedef __attribute__((address_space(3))) qbf16x4* lds_b4;
+    constexpr int THRESH_BITS = 0x41000000;        // 8.0f: positive floats compare like their bit patterns
+
+    int key0 = 0;
+    for (int tt = 0; tt < ntiles; ++tt) {
+        const int buf = tt & 1;
+        if (tt == tps) key0 = 0;                                  // second key segment
+        if (tt + 1 < ntiles) {
+            if (tt + 1 == tps) load_tile(1, 0); else load_tile(tt + 1 > tps ? 1 : 0, key0 + KT);
+        }
+#pragma unroll
+        for (int sub = 0; sub < KT / 32; ++sub) {
+            const int keyb = key0 + 32 * sub;                       // first key of this 32-key block
+            if (active && keyb < p.Nk) {
+                const char* Kl = smem_q + buf * STAGE + sub * 32 * KROW;
+                const char* Vl = smem_q + buf * STAGE + KBYTES + sub * 32 * VROW;
+                const bool first = tt == 0 && sub == 0;
+                const char* kp = Kl + j * KROW + h * 16;
+                qbf16x8 kf[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const qbf16x8*>(kp + s * 32);
+                qf32x16 st[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int s = 0; s < KS; ++s)
+                        st[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[b][s], s == 0 ? negm[b] : st[b], 0, 0, 0);
+                if (keyb + 32 > p.Nk) {
+                    asm volatile("" ::: "memory");              // (ragged last tile of a segment: a branch, not 32 selects on every tile)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = keyb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (key >= p.Nk) { st[0][r] = -INFINITY; st[1][r] = -INFINITY; }
+                    }
+                }
+                qbf16x8 vf[T][2];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const char* vb = Vl + tr_off + t * 64;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const qbf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s) * VROW));       // keys 16s + 4h + 0..3
+                        const qbf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s + 8) * VROW));   // keys 16s + 8 + 4h + 0..3
+                        vf[t][s] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    // st = scaled score - reference maximum.  The maximum moves only when some score of the wave tops its row's by more than
+                    // 2^8 (deferred maximum, attn.hip) -- such a score is positive, and positive floats order like their bit patterns:
+                    int mi = imax3(__float_as_int(st[b][0]), __float_as_int(st[b][1]), __float_as_int(st[b][2]));
+#pragma unroll
+                    for (int r = 3; r < 15; r += 2) mi = imax3(mi, __float_as_int(st[b][r]), __float_as_int(st[b][r + 1]));
+                    mi = max(mi, __float_as_int(st[b][15]));
+                    if (first || __any(mi > THRESH_BITS)) {
+                        asm volatile("" ::: "memory");          // (rare after the first tile)
+                        float mt = st[b][0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) mt = __builtin_fmaxf(mt, st[b][r]);
+                        {
+                            // the other half-wave holds the other 16 keys of the same query (v_permlane32_swap: lanes 32-63 of a <-> lanes
+                            // 0-31 of b; inline asm, the builtin drops its second result in ROCm 7.2; the wait states are inside the string)
+                            float a = mt, c = mt;
+                            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(c));
+                            mt = __builtin_fmaxf(a, c);
+                        }
+                        constexpr float DEFER = 8.0f;
+                        // first tile: the row takes the tile's true maximum whatever its sign (nothing accumulated yet, alpha unused)
+                        const float d = first ? mt : (mt > DEFER ? mt : 0.f);
+                        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { st[b][r] -= d; negm[b][r] -= d; }
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[b][t][r] *= alpha;
+                    }
+                    qbf16x8 pf[2];                       // P^T fragments: registers 8s..8s+7 are k-step s as they stand
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pf[s][e] = (__bf16)__builtin_amdgcn_exp2f(st[b][8 * s + e]);
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][s], pf[s], acc[b][t], 0, 0, 0);
+                }
+            }
+        }
+        if (tt + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+        key0 += KT;
+    }
+
+    if (active) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float l_tot = __shfl(acc[b][T - 1][LREG], j + 32 * LHALF);     // row D of O^T: lane (query j, half LHALF)
+            const int qrow = q0 + 32 * b + j;
+            if (qrow < p.Nq) {
+                const float inv = 1.0f / l_tot;
+                __bf16* op = reinterpret_cast<__bf16*>(p.o) + ((size_t)sf * p.Nq + qrow) * p.ldo + head * D;
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int dv = t * 32 + 8 * rg + 4 * h;
+                        if (dv < D) {
+                            qbf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[b][t][rg * 4 + e] * inv);
+                            *reinterpret_cast<qbf16x4*>(op + dv) = o;
+                        }
+                    }
+            }
+        }
+    }
+}
+
+template <int D, int NW>
+void launch_q64(const AttnArgs& a, hipStream_t s) {
+    typedef Q64Layout<D> L;
+    static bool configured = false;
+    constexpr size_t smem = 2 * (size_t)L::STAGE;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_b16q64_kernel<D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        configured = true;
+    }
+    hipLaunchKernelGGL((flash_attn_b16q64_kernel<D, NW>), dim3(q64_grid(a, 64 * NW)), dim3(64 * NW), smem, s, a);
+}
+
+}  // namespace
+
+// Which (if any) instance of the 64-queries-per-wave kernel serves the call: waves per workgroup, 0 = none (the caller falls back to
+// flash_attn_b16io_kernel).  A rule of the SHAPE only (never of the batch: the two kernels round differently, and a clip's bits must
+// not depend on how many clips run together).
+int flash_attention_q64_waves(const AttnArgs& a) {
+    // 0: every bf16 self-attention through flash_attn_b16io_kernel; 1: d = 40 here; 2: d = 80 as well (287+ registers: one wave per SIMD)
+    static const int* const on = knob("E2V_ATTN_Q64", 1);
+    if (!*on || !a.io_bf16 || a.mode != 0 || !(a.D == 40 || (a.D == 80 && *on >= 2)) || a.Nk <= 32) return 0;
+    if (a.Nq < 128) return 0;
+    int best = 0, waste = 1 << 30;
+    for (int nw = 4; nw >= 2; --nw) {                              // least padding of the last query block; ties: the larger workgroup
+        const int qb = 64 * nw, w = (a.Nq + qb - 1) / qb * qb - a.Nq;
+        if (w < waste) { waste = w; best = nw; }
+    }
+    return best;
+}
+
+bool flash_attention_q64(const AttnArgs& a, hipStream_t s) {
+    const int nw = flash_attention_q64_waves(a);
+    if (!nw) return false;
+    const double probs = (double)a.n * a.F * a.heads;
+    ProfScope ps("flash_attn_bf16_sparse_causal", 4.0 * probs * a.Nq * 2.0 * a.Nk * a.D, 2.0 * probs * a.D * (2.0 * a.Nq + 2.0 * a.Nk), s);
+    if (a.D == 40) { if (nw == 4) launch_q64<40, 4>(a, s); else if (nw == 3) launch_q64<40, 3>(a, s); else launch_q64<40, 2>(a, s); }
+    else           { if (nw == 4) launch_q64<80, 4>(a, s); else if (nw == 3) launch_q64<80, 3>(a, s); else launch_q64<80, 2>(a, s); }
+    return true;
+}
+
+}  // namespace e2v

@@ -147,6 +147,10 @@ struct AttnArgs {
 };
 void flash_attention(const AttnArgs& a, hipStream_t s);      // throws Error(E2V_EINVAL) for a head dim without a kernel instance
 bool flash_attention_supports(int D);
+// attn_q64.hip: bf16 sparse-causal attention with 64 queries per wave (head dims 40 / 80).  _waves: waves per workgroup of the instance
+// that would serve the call, 0 = not served (flash_attention falls back to flash_attn_b16io_kernel); the second launches it.
+int flash_attention_q64_waves(const AttnArgs& a);
+bool flash_attention_q64(const AttnArgs& a, hipStream_t s);
 // temporal self-attention over the F frames of every pixel (attention.py:261-267), qkv = [n*F*HW][3C]
 void temporal_attention(const float* qkv, int ld, float* out, int ldo, int n, int F, int HW, int heads, int D,
                         float scale, hipStream_t s, int bf16 = 0);          // bf16: qkv / out are bf16 rows
