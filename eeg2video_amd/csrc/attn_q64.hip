@@ -21,6 +21,7 @@
 #include "runtime.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace e2v {
 
@@ -316,6 +317,305 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnAr
     }
 }
 
+
+// ---- software-pipelined form (d = 40) -------------------------------------------------------------------------------------------
+// The kernel above still runs as phases -- a wave issues the score MFMAs of a key tile, WAITS for them, runs that tile's softmax on the
+// vector ALU, then the PV MFMAs -- and leaves it to the second wave of the SIMD to fill the other pipe (measured: 884 TFLOP/s
+// algorithmic at level 0 against an issue bound of ~1500).  Here a wave never waits for its own MFMAs: in iteration i the scores of key
+// tile i + 1 (both query blocks: 6 MFMAs) are issued first and the vector ALU exponentiates tile i (whose scores the previous iteration
+// produced) underneath them, then the PV MFMAs of tile i run while the maximum test of tile i + 1 and the K fragment reads of tile
+// i + 2 issue.  One basic block per iteration: the ragged last key tile of a segment is a separate instance of the body, and moving a
+// row's maximum is ONE rarely taken branch at the end of the iteration that repairs the already computed scores of tile i + 1.
+//   * The running maximum rides in Q: d = 40 pads the third 16-deep k-step of K Q^T to 48, so column 40 of every K row in LDS holds
+//     1.0 and slot 40 of a query's Q fragment holds -m: the MFMAs that compute the scores subtract the maximum, the 2 x 16 registers
+//     of the -m accumulator block of the form above are gone.  m must be a bf16 number for that; a softmax may take ANY reference, so
+//     the reference is the row maximum rounded to bf16 (the same P and the same denominator see it).
+//   * Three LDS stages of 64 keys: during stage s the waves read V of stage s, K of stage s + 1 (scores run one tile ahead) and, at
+//     its end, write stage s + 2 -- one barrier per 64 keys.
+//   * P is bounded as before: a reference moves when a score tops it by more than 2^8.
+template <int NW, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void flash_attn_b16q64p_kernel(const AttnArgs p) {
+    constexpr int D = 40;
+    typedef Q64Layout<D> L;
+    static_assert(L::DP > D, "the maximum rides in a spare k slot");
+    constexpr int NT = 64 * NW, QB = 64 * NW, NBUF = 3;
+    constexpr int KS = L::KS, T = L::T, KT = L::KT, KROW = L::KROW, VROW = L::VROW, KBYTES = L::KBYTES, STAGE = L::STAGE;
+    constexpr int LROW = D % 32, LREG = 4 * (LROW / 8) + (LROW & 3), LHALF = (LROW >> 2) & 1;      // where row D of O^T lives
+    constexpr int C8 = D / 8;
+    constexpr int NP = KT * C8;
+    constexpr int LPT = (NP + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem_q[];      // [3][K rows | V rows]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const Q64Block blk = q64_block(p, QB);
+    if (!blk.valid) return;
+    const int sf = blk.sf;
+    const int smp = sf / p.F, f = sf - smp * p.F;
+    const int head = blk.head;
+    const int q0 = blk.qb * QB + wave * 64;
+    const bool active = q0 < p.Nq;
+    const __bf16* __restrict__ Q = reinterpret_cast<const __bf16*>(p.q);
+    const __bf16* __restrict__ K = reinterpret_cast<const __bf16*>(p.k);
+    const __bf16* __restrict__ V = reinterpret_cast<const __bf16*>(p.v);
+
+    size_t kvbase[2];
+    kvbase[0] = (size_t)(smp * p.F) * p.Nk;
+    kvbase[1] = (size_t)(smp * p.F + (f > 0 ? f - 1 : 0)) * p.Nk;
+    const int nseg = f >= 2 ? 2 : 1;            // frames 0 and 1 see [K0; K0]: softmax over a duplicated key set = softmax over the set
+    const int tps = (p.Nk + KT - 1) / KT;
+    const int NS = nseg * tps;                  // stages of 64 keys
+
+    for (int i = tid * 16; i < NBUF * STAGE; i += NT * 16)               // pad columns are never rewritten: keep them finite
+        *reinterpret_cast<qf32x4*>(smem_q + i) = qf32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int i = tid; i < NBUF * KT; i += NT) {
+        char* st = smem_q + (i / KT) * STAGE;
+        *reinterpret_cast<__bf16*>(st + KBYTES + (i % KT) * VROW + D * 2) = (__bf16)1.0f;      // V column D: row D of O^T = the denominator
+    }
+
+    qbf16x8 qf[2][KS];
+    {
+        const float qs = p.scale * 1.44269504088896340736f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int qrow = min(q0 + 32 * b + j, p.Nq - 1);
+            const __bf16* qp = Q + ((size_t)sf * p.Nq + qrow) * p.ldq + head * D;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int k0 = 16 * s + 8 * h;
+                qbf16x8 a;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = (__bf16)0.f;
+                if (k0 < D) a = *reinterpret_cast<const qbf16x8*>(qp + k0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = (__bf16)((float)a[e] * qs);
+                qf[b][s] = a;
+            }
+            if (h) qf[b][KS - 1][1] = (__bf16)-32768.0f;            // slot D + 1: times the marker column of a key past its segment's end
+        }
+    }
+
+    constexpr unsigned OOB = 0x80000000u;
+    auto rsrc_of = [](const void* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, 0x7FFFFFF0,
+                                                 0x00020000);
+    };
+    int ld_row[LPT], ld_c8[LPT];
+    unsigned ld_off[LPT];
+#pragma unroll
+    for (int e = 0; e < LPT; ++e) {
+        const int idx = tid + NT * e;
+        const int row = idx / C8, c8 = idx - row * C8;
+        ld_row[e] = row; ld_c8[e] = c8;
+        ld_off[e] = idx < NP ? (unsigned)(row * p.ldkv + c8 * 8) * 2u : OOB;
+    }
+    qf32x4 kreg[LPT], vreg[LPT];
+    auto load_stage = [&](const int s) {                        // stage s of the key list -> staging registers
+        const int seg = s >= tps ? 1 : 0;
+        const int key0 = (s - seg * tps) * KT;
+        const size_t first = (kvbase[seg] + key0) * p.ldkv + head * D;
+        const __amdgpu_buffer_rsrc_t rk = rsrc_of(K + first), rv = rsrc_of(V + first);
+        const int left = p.Nk - key0;                           // keys this stage really has (uniform)
+#pragma unroll
+        for (int e = 0; e < LPT; ++e) {
+            unsigned off = ld_off[e];
+            if (left < KT) off = ld_row[e] < left ? off : OOB;  // ragged last stage of a segment only: zero rows
+            kreg[e] = __builtin_bit_cast(qf32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
+            vreg[e] = __builtin_bit_cast(qf32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
+        }
+    };
+    // Keys past the end of a segment (its ragged last stage) are masked by the MATRIX pipe as well: column D + 1 of their K rows holds
+    // 1.0 (0 in every real key's row) and slot D + 1 of every query's Q fragment holds -2^15, so their scores come out of the MFMA
+    // near -32768 and exponentiate to zero -- no select in the loop, no second instance of its body.  The thread that stores the
+    // first piece of a K row rewrites the row's two marker columns with every stage (the ring reuses the buffer).
+    auto store_stage = [&](const int buf, const int left) {     // left: valid keys from the stage's first on
+        char* Kl = smem_q + buf * STAGE;
+        char* Vl = Kl + KBYTES;
+#pragma unroll
+        for (int e = 0; e < LPT; ++e) {
+            if (tid + NT * e < NP) {
+                *reinterpret_cast<qf32x4*>(Kl + ld_row[e] * KROW + ld_c8[e] * 16) = kreg[e];
+                *reinterpret_cast<qf32x4*>(Vl + ld_row[e] * VROW + ld_c8[e] * 16) = vreg[e];
+                if (ld_c8[e] == 0) *reinterpret_cast<unsigned*>(Kl + ld_row[e] * KROW + D * 2) = ld_row[e] < left ? 0x00003F80u : 0x3F803F80u;
+            }
+        }
+    };
+    auto stage_keys = [&](const int s) { return p.Nk - (s - (s >= tps ? tps : 0)) * KT; };      // valid keys from the stage's first on
+
+    qf32x16 acc[2][T];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][t][r] = 0.f;
+    float mref[2] = {0.f, 0.f};                   // the reference maximum of the lane's query (a bf16 number)
+
+    load_stage(0);
+    store_stage(0, stage_keys(0));
+    if (NS > 1) { load_stage(1); store_stage(1, stage_keys(1)); }
+    __syncthreads();
+
+    const int ti = lane & 15;
+    const int k_off = j * KROW + h * 16;                                              // K fragment: key row j, columns 16 s + 8 h ..
+    const int v_off = KBYTES + (4 * h + (ti >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (ti & 3)) * 2;      // V^T fragment (tr read), as above
+    typedef __attribute__((address_space(3))) qbf16x4* lds_b4;
+    constexpr int THRESH_BITS = 0x41000000;        // 8.0f
+    const qf32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    qbf16x8 kf[KS];
+    auto read_k = [&](const int buf, const int sub) {
+        const char* kp = smem_q + buf * STAGE + sub * 32 * KROW + k_off;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const qbf16x8*>(kp + s * 32);
+    };
+    auto scores = [&](qf32x16 (&S)[2]) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) S[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[b][s], s == 0 ? zero16 : S[b], 0, 0, 0);
+    };
+    // Move the reference maxima of the rows whose new scores S (computed against the old references) top them by more than 2^8
+    // (FIRST: take the tile's maximum whatever it is): new reference = a bf16 number, S and the accumulators follow, -m goes into Q.
+    auto move_maximum = [&](qf32x16 (&S)[2], const bool first) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float mt = S[b][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mt = __builtin_fmaxf(mt, S[b][r]);
+            {
+                float a = mt, c = mt;       // the other half-wave holds the other 16 keys of the same query
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(c));
+                mt = __builtin_fmaxf(a, c);
+            }
+            constexpr float DEFER = 8.0f;
+            const float d = first ? mt : (mt > DEFER ? mt : 0.f);
+            const float mnew = (float)(__bf16)(mref[b] + d);
+            const float delta = mnew - mref[b];
+            mref[b] = mnew;
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[b][r] -= delta;
+            if (!first) {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[b][t][r] *= alpha;
+            }
+            const __bf16 slot = (__bf16)(-mnew);
+            qf[b][KS - 1][0] = h ? slot : qf[b][KS - 1][0];      // k = D lives in the upper half-wave's fragment of the last k-step
+        }
+    };
+    // One iteration: scores of the NEXT tile into Sn (from the K fragment registers), softmax numerators and PV of THIS tile (scores
+    // Sc, V rows at vl), then the K fragments of the tile after next.
+    auto iteration = [&](qf32x16 (&Sc)[2], qf32x16 (&Sn)[2], const char* vl, const int kbuf, const int ksub, const bool has_next) {
+        qbf16x8 vf[T][2];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const char* vb = vl + t * 64;
+                const qbf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s) * VROW));       // keys 16s + 4h + 0..3
+                const qbf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s + 8) * VROW));   // keys 16s + 8 + 4h + 0..3
+                vf[t][s] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        scores(Sn);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            qbf16x8 pf[2];                       // P^T fragments: registers 8s..8s+7 are k-step s as they stand
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[s][e] = (__bf16)__builtin_amdgcn_exp2f(Sc[b][8 * s + e]);
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][s], pf[s], acc[b][t], 0, 0, 0);
+        }
+        read_k(kbuf, ksub);
+        int mi = imax3(__float_as_int(Sn[0][0]), __float_as_int(Sn[0][1]), __float_as_int(Sn[0][2]));
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mi = imax3(mi, __float_as_int(Sn[0][r]), __float_as_int(Sn[0][r + 1]));
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mi = imax3(mi, __float_as_int(Sn[1][r]), __float_as_int(Sn[1][r + 1]));
+        mi = max(mi, __float_as_int(Sn[0][15]));
+        const bool tops = __any(mi > THRESH_BITS);
+        if (tops & has_next) {
+            asm volatile("" ::: "memory");          // (rare: keep it a branch)
+            move_maximum(Sn, false);
+        }
+    };
+
+    if (active) {                                   // scores of tile 0, its maxima = the first references
+        qf32x16 S0[2], S1[2];
+        read_k(0, 0);
+        scores(S0);
+        move_maximum(S0, true);
+        read_k(0, 1);
+        int b0 = 0;                                 // buffer of stage s
+        for (int s = 0; s < NS; ++s) {
+            if (s + 2 < NS) load_stage(s + 2);
+            const int b1 = b0 == NBUF - 1 ? 0 : b0 + 1, b2 = b1 == NBUF - 1 ? 0 : b1 + 1;
+            const char* vl = smem_q + b0 * STAGE + v_off;
+            iteration(S0, S1, vl, b1, 0, true);
+            iteration(S1, S0, vl + 32 * VROW, b1, 1, s + 1 < NS);
+            if (s + 2 < NS) store_stage(b2, stage_keys(s + 2));
+            __syncthreads();
+            b0 = b1;
+        }
+    } else {                                        // a wave without queries only stages
+        int b0 = 0;
+        for (int s = 0; s < NS; ++s) {
+            if (s + 2 < NS) load_stage(s + 2);
+            const int b1 = b0 == NBUF - 1 ? 0 : b0 + 1, b2 = b1 == NBUF - 1 ? 0 : b1 + 1;
+            if (s + 2 < NS) store_stage(b2, stage_keys(s + 2));
+            __syncthreads();
+            b0 = b1;
+        }
+    }
+
+    if (active) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float l_tot = __shfl(acc[b][T - 1][LREG], j + 32 * LHALF);     // row D of O^T: lane (query j, half LHALF)
+            const int qrow = q0 + 32 * b + j;
+            if (qrow < p.Nq) {
+                const float inv = 1.0f / l_tot;
+                __bf16* op = reinterpret_cast<__bf16*>(p.o) + ((size_t)sf * p.Nq + qrow) * p.ldo + head * D;
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int dv = t * 32 + 8 * rg + 4 * h;
+                        if (dv < D) {
+                            qbf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[b][t][rg * 4 + e] * inv);
+                            *reinterpret_cast<qbf16x4*>(op + dv) = o;
+                        }
+                    }
+            }
+        }
+    }
+}
+
+template <int NW, int WPE>
+void launch_q64p(const AttnArgs& a, hipStream_t s) {
+    typedef Q64Layout<40> L;
+    static bool configured = false;
+    constexpr size_t smem = 3 * (size_t)L::STAGE;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_b16q64p_kernel<NW, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        configured = true;
+    }
+    hipLaunchKernelGGL((flash_attn_b16q64p_kernel<NW, WPE>), dim3(q64_grid(a, 64 * NW)), dim3(64 * NW), smem, s, a);
+}
+
 template <int D, int NW>
 void launch_q64(const AttnArgs& a, hipStream_t s) {
     typedef Q64Layout<D> L;
@@ -351,7 +651,10 @@ bool flash_attention_q64(const AttnArgs& a, hipStream_t s) {
     if (!nw) return false;
     const double probs = (double)a.n * a.F * a.heads;
     ProfScope ps("flash_attn_bf16_sparse_causal", 4.0 * probs * a.Nq * 2.0 * a.Nk * a.D, 2.0 * probs * a.D * (2.0 * a.Nq + 2.0 * a.Nk), s);
-    if (a.D == 40) { if (nw == 4) launch_q64<40, 4>(a, s); else if (nw == 3) launch_q64<40, 3>(a, s); else launch_q64<40, 2>(a, s); }
+    static const int* const pipelined = knob("E2V_ATTN_Q64P", 1);      // 0: the phase-by-phase form of the 64-query kernel
+    if (a.D == 40 && *pipelined == 2) { if (nw == 4) launch_q64p<4, 1>(a, s); else if (nw == 3) launch_q64p<3, 1>(a, s); else launch_q64p<2, 1>(a, s); }
+    else if (a.D == 40 && *pipelined) { if (nw == 4) launch_q64p<4, 2>(a, s); else if (nw == 3) launch_q64p<3, 2>(a, s); else launch_q64p<2, 2>(a, s); }
+    else if (a.D == 40) { if (nw == 4) launch_q64<40, 4>(a, s); else if (nw == 3) launch_q64<40, 3>(a, s); else launch_q64<40, 2>(a, s); }
     else           { if (nw == 4) launch_q64<80, 4>(a, s); else if (nw == 3) launch_q64<80, 3>(a, s); else launch_q64<80, 2>(a, s); }
     return true;
 }

@@ -693,6 +693,44 @@ def test_bf16_upsample_conv_sub_pixel_form(bf256, n, c, cout, hs, ws):
     close(y, y0, rtol=4e-3, atol=4e-3)
 
 
+@pytest.mark.parametrize("d,nq,f,n", [(40, 256, 3, 1), (40, 333, 4, 9), (40, 192, 2, 2), (40, 130, 3, 1), (40, 2304, 2, 1)])
+def test_bf16_attention_64_queries_per_wave(eng, d, nq, f, n):
+    """flash_attn_b16q64_kernel (attn_q64.hip; SparseCausalAttention, attention.py:272-328): a wave owns two 32-query blocks.  Whole
+    workgroups of 4 / 3 / 2 waves (256 / 192 / 128 queries), a ragged last query block (333, 130: a wave whose second block is empty, a
+    wave with no query at all), a ragged last key tile, >= 8 samples (whole samples per XCD) and fewer, frames 0 / 1 (one key segment) and
+    later ones (two), and the UNet's level-0 size.  Against the fp32 reference on the operands as the kernel rounds them (Q pre-multiplied
+    by scale * log2 e and rounded to bf16 once), and bit for bit against the 32-query kernel (the integer test for "some score tops its
+    row's maximum by 2^8" decides as the float maximum does)."""
+    heads = 8
+    c = heads * d
+    qkv = rnd(n * f * nq, 3 * c, seed=280)
+    qs = d ** -0.5 * 1.4426950408889634
+    q = (rb(rb(qkv[:, :c]) * qs) / qs).reshape(n * f, nq, c)
+    k, v = (rb(qkv[:, i * c:(i + 1) * c]).reshape(n * f, nq, c) for i in (1, 2))
+    former = torch.arange(f) - 1
+    former[0] = 0
+    gather = lambda t: torch.cat([t.reshape(n, f, nq, c)[:, [0] * f], t.reshape(n, f, nq, c)[:, former]], dim=2).reshape(n * f, 2 * nq, c)
+    ref = _unheads(_ref_attn(_heads(q, heads), _heads(gather(k), heads), _heads(gather(v), heads), d ** -0.5), heads)
+    try:
+        eng.set_compute_dtype("bf16")
+        g = qkv.cuda()
+        run = lambda: eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5)
+        y = run()                                         # the software-pipelined form (the default at d = 40)
+        eng.set_knob("E2V_ATTN_Q64P", 0)
+        yp = run()                                        # the phase-by-phase form
+        eng.set_knob("E2V_ATTN_Q64", 0)
+        y32 = run()
+    finally:
+        eng.set_knob("E2V_ATTN_Q64", 1); eng.set_knob("E2V_ATTN_Q64P", 1)
+        eng.set_compute_dtype("fp32")
+    # phase form: same MFMA sequence per (query, key tile) and the same maximum decisions per 32-query block as the 32-query kernel
+    assert torch.equal(yp, y32)
+    # pipelined form: the reference maximum is a bf16 number carried in Q, so P rounds differently: same softmax, other roundings
+    assert not torch.equal(y, y32)
+    close(y.reshape(n * f, nq, c), ref, rtol=1e-2, atol=1e-2)            # bf16 rounding of P and of the output
+    close(yp.reshape(n * f, nq, c), ref, rtol=1e-2, atol=1e-2)
+
+
 @pytest.mark.parametrize("boost", [3.0, 25.0])
 def test_bf16_attention_deferred_maximum_branches(eng, boost):
     """bf16 attention keeps a row's reference maximum until a score exceeds it by more than 2^8 (the rescale of the accumulators is
@@ -715,11 +753,15 @@ def test_bf16_attention_deferred_maximum_branches(eng, boost):
         eng.set_compute_dtype("bf16")
         g = qkv.cuda()
         outs = []
-        for fold in (1, 0):
+        for q64, q64p, fold in ((1, 1, 1), (1, 0, 1), (0, 0, 1), (0, 0, 0)):   # 64 queries per wave (attn_q64.hip: pipelined, phase form), then the 32-query kernel's two forms
+            eng.set_knob("E2V_ATTN_Q64", q64)
+            eng.set_knob("E2V_ATTN_Q64P", q64p)
             eng.set_knob("E2V_ATTN_FOLD", fold)
             outs.append(eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5))
     finally:
         eng.set_knob("E2V_ATTN_FOLD", 1)
+        eng.set_knob("E2V_ATTN_Q64", 1); eng.set_knob("E2V_ATTN_Q64P", 1)
         eng.set_compute_dtype("fp32")
+    assert torch.equal(outs[1], outs[2])                     # both sides of the threshold: the phase form and the 32-query kernel decide and round alike
     for y in outs:
         close(y.reshape(n * f, nq, c), ref, rtol=2e-2, atol=2e-2)

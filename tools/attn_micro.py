@@ -1,5 +1,6 @@
 """Micro-benchmark of the sparse-causal attention kernel at the UNet's level-0..2 shapes: fp32 (B = 8 -> 16 samples) and bf16 rows
-(B = 32 -> 64 samples), HIP-event kernel time; the bf16 variants (E2V_ATTN_FOLD, E2V_ATTN_KT64) A/B'd in one process, interleaved."""
+(B = 32 -> 64 samples), HIP-event kernel time; the bf16 variants (E2V_ATTN_Q64: 64 queries per wave, 2 = also at d = 80; E2V_ATTN_FOLD,
+E2V_ATTN_KT64 with OLD_VARIANTS=1) A/B'd in one process, interleaved."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,5 +28,8 @@ def run(mode, n, variants):
         alg = 4.0 * n * f * heads * nq * (2 * nq) * d
         print(f"{mode} {name} n={n}: " + "  ".join(f"[{v or 'default'}] {best[v]:.3f} ms {alg/best[v]/1e9:.0f} TF" for v in variants))
 run("fp32", 16, [""])
-run("bf16", 64, ["E2V_ATTN_FOLD=0,E2V_ATTN_KT64=0", "E2V_ATTN_FOLD=1,E2V_ATTN_KT64=0", "E2V_ATTN_FOLD=0,E2V_ATTN_KT64=1", "E2V_ATTN_FOLD=1,E2V_ATTN_KT64=1"])
+if os.environ.get("OLD_VARIANTS"):
+    run("bf16", 64, ["E2V_ATTN_Q64=0,E2V_ATTN_FOLD=0,E2V_ATTN_KT64=0", "E2V_ATTN_Q64=0,E2V_ATTN_FOLD=1,E2V_ATTN_KT64=0", "E2V_ATTN_Q64=0,E2V_ATTN_FOLD=0,E2V_ATTN_KT64=1"])
+run("bf16", 64, ["E2V_ATTN_Q64=0,E2V_ATTN_FOLD=1,E2V_ATTN_KT64=1", "E2V_ATTN_Q64=1,E2V_ATTN_Q64P=0", "E2V_ATTN_Q64=1,E2V_ATTN_Q64P=1"])
+eng.set_knob("E2V_ATTN_Q64", 1); eng.set_knob("E2V_ATTN_Q64P", 1)
 eng.set_compute_dtype("fp32")
