@@ -363,6 +363,32 @@ e2v_status e2v_unet_forward(e2v_ctx* c, const float* sample, const int64_t* host
     });
 }
 
+// Test aid (eeg2video_hip_ops.h): the forward above with the block outputs the oracle exposes copied out on the way.
+e2v_status e2v_op_unet_forward_taps(e2v_ctx* c, const float* sample, const int64_t* host_t, int n_t, const float* cond, int N,
+                                    int F, int H, int W, int T, float* out, float* taps, int64_t taps_cap, int64_t* shapes,
+                                    int* n_taps, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(sample && host_t && cond && out && taps && shapes && n_taps, E2V_EINVAL, "null argument");
+        E2V_REQUIRE(N > 0 && F > 0 && H > 0 && W > 0 && T > 0 && taps_cap > 0, E2V_ESHAPE, "non-positive dimension");
+        hipStream_t s = S(c, stream);
+        const int Cin = c->cfg.in_channels, Cout = c->cfg.out_channels;
+        const int FHW = F * H * W;
+        e2v_ctx::TapSink sink;
+        sink.buf = taps; sink.cap = taps_cap;
+        struct Guard { e2v_ctx* c; ~Guard() { c->tap_sink = nullptr; } } guard{c};
+        c->tap_sink = &sink;
+        Act x(c->pool, (int64_t)N * FHW, Cin);
+        ncfhw_to_cl(sample, x.p, N, Cin, Cin, FHW, 1.0f, s);
+        Act y = c->unet_forward_cl(x.p, host_t, n_t, cond, N, F, H, W, T, s);
+        cl_to_ncfhw(y.p, Cout, out, N, Cout, FHW, 1.0f, 0.0f, 0, 0.f, 0.f, s);
+        E2V_HIP(hipGetLastError());
+        *n_taps = sink.count;
+        for (int i = 0; i < sink.count; ++i)
+            for (int k = 0; k < 5; ++k) shapes[5 * i + k] = sink.shapes[i][k];
+    });
+}
+
 e2v_status e2v_unet_forward_ft(e2v_ctx* c, const float* sample, const float* host_t, int n_t, const float* cond, int N,
                                int F, int H, int W, int T, float* out, e2v_stream stream) {
     if (!c) return E2V_EINVAL;

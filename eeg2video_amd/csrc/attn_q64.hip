@@ -25,8 +25,6 @@
 
 namespace e2v {
 
-namespace {
-
 typedef float qf32x16 __attribute__((ext_vector_type(16)));
 typedef float qf32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 qbf16x4 __attribute__((ext_vector_type(4)));
@@ -53,7 +51,7 @@ __device__ __forceinline__ Q64Block q64_block(const AttnArgs& p, const int QB) {
     }
     return r;
 }
-inline unsigned q64_grid(const AttnArgs& a, const int QB) {
+static inline unsigned q64_grid(const AttnArgs& a, const int QB) {
     const unsigned nqb = (a.Nq + QB - 1) / QB;
     if (a.n >= 8) return 8u * ((a.n + 7) / 8) * (unsigned)(a.F * a.heads) * nqb;
     return 8u * ((a.n * a.F + 7) / 8) * (unsigned)a.heads * nqb;
@@ -605,7 +603,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 }
 
 template <int NW, int WPE>
-void launch_q64p(const AttnArgs& a, hipStream_t s) {
+static void launch_q64p(const AttnArgs& a, hipStream_t s) {
     typedef Q64Layout<40> L;
     static bool configured = false;
     constexpr size_t smem = 3 * (size_t)L::STAGE;
@@ -617,7 +615,7 @@ void launch_q64p(const AttnArgs& a, hipStream_t s) {
 }
 
 template <int D, int NW>
-void launch_q64(const AttnArgs& a, hipStream_t s) {
+static void launch_q64(const AttnArgs& a, hipStream_t s) {
     typedef Q64Layout<D> L;
     static bool configured = false;
     constexpr size_t smem = 2 * (size_t)L::STAGE;
@@ -628,8 +626,6 @@ void launch_q64(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((flash_attn_b16q64_kernel<D, NW>), dim3(q64_grid(a, 64 * NW)), dim3(64 * NW), smem, s, a);
 }
 
-}  // namespace
-
 // Which (if any) instance of the 64-queries-per-wave kernel serves the call: waves per workgroup, 0 = none (the caller falls back to
 // flash_attn_b16io_kernel).  A rule of the SHAPE only (never of the batch: the two kernels round differently, and a clip's bits must
 // not depend on how many clips run together).
@@ -638,6 +634,8 @@ int flash_attention_q64_waves(const AttnArgs& a) {
     static const int* const on = knob("E2V_ATTN_Q64", 1);
     if (!*on || !a.io_bf16 || a.mode != 0 || !(a.D == 40 || (a.D == 80 && *on >= 2)) || a.Nk <= 32) return 0;
     if (a.Nq < 128) return 0;
+    static const int* const force_nw = knob("E2V_ATTN_Q64_NW", 0);     // 2..4: that many waves per workgroup whatever the padding (A/B)
+    if (*force_nw >= 2 && *force_nw <= 4) return *force_nw;
     int best = 0, waste = 1 << 30;
     for (int nw = 4; nw >= 2; --nw) {                              // least padding of the last query block; ties: the larger workgroup
         const int qb = 64 * nw, w = (a.Nq + qb - 1) / qb * qb - a.Nq;

@@ -835,6 +835,23 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
     const float eps = cfg.norm_eps;
     const int boc0 = cfg.block_out_channels[0], temb_dim = boc0 * 4;
 
+    // test aid (e2v_op_unet_forward_taps): activation [n * F * h * w][C] -> fp32 NCFHW at the sink's cursor
+    auto tap = [&](const Act& a, int n, int C, int f, int h, int w) {
+        TapSink& t = *tap_sink;
+        const int64_t fhw = (int64_t)f * h * w, count = (int64_t)n * C * fhw;
+        E2V_REQUIRE(t.count < 16 && t.used + count <= t.cap, E2V_EINVAL, "tap buffer too small");
+        const float* rows = a.p;
+        Act wide;
+        if (a.bf16) {
+            wide = Act(pool, a.rows, a.C);
+            cvt_rows(a.p, a.C, 1, wide.p, a.C, 0, a.rows, a.C, a.C, s);
+            rows = wide.p;
+        }
+        cl_to_ncfhw(rows, a.C, t.buf + t.used, n, C, (int)fhw, 1.0f, 0.0f, 0, 0.f, 0.f, s);
+        const int64_t shp[5] = {n, C, f, h, w};
+        for (int i = 0; i < 5; ++i) t.shapes[t.count][i] = shp[i];
+        t.used += count; ++t.count;
+    };
     // time embedding (unet.py:324-345): sinusoid -> linear_1 -> SiLU -> linear_2; resnets consume SiLU(emb)
     if (d_timesteps_cap < N) {
         E2V_HIP(hipStreamSynchronize(s));
@@ -852,6 +869,7 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
         Act e1 = R.linear(unet.te1, sin.p, boc0, N, nullptr, 0, false, nullptr, 0, 0, true);        // fp32 rows in both modes
         silu(e1.p, e1.p, (long long)N * temb_dim, s);
         Act emb = R.linear(unet.te2, e1.p, temb_dim, N, nullptr, 0, false, nullptr, 0, 0, true);
+        if (tap_sink) tap(emb, N, temb_dim, 1, 1, 1);                                              // taps["emb"] (unet.py:345)
         silu(emb.p, emb.p, (long long)N * temb_dim, s);
         temb_silu = std::move(emb);
     }
@@ -907,11 +925,13 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
             Act d = R.conv3(b.rs, cur->p, cur->C, nullptr, 0, geo_of(i), hs[i], ws[i], hs[i + 1], ws[i + 1], 2, 1);
             cur = &keep(std::move(d), i + 1);
         }
+        if (tap_sink) { const int l = b.resample ? i + 1 : i; tap(*cur, N, cfg.block_out_channels[i], F, hs[l], ws[l]); }       // taps["down{i}"]
     }
     // mid (unet_blocks.py:199-205)
     Act h = R.resnet(unet.mid_r0, cur->p, cur->C, nullptr, 0, N, P_of(3), geo_of(3), groups, eps, temb_silu.p, temb_dim);
     h = R.transformer(unet.mid_attn, h, N, F, hs[3] * ws[3], cond, T, heads, groups);
     h = R.resnet(unet.mid_r1, h.p, h.C, nullptr, 0, N, P_of(3), geo_of(3), groups, eps, temb_silu.p, temb_dim);
+    if (tap_sink) tap(h, N, cfg.block_out_channels[3], F, hs[3], ws[3]);                               // taps["mid"]
     // up (unet.py:381-404)
     for (int i = 0; i < 4; ++i) {
         const UNetW::Block& b = unet.up[i];
@@ -927,6 +947,7 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
         if (b.resample) {   // Upsample3D: nearest to the next skip's (f,h,w) then 3x3 conv (resnet.py:58-69, unet.py:389-390)
             h = R.conv3(b.rs, h.p, h.C, nullptr, 0, geo_of(lvl), hs[lvl - 1], ws[lvl - 1], hs[lvl - 1], ws[lvl - 1], 1, 1);
         }
+        if (tap_sink) { const int l = b.resample ? lvl - 1 : lvl; tap(h, N, cfg.block_out_channels[lvl], F, hs[l], ws[l]); }   // taps["up{i}"]
     }
     Act hn = R.gn(unet.norm_out, h.p, h.C, nullptr, 0, N, P_of(0), groups, eps, true);                 // :406-407
     h.reset();

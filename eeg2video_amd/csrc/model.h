@@ -128,6 +128,10 @@ struct e2v_ctx {
     std::vector<float*> owned_part[3];
     std::unordered_map<void*, size_t> owned_bytes;
     void* comm = nullptr; int comm_rank = 0, comm_world = 0;     // RCCL communicator of e2v_comm_init (comm.cpp)
+    // e2v_op_unet_forward_taps (test aid): while set, unet_forward_cl copies the tensors the oracle exposes (emb, down0..3, mid,
+    // up0..3) out as fp32 NCFHW, back to back; shapes = {n, C, F, H, W} per tap
+    struct TapSink { float* buf = nullptr; int64_t cap = 0, used = 0; int count = 0; int64_t shapes[16][5]; };
+    TapSink* tap_sink = nullptr;
     int alloc_part = -1;                                         // >= 0: dev_alloc files the block under owned_part[alloc_part]
     void free_part(int part);
 

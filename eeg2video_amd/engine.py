@@ -200,6 +200,38 @@ class Engine:
                                               cond.data_ptr(), n, f, h, w, cond.shape[1], out.data_ptr(), _stream()))
         return out
 
+    TAP_NAMES = ("emb", "down0", "down1", "down2", "down3", "mid", "up0", "up1", "up2", "up3")
+
+    def unet_forward_taps(self, sample: torch.Tensor, timesteps: Sequence[int], cond: torch.Tensor):
+        """Test aid (``e2v_op_unet_forward_taps``): the forward plus the block outputs ``oracle/unet3d.py`` exposes as ``taps``
+        (fp32 NCFHW; ``emb`` as [N, 1280]).  Returns ``(sample_out, {name: tensor})``."""
+        sample, cond = self._dev(sample, "sample"), self._dev(cond, "encoder_hidden_states")
+        n, c, f, h, w = sample.shape
+        out = torch.empty((n, self.unet_cfg.out_channels, f, h, w), device=self.device, dtype=torch.float32)
+        boc = list(self.unet_cfg.block_out_channels)
+        down = lambda v: (v - 1) // 2 + 1                              # 3x3, stride 2, padding 1
+        hs, ws = [h], [w]
+        for _ in range(3):
+            hs.append(down(hs[-1])); ws.append(down(ws[-1]))
+        lv = lambda ch, l: n * ch * f * hs[l] * ws[l]
+        cap = (n * 4 * boc[0] + sum(lv(boc[i], min(i + 1, 3)) for i in range(4)) + lv(boc[3], 3)
+               + sum(lv(boc[3 - i], max(3 - i - 1, 0)) for i in range(4)))
+        buf = torch.empty(int(cap), device=self.device, dtype=torch.float32)
+        shapes = np.zeros(80, dtype=np.int64)
+        count = C.c_int(0)
+        ts = np.ascontiguousarray(np.asarray(timesteps).reshape(-1).astype(np.int64))
+        self._check(self.lib.e2v_op_unet_forward_taps(self.ctx, sample.data_ptr(), ts.ctypes.data_as(_lib.c_int64_p), ts.size,
+                                                      cond.data_ptr(), n, f, h, w, cond.shape[1], out.data_ptr(), buf.data_ptr(),
+                                                      buf.numel(), shapes.ctypes.data_as(_lib.c_int64_p), C.byref(count), _stream()))
+        taps, off = {}, 0
+        for i in range(count.value):
+            shp = [int(v) for v in shapes[5 * i:5 * i + 5]]
+            cnt = int(np.prod(shp))
+            t = buf[off:off + cnt].reshape(shp)
+            taps[self.TAP_NAMES[i]] = t.reshape(shp[0], shp[1]) if self.TAP_NAMES[i] == "emb" else t
+            off += cnt
+        return out, taps
+
     def ddim_cfg_step(self, eps_uncond: torch.Tensor, eps_cond: Optional[torch.Tensor], x: torch.Tensor,
                       guidance_scale: float, t: int, t_prev: int) -> torch.Tensor:
         eu, x = self._dev(eps_uncond, "eps"), self._dev(x, "sample")

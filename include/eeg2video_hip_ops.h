@@ -59,6 +59,16 @@ e2v_status e2v_op_to_channels_last(e2v_ctx* ctx, const float* in, float* out, in
 e2v_status e2v_op_from_channels_last(e2v_ctx* ctx, const float* in, int ld, float* out, int n, int C, int FHW,
                                      e2v_stream stream);
 
+/* Test aid: UNet3DConditionModel.forward (EEG2Video/models/unet.py:278-413, as e2v_unet_forward) that also copies out the
+ * intermediate tensors oracle/unet3d.py exposes as `taps`, in this order: "emb" (time embedding before the resnets' SiLU, unet.py:345,
+ * [N, 1280, 1, 1, 1]), "down0".."down3" (after each down block incl. its downsampler, unet.py:362-373), "mid" (unet.py:376-378),
+ * "up0".."up3" (after each up block incl. its upsampler, unet.py:381-404).  Each is written to `taps` (device, fp32) as a contiguous
+ * NCFHW tensor, back to back; shapes[5 i ..] = {n, C, F, H, W} of tap i (host, room for 16 taps = 80 entries), *n_taps their number.
+ * taps_cap = capacity of `taps` in floats (E2V_EINVAL when too small).  In the bf16 mode the taps are the bf16 tensors widened. */
+e2v_status e2v_op_unet_forward_taps(e2v_ctx* ctx, const float* sample, const int64_t* host_t, int n_t, const float* cond, int N,
+                                    int F, int H, int W, int T, float* out, float* taps, int64_t taps_cap, int64_t* shapes,
+                                    int* n_taps, e2v_stream stream);
+
 /* Test / profiling aid: set one of the run-time switches of DESIGN.md section 10 (the integer an environment variable of the
  * same name would give it at first use), for same-process A/B comparisons of kernel variants -- e.g. "E2V_BGEMM_PERS" 0/1.
  * Process-wide; E2V_EINVAL for an unknown name.  No reference counterpart. */

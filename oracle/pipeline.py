@@ -32,8 +32,9 @@ def generate(unet_sd, unet_cfg, vae_sd, vae_cfg, latents: torch.Tensor, cond: to
              decode: bool = True, scheduler=None, noises: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
     """latents ``[B,4,F,h,w]``, cond ``[B,77,D]``, uncond ``[1 or B,77,D]`` -> videos ``[B,3,F,8h,8w]``.
 
-    ``trace`` (optional) collects per-step ``eps`` (after guidance) and ``latents`` for the
-    teacher-forced per-step parity tests.  ``noises`` (optional): the per-step N(0, 1) draws of a stochastic scheduler
+    ``trace`` (optional) collects per-step ``eps`` (after guidance), the two unguided halves ``eps_u`` / ``eps_c`` and ``latents`` for
+    the teacher-forced per-step parity tests; ``trace["taps_step"] = k`` on entry additionally keeps the block outputs of step k's
+    UNet forward (``unet3d_forward(..., taps=...)``: emb, down0..3, mid, up0..3) in ``trace["taps"]``.  ``noises`` (optional): the per-step N(0, 1) draws of a stochastic scheduler
     (DDIM with ``eta > 0``, Euler-ancestral), passed in so that a test can hand the device path the same numbers."""
     sched = scheduler if scheduler is not None else DDIMOracle()      # any oracle scheduler (DDIMOracle, PNDMOracle)
     b = latents.shape[0]
@@ -48,9 +49,15 @@ def generate(unet_sd, unet_cfg, vae_sd, vae_cfg, latents: torch.Tensor, cond: to
         t = int(t) if float(t).is_integer() else float(t)         # sigma-space schedulers step through fractional timesteps
         x_in = torch.cat([x] * 2) if do_cfg else x                                   # :313
         x_in = sched.scale_model_input(x_in, t)                                      # :314
-        eps = unet3d_forward(unet_sd, unet_cfg, x_in, t, emb)                        # :317
+        taps = {} if trace is not None and trace.get("taps_step") == i else None    # block outputs of this step's forward (tests)
+        eps = unet3d_forward(unet_sd, unet_cfg, x_in, t, emb, taps=taps)             # :317
+        if taps is not None:
+            trace["taps"] = taps
         if do_cfg:                                                                   # :320-322
             eps_u, eps_c = eps.chunk(2)
+            if trace is not None:
+                trace.setdefault("eps_u", []).append(eps_u.clone())
+                trace.setdefault("eps_c", []).append(eps_c.clone())
             eps = eps_u + guidance_scale * (eps_c - eps_u)
         x = sched.step(eps, t, x, eta=eta, noise=noises[i] if noises is not None else None)   # :325
         if trace is not None:

@@ -94,7 +94,7 @@ def config0(full):
     lat = _t(counter_normal(1234, "latent", (1, 4, 6, 36, 64)))
     cond = _t(counter_normal(1235, "cond", (1, 77, 768)))
     unc = _t(counter_normal(1236, "uncond", (1, 77, 768)))
-    trace = {}
+    trace = {"taps_step": 0}                 # also keep the block outputs of step 0's forward (the block-granularity tests)
     with torch.no_grad():
         ref = generate({k: _t(v) for k, v in usd.items()}, UNetConfig(), {k: _t(v) for k, v in vsd.items()}, VAEConfig(),
                        lat, cond, unc, num_inference_steps=4, guidance_scale=12.5, trace=trace)
@@ -295,8 +295,9 @@ def test_configs2_bf16_batch32_equals_single_clip_calls(full):
 def test_config0_bf16_teacher_forced_steps_vs_fp32_oracle(full, config0):
     """Per-step bf16 check (SURVEY 8(d) procedure ii in the bf16-activation mode): the fp32 oracle's latents of step k-1 go into the
     bf16 UNet of step k, so that rounding does not chain across steps and a defect of a few 1e-2 in ONE layer cannot hide inside
-    the end-to-end noise.  Bounds, of the tensor's scale (max |ref|): each of the two UNet outputs (one bf16 forward against the fp32
-    forward of the same input) < 2e-2 -- THE per-step check; measured 1.1e-2 at step 0.  The guided eps = eps_u + 12.5 (eps_c - eps_u)
+    the end-to-end noise.  Bounds, of the tensor's scale (max |ref|): each of the two UNet outputs (one bf16 forward against the
+    ORACLE's fp32 forward of the same input, trace["eps_u"] / ["eps_c"]; the fp32 HIP forward beside it) < 2e-2 -- THE per-step
+    check; measured 1.1e-2 at step 0.  The guided eps = eps_u + 12.5 (eps_c - eps_u)
     amplifies the difference of the two forwards' rounding 12.5x (measured 9.0e-2 at step 0) and the DDIM update carries a third of
     that into the latents (3.1e-2): they are printed and only bounded loosely (0.25 / 0.1)."""
     pipe = full[0]
@@ -316,15 +317,61 @@ def test_config0_bf16_teacher_forced_steps_vs_fp32_oracle(full, config0):
             guided = eng.cfg_combine(eps16[:1], eps16[1:], 12.5)
             x_new = eng.ddim_cfg_step(eps16[:1], eps16[1:], xg, 12.5, int(t), int(t) - 250)
             e_u, e_c = rel_err(eps16[:1], eps32[:1]), rel_err(eps16[1:], eps32[1:])
+            o_u, o_c = rel_err(eps16[:1], trace["eps_u"][k]), rel_err(eps16[1:], trace["eps_c"][k])     # against the ORACLE's two forwards
             e_g, e_x = rel_err(guided, trace["eps"][k]), rel_err(x_new, trace["latents"][k])
-            print(f"  bf16 teacher-forced step {k} (t = {int(t)}): eps_uncond {e_u:.3e} eps_cond {e_c:.3e} (vs fp32 HIP) | "
-                  f"guided eps {e_g:.3e} latents {e_x:.3e} (vs fp32 oracle), all max-abs / max-ref")
+            print(f"  bf16 teacher-forced step {k} (t = {int(t)}): eps_uncond {o_u:.3e} eps_cond {o_c:.3e} (vs fp32 oracle; vs fp32 HIP "
+                  f"{e_u:.3e} / {e_c:.3e}) | guided eps {e_g:.3e} latents {e_x:.3e} (vs fp32 oracle), all max-abs / max-ref")
             assert torch.isfinite(eps16).all()
+            assert o_u < 2e-2 and o_c < 2e-2, k                 # THE per-step bound: one bf16 forward against the oracle's fp32 forward
             assert e_u < 2e-2 and e_c < 2e-2, k
             assert e_g < 0.25 and e_x < 0.1, k
             x = trace["latents"][k]
     finally:
         eng.set_compute_dtype("fp32")
+
+
+TAP_ORDER = ("emb", "down0", "down1", "down2", "down3", "mid", "up0", "up1", "up2", "up3")
+# bound per tap, of the tap's scale (max |oracle tap|): fp32 mode / bf16 mode.  Measured at full size (round 4): fp32 3.5e-6 .. 3.3e-5;
+# bf16 emb 5.4e-6 (the time-embedding MLP stays fp32), down0 7.4e-3, down1 1.06e-2, down2 1.40e-2, down3 1.43e-2, mid 1.83e-2, up0 1.69e-2,
+# up1 1.43e-2, up2 1.42e-2, up3 8.6e-3 -- the error grows down the graph (every stored tensor is one bf16 rounding, 2^-9 relative) and
+# shrinks again where the wide skip tensors of the shallow levels re-enter.  Bounds = measured x 1.4.
+TAP_BOUND_FP32 = 1e-4
+TAP_BOUND_BF16 = {"emb": 2e-5, "down0": 1.05e-2, "down1": 1.5e-2, "down2": 2e-2, "down3": 2e-2, "mid": 2.6e-2, "up0": 2.4e-2, "up1": 2e-2,
+                  "up2": 2e-2, "up3": 1.2e-2}
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_config0_block_taps_vs_fp32_oracle(full, config0, mode):
+    """Block-granularity parity at full size (UNet3DConditionModel.forward, unet.py:358-408): step 0 of configs[0] -- the oracle's own
+    input [x; x], t = 751, [uncond; cond] -- through the HIP UNet with the outputs of every block copied out
+    (e2v_op_unet_forward_taps), each compared with the tensor the fp32 ORACLE holds at the same point (oracle/unet3d.py taps: emb,
+    down0..3, mid, up0..3).  fp32 mode: every tap within 1e-4 of its scale.  bf16 mode: per-tap bounds (TAP_BOUND_BF16) -- a
+    single-layer defect of 1e-2 shows up at ITS block instead of inside the end-to-end noise."""
+    pipe = full[0]
+    eng = pipe.unet.engine
+    lat, cond, unc, ref, trace = config0
+    taps_ref = trace["taps"]
+    t0 = int(eng.ddim_timesteps(4)[0])
+    emb = torch.cat([unc, cond]).cuda()
+    xg = lat.cuda()
+    try:
+        eng.set_compute_dtype(mode)
+        eps, taps = eng.unet_forward_taps(torch.cat([xg, xg]), [t0], emb)
+        plain = pipe.unet(torch.cat([xg, xg]), t0, emb).sample
+    finally:
+        eng.set_compute_dtype("fp32")
+    assert torch.equal(eps, plain)                           # the tapped forward IS the forward
+    assert tuple(taps) == TAP_ORDER
+    errs = {}
+    for name in TAP_ORDER:
+        assert taps[name].shape == taps_ref[name].shape, (name, taps[name].shape, taps_ref[name].shape)
+        errs[name] = rel_err(taps[name], taps_ref[name])
+    e_u, e_c = rel_err(eps[:1], trace["eps_u"][0]), rel_err(eps[1:], trace["eps_c"][0])
+    print(f"{mode} block taps vs fp32 oracle (max-abs / max-ref): " + "  ".join(f"{k} {v:.2e}" for k, v in errs.items())
+          + f"  | eps_uncond {e_u:.2e} eps_cond {e_c:.2e}")
+    for name, e in errs.items():
+        assert e < (TAP_BOUND_FP32 if mode == "fp32" else TAP_BOUND_BF16[name]), (name, e)
+    assert e_u < (1e-4 if mode == "fp32" else 2e-2) and e_c < (1e-4 if mode == "fp32" else 2e-2)
 
 
 def test_configs4_sweep_full_size_one_concept_bf16(full, capsys):

@@ -30,6 +30,6 @@ def run(mode, n, variants):
 run("fp32", 16, [""])
 if os.environ.get("OLD_VARIANTS"):
     run("bf16", 64, ["E2V_ATTN_Q64=0,E2V_ATTN_FOLD=0,E2V_ATTN_KT64=0", "E2V_ATTN_Q64=0,E2V_ATTN_FOLD=1,E2V_ATTN_KT64=0", "E2V_ATTN_Q64=0,E2V_ATTN_FOLD=0,E2V_ATTN_KT64=1"])
-run("bf16", 64, ["E2V_ATTN_Q64=0,E2V_ATTN_FOLD=1,E2V_ATTN_KT64=1", "E2V_ATTN_Q64=1,E2V_ATTN_Q64P=0", "E2V_ATTN_Q64=1,E2V_ATTN_Q64P=1"])
-eng.set_knob("E2V_ATTN_Q64", 1); eng.set_knob("E2V_ATTN_Q64P", 1)
+run("bf16", 64, ["E2V_ATTN_Q64=0,E2V_ATTN_FOLD=1,E2V_ATTN_KT64=1", "E2V_ATTN_Q64=1,E2V_ATTN_Q64P=0", "E2V_ATTN_Q64=1,E2V_ATTN_Q64P=1"] + [v for v in os.environ.get("EXTRA_VARIANTS", "").split(";") if v])
+eng.set_knob("E2V_ATTN_Q64", 1); eng.set_knob("E2V_ATTN_Q64P", 1); eng.set_knob("E2V_ATTN_Q64_NW", 0)
 eng.set_compute_dtype("fp32")
