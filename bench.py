@@ -69,9 +69,10 @@ def parse_args(argv):
                          "RCCL communicator; torch.distributed then only ships the 128-byte id)")
     ap.add_argument("--no-configs2", action="store_true",
                     help="skip the BASELINE configs[2] leg (bf16, B = 32) that a default fp32 run at N = 1 attaches to its JSON line")
+    ap.add_argument("--configs2-steps", type=int, default=4, help="timed passes of the configs[2] leg")
     ap.add_argument("--configs2-budget-s", type=float, default=455.0,
                     help="run the configs[2] leg only if the process is younger than this when the fp32 part is done (the driver's limit "
-                         "is 600 s; the leg takes ~50 s and the CPU baseline ~65 s after it)")
+                         "is 600 s; the leg takes ~50 s, the CPU baseline ~65 s runs beside it on a thread)")
     ap.add_argument("--dist-single", action="store_true",
                     help="N = 1 rehearsal of the collective: initialise the process group (world size 1) and run the frame "
                          "all-gather through it, so that the RCCL code path executes on a one-GPU box")
@@ -128,11 +129,11 @@ def host_cores() -> dict:
     return {"cores": cores, "affinity": aff, "os_cpu_count": os.cpu_count(), "cgroup_cpu_max": raw or None, "cpu_model": model}
 
 
-def cpu_baseline(pipe_gen, usd, vsd, ucfg, vcfg, ddim_steps, guidance):
-    """BASELINE configs[0] for real: the oracle (CPU restatement of the reference's op sequence, fp32) generates ONE clip
-    -- random [1,4,6,36,64] latent, [1,77,768] cond, 4-step DDIM with classifier-free guidance, UNet3D + VAE decode -- on
-    this box's host cores, and the same clip goes through the HIP path for the parity figure.  BASELINE.md section 4's
-    extrapolation gives the 50-step rate: 1 / (t_vae + ddim_steps * (t_total - t_vae) / 4)."""
+def cpu_oracle_run(usd, vsd, ucfg, vcfg, guidance):
+    """BASELINE configs[0] for real, CPU part: the oracle (CPU restatement of the reference's op sequence, fp32) generates ONE clip
+    -- random [1,4,6,36,64] latent, [1,77,768] cond, 4-step DDIM with classifier-free guidance, UNet3D + VAE decode -- on this box's
+    host cores.  Touches no GPU state: the default run executes it on a thread beside the untimed warm-up steps (whose host thread
+    sleeps in the HIP runtime) and joins it before the timed region starts."""
     import numpy as np
     import torch
     from eeg2video_amd.weights import TINY_UNET, counter_normal, synth_state_dict, unet_param_spec
@@ -161,19 +162,29 @@ def cpu_baseline(pipe_gen, usd, vsd, ucfg, vcfg, ddim_steps, guidance):
         ref = decode_latents(vsd_t, vcfg, x)
         t_vae = time.perf_counter() - t0
         del vsd_t
+    return {"hc": hc, "cores": cores, "n_cpu": n_cpu, "t_loop": t_loop, "t_vae": t_vae, "lat": lat, "cond": cond, "unc": unc, "x": x, "ref": ref,
+            "torch": torch.__version__}
+
+
+def cpu_baseline(run, pipe_gen, ddim_steps, guidance, overlapped_with=None):
+    """The `cpu_baseline` and `parity` objects from a finished cpu_oracle_run: BASELINE.md section 4's extrapolation gives the 50-step
+    rate, 1 / (t_vae + ddim_steps * (t_total - t_vae) / 4); the same clip goes through the HIP path for the parity figure."""
+    hc, cores, n_cpu, t_loop, t_vae = run["hc"], run["cores"], run["n_cpu"], run["t_loop"], run["t_vae"]
     t_total = t_loop + t_vae
     clip_s = t_vae + ddim_steps * t_loop / n_cpu
-    vid, lat_gpu = pipe_gen(lat, cond, unc, n_cpu)
+    vid, lat_gpu = pipe_gen(run["lat"], run["cond"], run["unc"], n_cpu)
+    ref, x = run["ref"], run["x"]
     frames_err = (vid.cpu().double() - ref.double()).abs().max().item()
     lat_err = ((lat_gpu.cpu().double() - x.double()).abs().max() / x.double().abs().max()).item()
     return {
         "value": 1.0 / clip_s, "unit": "clips/s", "cores": cores, "kind": "port",
-        "sample": (f"BASELINE configs[0] run in full: oracle (torch {torch.__version__} CPU fp32) on {hc['cpu_model']}, {cores} threads "
+        "sample": (f"BASELINE configs[0] run in full: oracle (torch {run['torch']} CPU fp32) on {hc['cpu_model']}, {cores} threads "
                    f"(affinity {hc['affinity']}, cgroup cpu.max '{hc['cgroup_cpu_max']}'): 1 clip, {n_cpu}-step DDIM, CFG {guidance}, "
                    f"UNet3D loop {t_loop:.1f} s + VAE decode of 6 frames {t_vae:.1f} s = {t_total:.1f} s; "
                    f"{ddim_steps}-step rate = 1 / (t_vae + {ddim_steps} * t_loop / {n_cpu}) (BASELINE.md section 4)"),
         "wall_s": t_total, "unet_loop_s": t_loop, "vae_decode_s": t_vae, "vae_share": t_vae / t_total,
         "cpu_model": hc["cpu_model"], "affinity": hc["affinity"], "cgroup_cpu_max": hc["cgroup_cpu_max"],
+        "overlapped_with": overlapped_with,
     }, {"config": "BASELINE configs[0]: 1 clip, seeds 1234/1235/1236, 4-step DDIM (751,501,251,1), CFG, UNet3D + VAE decode",
         "frames_max_abs": frames_err, "final_latents_max_abs_over_max_ref": lat_err}
 
@@ -192,6 +203,11 @@ def instrumented_pass(eng, lat, cond, unc, ddim_steps, guidance, B, dtype, value
     eng.profile_begin()
     eng.generate(lat, cond, unc, ddim_steps, guidance, 0.0, decode=True)
     table = eng.profile_end()
+    return roofline_of(table, ddim_steps, B, dtype, value_per_gpu, kernel_table_path)
+
+
+def roofline_of(table, ddim_steps, B, dtype, value_per_gpu, kernel_table_path="", where="one e2v_generate pass"):
+    """The `roofline` object from the per-class event table of an instrumented pass."""
     tot_ms = sum(v["ms"] for v in table.values())
     for k, v in table.items():
         v["avg_us"] = 1e3 * v["ms"] / max(v["launches"], 1)
@@ -224,7 +240,7 @@ def instrumented_pass(eng, lat, cond, unc, ddim_steps, guidance, B, dtype, value
     roof.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": dom, "launches": d["launches"],
                  "avg_launch_us": d["avg_us"], "flops_per_launch": d["flops"] / max(d["launches"], 1),
                  "bytes_per_launch": d["bytes"] / max(d["launches"], 1), "share_of_gpu_time": d["share"],
-                 "sample": f"HIP events around every launch of one e2v_generate pass ({ddim_steps} DDIM steps + decode, B={B})",
+                 "sample": f"HIP events around every launch of {where} ({ddim_steps} DDIM steps + decode, B={B})",
                  "whole_path_direct_conv_flops_over_f32_mfma_peak": value_per_gpu * (2 * ddim_steps * TFLOP_UNET_SAMPLE + TFLOP_VAE_CLIP) / PEAK_F32_MFMA_TFLOPS,
                  # the path as a whole against the MFMA peak of the arithmetic type, counted in ALGORITHMIC flops per clip
                  # (direct convolutions, every key of the reference's attention) -- Winograd / sub-pixel convs and the shared frame-0 keys
@@ -242,8 +258,9 @@ def instrumented_pass(eng, lat, cond, unc, ddim_steps, guidance, B, dtype, value
 
 def configs2_leg(eng, args, host_frames_u8=None):
     """BASELINE configs[2] inside the default run: "1xMI355X: bf16 UNet3D with fp32 GroupNorm, batch=32" -- the same engine switched
-    to the bf16-activation mode, B = 32 fresh synthetic clips resident in HBM, a 2-step warm-up pass (builds the bf16 weight forms),
-    2 timed passes (e2v_generate + D2H of the fp32 frames, as the headline) and one event-instrumented pass."""
+    to the bf16-activation mode, B = 32 fresh synthetic clips resident in HBM, one event-instrumented full pass that doubles as the
+    warm-up (builds the bf16 weight forms), then --configs2-steps (4) timed passes (e2v_generate + D2H of the fp32 frames, as the
+    headline)."""
     import numpy as np
     import torch
     from eeg2video_amd.weights import counter_normal
@@ -256,9 +273,13 @@ def configs2_leg(eng, args, host_frames_u8=None):
     host = torch.empty((B, 3, 6, 288, 512), dtype=torch.float32).pin_memory()
     eng.set_compute_dtype("bf16")
     try:
-        eng.generate(lat, cond, unc, 2, args.guidance, 0.0, decode=True)
+        # the event-instrumented pass comes FIRST and is the leg's warm-up (it builds the bf16 weight forms; event timings are per
+        # kernel, so the one-off packing launches only add their own small classes)
+        eng.profile_begin()
+        eng.generate(lat, cond, unc, args.ddim_steps, args.guidance, 0.0, decode=True)
+        table = eng.profile_end()
         torch.cuda.synchronize()
-        n = 2
+        n = args.configs2_steps
         t0 = time.perf_counter()
         for _ in range(n):
             frames = eng.generate(lat, cond, unc, args.ddim_steps, args.guidance, 0.0, decode=True)
@@ -267,11 +288,11 @@ def configs2_leg(eng, args, host_frames_u8=None):
         el = time.perf_counter() - t0
         finite = bool(torch.isfinite(frames).all().item())
         value = B * n / el
-        roof, _ = instrumented_pass(eng, lat, cond, unc, args.ddim_steps, args.guidance, B, "bf16", value,
-                                    (args.kernel_table + ".configs2.json") if args.kernel_table else "")
+        roof, _ = roofline_of(table, args.ddim_steps, B, "bf16", value, (args.kernel_table + ".configs2.json") if args.kernel_table else "",
+                              where="the leg's first (warm-up) e2v_generate pass")
     finally:
         eng.set_compute_dtype("fp32")
-    return {"value": value, "unit": "clips/s", "ms_per_step": 1e3 * el / n, "steps": n, "warmup": "one 2-DDIM-step pass",
+    return {"value": value, "unit": "clips/s", "ms_per_step": 1e3 * el / n, "steps": n, "warmup": "one full pass (the event-instrumented one)",
             "dtype": "bf16", "output_finite": finite,
             "config": {"workload": (f"1xMI355X: batch={B} synthetic latents [B,4,6,36,64] + [B,77,768] cond, {args.ddim_steps}-step DDIM, CFG "
                                     f"{args.guidance}, 288x512x6 VAE decode, bf16 MFMA, bf16 activations in HBM, fp32 accumulate / norm "
@@ -366,9 +387,45 @@ def main() -> int:
             host_frames.copy_(frames, non_blocking=True)
         return frames
 
-    for _ in range(args.warmup):
-        step()
+    # The CPU baseline (the oracle on the host cores, ~1 min) runs on a thread BESIDE THE WARM-UP STEPS and is joined before the timed
+    # region starts: the warm-up is untimed GPU work whose host thread sleeps in the HIP runtime, so the two share nothing, the timed
+    # region never sees the oracle's threads, and the default run is a minute shorter than with the leg at its end.
+    cpu_thread, cpu_run, cpu_overlap = None, {}, None
+    cpu_wanted = rank == 0 and world == 1 and not args.no_cpu_baseline
+
+    def start_cpu_leg():
+        import threading
+
+        def _cpu_leg():
+            try:
+                cpu_run["run"] = cpu_oracle_run(usd, vsd, ucfg, vcfg, args.guidance)
+            except BaseException as e:          # reported in the line instead of killing the run
+                cpu_run["error"] = f"{type(e).__name__}: {e}"
+        th = threading.Thread(target=_cpu_leg, name="cpu_baseline", daemon=True)
+        th.start()
+        return th
+
+    if cpu_wanted and args.warmup > 0:
+        cpu_thread = start_cpu_leg()
+        cpu_overlap = f"the {args.warmup} untimed warm-up step(s); joined before the timed region started"
+
+    # The LAST warm-up step of rank 0 carries the HIP-event instrumentation (the roofline's table): it is a full pass of the timed
+    # workload either way, and it saves the default run a separate 14 s pass.  (No warm-up, or a different --profile-ddim-steps:
+    # a separate instrumented pass after the timed region, as before.)
+    warm_table = None
+    instr_in_warmup = (rank == 0 and not args.no_roofline and args.warmup > 0 and args.profile_ddim_steps in (0, args.ddim_steps))
+    for i in range(args.warmup):
+        if instr_in_warmup and i == args.warmup - 1:
+            eng.profile_begin()
+            step()
+            warm_table = eng.profile_end()
+        else:
+            step()
     torch.cuda.synchronize()
+    if cpu_thread is not None:
+        t_join = time.perf_counter()
+        cpu_thread.join()
+        log(f"cpu_baseline thread joined {time.perf_counter() - t_join:.1f} s after the warm-up ended")
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
@@ -392,6 +449,10 @@ def main() -> int:
     finite = bool(torch.isfinite(out.float()).all().item())
     clips = world * B * args.steps
     value = clips / elapsed
+
+    if cpu_wanted and cpu_thread is None:       # no warm-up to hide it under: beside the GPU-only tail of the run instead
+        cpu_thread = start_cpu_leg()
+        cpu_overlap = "the GPU-only tail of the run (exchange / D2H figures, configs[2] leg); the timed region was over"
 
     # the exchange and the D2H on their own (both are inside the timed step above)
     gather_ms = d2h_ms = None
@@ -421,8 +482,12 @@ def main() -> int:
         if not args.no_roofline:
             if args.profile_ddim_steps <= 0:
                 args.profile_ddim_steps = args.ddim_steps
-            roof, _ = instrumented_pass(eng, lat, cond, unc, args.profile_ddim_steps, args.guidance, B, args.dtype, value / world,
-                                        args.kernel_table)
+            if warm_table is not None:
+                roof, _ = roofline_of(warm_table, args.ddim_steps, B, args.dtype, value / world, args.kernel_table,
+                                      where="the last warm-up step (one e2v_generate pass of the timed workload)")
+            else:
+                roof, _ = instrumented_pass(eng, lat, cond, unc, args.profile_ddim_steps, args.guidance, B, args.dtype, value / world,
+                                            args.kernel_table)
 
         # ---- BASELINE configs[2] (bf16, B = 32) as a second leg of the default run, inside the driver's wall-clock budget ----
         configs2 = None
@@ -438,11 +503,15 @@ def main() -> int:
                 configs2 = {"skipped": f"process age {age:.0f} s >= budget {args.configs2_budget_s:.0f} s (the driver's limit is 600 s)"}
 
         cpu, parity = None, None
-        if world == 1 and not args.no_cpu_baseline:
-            def gpu_gen(l, c, u, n):
-                return eng.generate(l.to(dev), c.to(dev), u.to(dev), n, args.guidance, 0.0, decode=True, return_latents=True)
-            cpu, parity = cpu_baseline(gpu_gen, usd, vsd, ucfg, vcfg, args.ddim_steps, args.guidance)
-            parity["tolerance_frames_max_abs"] = 1e-1 if args.dtype == "bf16" else 1e-3
+        if cpu_thread is not None:
+            cpu_thread.join()
+            if "run" in cpu_run:
+                def gpu_gen(l, c, u, n):
+                    return eng.generate(l.to(dev), c.to(dev), u.to(dev), n, args.guidance, 0.0, decode=True, return_latents=True)
+                cpu, parity = cpu_baseline(cpu_run["run"], gpu_gen, args.ddim_steps, args.guidance, cpu_overlap)
+                parity["tolerance_frames_max_abs"] = 1e-1 if args.dtype == "bf16" else 1e-3
+            else:
+                cpu = {"skipped": cpu_run.get("error", "no result")}
         dtype_name = {"fp32": "f32", "bf16": "bf16", "f32x3": "f32 products from 3-way split bf16 operands (6 bf16 MFMAs), f32 accumulate"}[args.dtype]
         result = {
             "metric": "6-frame 288x512 clips/sec (50-step DDIM)", "value": value, "unit": "clips/s", "n_gpus": world,
@@ -464,7 +533,7 @@ def main() -> int:
                                                       else f"torch.distributed ({args.backend})") if use_dist else "none"},
             "per_rank_clips_per_s": ({"min": B * 1e3 / max(own_ms), "max": B * 1e3 / min(own_ms), "ms_per_step": own_ms} if own_ms else None),
             "roofline": roof, "configs2": configs2, "cpu_baseline": cpu, "parity": parity, "output_finite": finite,
-            "gpu_over_cpu": (value / cpu["value"]) if cpu else None,
+            "gpu_over_cpu": (value / cpu["value"]) if cpu and "value" in cpu else None,
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
