@@ -1519,8 +1519,8 @@ static void temporal_attention_launch(const T* qkv, int ld, T* out, int ldo, int
                                       hipStream_t s) {
     const size_t total = (size_t)n * HW * heads * F;
     const int C = heads * D;
-    static const bool wave_on = [] { const char* e = std::getenv("E2V_TATTN_WAVE"); return !e || std::atoi(e) != 0; }();
-    if (wave_on) {
+    static const int* const wave_on = knob("E2V_TATTN_WAVE", 1);      // 0: the LDS-staged kernel (same-process A/B, the op test)
+    if (*wave_on) {
         bool done = false;
         switch (D) {
             case 8: done = temporal_wave_launch<T, 8>(qkv, ld, out, ldo, n, F, HW, heads, scale, s); break;

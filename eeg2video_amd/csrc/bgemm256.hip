@@ -964,6 +964,10 @@ static int t256_tile_cols(const IgemmArgs& a, const bool force = false) {      /
     if (a.taps != 1) {          // a tile's rows span at most ceil(256 / (Ho Wo)) + 1 images: their pixel indices must fit 20 bits
         const long span = (255 / ((long)a.Ho * a.Wo) + 2) * (long)a.Hs * a.Ws;
         if (span >= (1L << 20)) return 0;
+        // ... and the gather's 32-bit BYTE offset (pixel x row pitch) must stay below the out-of-window marker (0x80000000) and inside
+        // the descriptor's 0x7FFFFFF0-byte record: a wide source (lda * 2 bytes per pixel) on a large map would wrap or read zeros
+        const long ldmax = a.lda0 > a.lda1 ? a.lda0 : a.lda1;
+        if (span * ldmax * 2 >= (1L << 31) - 16) return 0;
     }
     if (!force && *on != 2 && (long)((a.M + 255) / 256) * (a.N / cols) < *mintiles) return 0;
     return cols;
@@ -1003,7 +1007,8 @@ static void t256_launch_part(IgemmArgs a, const int cols, const int rb0, const i
     const long ntiles = (long)a.nbm * nct;
     // (the epilogue reads the residual in the output's type: fp32 with fp32 at the test entry points, bf16 with bf16 in the graph)
     const bool io_ok = !a.resid || (a.out_f32 ? !a.resid_bf16 : a.resid_bf16 != 0);
-    if (allow_persistent && lin && io_ok && *persp && (*persp == 2 || (a.c0 + a.c1 <= *pmaxk && ntiles >= *pmint))) {
+    // (the persistent epilogue adds no per-sample row bias: such a launch -- none in the graph today -- stays on the tile kernel)
+    if (allow_persistent && lin && io_ok && !a.rowbias && *persp && (*persp == 2 || (a.c0 + a.c1 <= *pmaxk && ntiles >= *pmint))) {
         // bias in LDS where it fits behind the operand buffers (160 KB per CU) and the epilogue loads nothing else (no residual)
         static const int* const bldsp = knob("E2V_BGEMM_T256P_BIAS_LDS", 1);
         const bool blds = *bldsp && !a.resid && smem + (size_t)a.N * 4 <= (size_t)160 * 1024;      // (no bias: the LDS copy is zeros)
@@ -1129,6 +1134,9 @@ bool bgemm_up2x_applies(const IgemmArgs& g) {
 }
 
 void bgemm_up2x_launch(const IgemmArgs& g, const void* w16_up2, hipStream_t s) {
+    // this route does not pass igemm()'s operand checks: the LDS-DMA moves 16-byte pieces
+    if ((g.lda0 & 7) || (g.ldc & 7) || (reinterpret_cast<uintptr_t>(g.a0) & 15) || (reinterpret_cast<uintptr_t>(g.out) & 15))
+        throw Error(E2V_ESHAPE, "bf16 sub-pixel conv: row strides must be multiples of 8 elements and rows 16-byte aligned");
     const size_t per = (size_t)g.N * conv_up2x_packed_ld(g.c0);
     for (int par = 0; par < 4; ++par) {
         IgemmArgs q = up2x_parity_args(g, par >> 1, par & 1);

@@ -40,7 +40,9 @@ Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
+        // the soname first: that resolves to the copy ALREADY in the process (torch's, when the host is PyTorch) instead of loading a
+        // second RCCL beside it through the unversioned development link
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.handle) break;
         }

@@ -38,10 +38,17 @@ def all_gather_frames(frames: torch.Tensor, group: Optional[dist.ProcessGroup] =
 
     ``engine``: run the exchange BELOW the C ABI -- ``e2v_allgather_frames`` on the library's own RCCL communicator
     (``Engine.comm_init``; ``torch.distributed`` then only ships the 128-byte communicator id), with the uint8 conversion fused in
-    front of it.  Needs the same ``b`` on every rank (the benchmark's and the sweep's full batches)."""
+    front of it.  ``ncclAllGather`` needs the same ``b`` on every rank: the counts are exchanged first (one tiny all-gather) and a
+    ragged set of shards -- the last batch of a sweep -- goes through the padded ``torch.distributed`` path below instead."""
     if engine is not None and dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective):
-        engine.comm_init(group)
-        return engine.allgather_frames(frames, as_uint8=as_uint8)
+        world = dist.get_world_size(group)
+        dev = frames.device if frames.is_cuda or dist.get_backend(group) != "nccl" else torch.device("cuda")
+        counts = torch.tensor([frames.shape[0]], device=dev, dtype=torch.int64)
+        all_counts = [torch.zeros_like(counts) for _ in range(world)]
+        dist.all_gather(all_counts, counts, group=group)
+        if len({int(c.item()) for c in all_counts}) == 1:
+            engine.comm_init(group)
+            return engine.allgather_frames(frames, as_uint8=as_uint8)
     x = frames_to_uint8(frames) if as_uint8 else frames
     if not (dist.is_available() and dist.is_initialized()):
         return x

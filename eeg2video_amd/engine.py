@@ -360,8 +360,12 @@ class Engine:
         rank 0 draws the id, ``torch.distributed`` only ships its 128 bytes.  Returns the world size."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        if self.lib.e2v_comm_world(self.ctx) == world:
+        # one communicator per GROUP: a different group of the same size must not reuse it (its ranks are other processes)
+        key = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
+        if self.lib.e2v_comm_world(self.ctx) == world and getattr(self, "_comm_key", None) == key:
             return world
+        if self.lib.e2v_comm_world(self.ctx) > 0:
+            self.comm_destroy()
         buf = (C.c_ubyte * 128)()
         if rank == 0:
             if self.lib.e2v_comm_unique_id(buf) != _lib.E2V_OK:
@@ -370,10 +374,12 @@ class Engine:
         dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         raw = (C.c_ubyte * 128).from_buffer_copy(ids[0])
         self._check(self.lib.e2v_comm_init(self.ctx, raw, rank, world))
+        self._comm_key = key
         return world
 
     def comm_destroy(self) -> None:
         self._check(self.lib.e2v_comm_destroy(self.ctx))
+        self._comm_key = None
 
     def allgather_frames(self, frames: torch.Tensor, as_uint8: bool = False) -> torch.Tensor:
         """``[b,3,F,H,W]`` fp32 frames of this rank -> ``[world*b,3,F,H,W]`` of all ranks (fp32 or uint8), one ``ncclAllGather``

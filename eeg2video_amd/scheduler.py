@@ -426,7 +426,10 @@ def scheduler_from_config(config: dict, engine=None):
     #: key -> the only value(s) implemented (diffusers 0.11.1 defaults of the Stable-Diffusion configs)
     only = {"prediction_type": ("epsilon",), "trained_betas": (None,), "thresholding": (False,), "set_alpha_to_one": (False,),
             "beta_schedule": ("scaled_linear",), "variance_type": (None, "fixed_small"),
-            "rescale_betas_zero_snr": (False,), "timestep_spacing": ("leading",), "use_karras_sigmas": (False,)}
+            "rescale_betas_zero_snr": (False,), "use_karras_sigmas": (False,),
+            # the spacing each 0.11.1 class implements (and newer diffusers write into its config as the default): DDIM / PNDM step
+            # through multiples of T // n ("leading"), the sigma-space schedulers and DPM-Solver++ through linspace(0, T - 1, .)
+            "timestep_spacing": ("leading",) if name in ("DDIMScheduler", "PNDMScheduler") else ("linspace",)}
     for k, ok in only.items():
         if k in config and config[k] not in ok:
             raise NotImplementedError(f"{name}: {k}={config[k]!r} is not implemented on this path (supported: {ok})")

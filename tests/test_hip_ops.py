@@ -281,6 +281,36 @@ def test_temporal_attention(eng, d, f, hw):
     close(y, ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("d,f,hw", [(40, 6, 50), (80, 6, 33), (160, 6, 7)])
+def test_temporal_attention_wave_kernel_vs_staged_kernel(eng, mode, d, f, hw):
+    """attn_temp (attention.py:261-267) has two kernels: temporal_attn_wave_kernel (registers only, the default) and the LDS-staged
+    one behind E2V_TATTN_WAVE = 0.  Same-process A/B through the knob table: both against the reference, and against each other to
+    summation order (fp32) / one output rounding (bf16)."""
+    heads, n = 8, 2
+    c = heads * d
+    qkv = rnd(n * f * hw, 3 * c, seed=254)
+    src = qkv.to(torch.bfloat16).float() if mode == "bf16" else qkv
+    t = src.reshape(n, f, hw, 3 * c).permute(0, 2, 1, 3).reshape(n * hw, f, 3 * c)
+    q, k, v = t[..., :c], t[..., c:2 * c], t[..., 2 * c:]
+    ref = _unheads(_ref_attn(_heads(q, heads), _heads(k, heads), _heads(v, heads), d ** -0.5), heads)
+    ref = ref.reshape(n, hw, f, c).permute(0, 2, 1, 3).reshape(n * f * hw, c)
+    try:
+        eng.set_compute_dtype(mode)
+        g = qkv.cuda()
+        run = lambda: eng.op_temporal_attention(g, n=n, F=f, HW=hw, heads=heads, D=d, scale=d ** -0.5)
+        wave = run()
+        eng.set_knob("E2V_TATTN_WAVE", 0)
+        staged = run()
+    finally:
+        eng.set_knob("E2V_TATTN_WAVE", 1)
+        eng.set_compute_dtype("fp32")
+    tol = 8e-3 if mode == "bf16" else 1e-4
+    close(wave, ref, rtol=tol, atol=tol)
+    close(staged, ref, rtol=tol, atol=tol)
+    close(wave, staged, rtol=tol, atol=tol)
+
+
 # ------------------------------------------------------------------ bf16-activation mode (BASELINE configs[2]) -------
 # e2v_set_compute_dtype(E2V_BF16): the op entry points round their fp32 operands to bf16 once and run the kernels the graph
 # runs in that mode (bgemm.hip LDS-DMA tiles, flash_attn_b16io, the bf16-I/O norm kernels).  GEMM-shaped ops return fp32, so

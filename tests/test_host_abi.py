@@ -208,6 +208,13 @@ def test_scheduler_config_with_unsupported_arithmetic_is_refused():
         scheduler_from_config(dict(base, trained_betas=[0.1, 0.2]))
     with pytest.raises(NotImplementedError, match="set_alpha_to_one"):
         scheduler_from_config(dict(base, set_alpha_to_one=True))
+    # timestep_spacing: per class, the spacing that class implements (newer diffusers write the default into the config)
+    for cls, ok, bad in (("DDIMScheduler", "leading", "linspace"), ("PNDMScheduler", "leading", "trailing"),
+                         ("EulerDiscreteScheduler", "linspace", "leading"), ("EulerAncestralDiscreteScheduler", "linspace", "trailing"),
+                         ("LMSDiscreteScheduler", "linspace", "leading"), ("DPMSolverMultistepScheduler", "linspace", "leading")):
+        assert type(scheduler_from_config(dict(base, _class_name=cls, timestep_spacing=ok))).__name__ == cls
+        with pytest.raises(NotImplementedError, match="timestep_spacing"):
+            scheduler_from_config(dict(base, _class_name=cls, timestep_spacing=bad))
     with pytest.raises(NotImplementedError, match="thresholding"):
         scheduler_from_config(dict(base, _class_name="DPMSolverMultistepScheduler", thresholding=True))
     with pytest.raises(ValueError):
