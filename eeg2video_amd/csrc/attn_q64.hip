@@ -331,8 +331,10 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnAr
 //   * Three LDS stages of 64 keys: during stage s the waves read V of stage s, K of stage s + 1 (scores run one tile ahead) and, at
 //     its end, write stage s + 2 -- one barrier per 64 keys.
 //   * P is bounded as before: a reference moves when a score tops it by more than 2^8.
-template <int NW, int WPE>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void flash_attn_b16q64p_kernel(const AttnArgs p) {
+// (Pinning the interleave of an iteration with sched_group_barrier -- one MFMA, 3 v_exp_f32 + 1-2 conversions, ... -- made the
+// scheduler give up and bunch eight MFMAs back to back; the compiler's own interleave of the single basic block is the one kept.)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn_b16q64p_kernel(const AttnArgs p) {
     constexpr int D = 40;
     typedef Q64Layout<D> L;
     static_assert(L::DP > D, "the maximum rides in a spare k slot");
@@ -602,16 +604,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     }
 }
 
-template <int NW, int WPE>
+template <int NW>
 static void launch_q64p(const AttnArgs& a, hipStream_t s) {
     typedef Q64Layout<40> L;
     static bool configured = false;
     constexpr size_t smem = 3 * (size_t)L::STAGE;
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_b16q64p_kernel<NW, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_b16q64p_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         configured = true;
     }
-    hipLaunchKernelGGL((flash_attn_b16q64p_kernel<NW, WPE>), dim3(q64_grid(a, 64 * NW)), dim3(64 * NW), smem, s, a);
+    hipLaunchKernelGGL((flash_attn_b16q64p_kernel<NW>), dim3(q64_grid(a, 64 * NW)), dim3(64 * NW), smem, s, a);
 }
 
 template <int D, int NW>
@@ -650,8 +652,7 @@ bool flash_attention_q64(const AttnArgs& a, hipStream_t s) {
     const double probs = (double)a.n * a.F * a.heads;
     ProfScope ps("flash_attn_bf16_sparse_causal", 4.0 * probs * a.Nq * 2.0 * a.Nk * a.D, 2.0 * probs * a.D * (2.0 * a.Nq + 2.0 * a.Nk), s);
     static const int* const pipelined = knob("E2V_ATTN_Q64P", 1);      // 0: the phase-by-phase form of the 64-query kernel
-    if (a.D == 40 && *pipelined == 2) { if (nw == 4) launch_q64p<4, 1>(a, s); else if (nw == 3) launch_q64p<3, 1>(a, s); else launch_q64p<2, 1>(a, s); }
-    else if (a.D == 40 && *pipelined) { if (nw == 4) launch_q64p<4, 2>(a, s); else if (nw == 3) launch_q64p<3, 2>(a, s); else launch_q64p<2, 2>(a, s); }
+    if (a.D == 40 && *pipelined) { if (nw == 4) launch_q64p<4>(a, s); else if (nw == 3) launch_q64p<3>(a, s); else launch_q64p<2>(a, s); }
     else if (a.D == 40) { if (nw == 4) launch_q64<40, 4>(a, s); else if (nw == 3) launch_q64<40, 3>(a, s); else launch_q64<40, 2>(a, s); }
     else           { if (nw == 4) launch_q64<80, 4>(a, s); else if (nw == 3) launch_q64<80, 3>(a, s); else launch_q64<80, 2>(a, s); }
     return true;

@@ -423,7 +423,7 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
                         f32x4 y;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            y[e] = (acc[h][mt][nt][e] * p.alpha + bv[e]) * gelu_erf(acc[h][mt][nt + 2][e] * p.alpha + bg[e]);
+                            y[e] = (acc[h][mt][nt][e] * p.alpha + bv[e]) * gelu_bf16_grade(acc[h][mt][nt + 2][e] * p.alpha + bg[e]);
                         *reinterpret_cast<f32x4*>(st + (t * 16 + fl) * SLD + nt * 16 + 4 * fq) = y;
                     }
                 }
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            yg[nt][e] = (acc[h][mt][nt][e] * p.alpha + bias[nt][e]) * gelu_erf(acc[h][mt][nt + 2][e] * p.alpha + bias[nt + 2][e]);
+                            yg[nt][e] = (acc[h][mt][nt][e] * p.alpha + bias[nt][e]) * gelu_bf16_grade(acc[h][mt][nt + 2][e] * p.alpha + bias[nt + 2][e]);
                     if constexpr (F32IO) { store4(yg[0], vo, 0); store4(yg[1], vo, 1); }
                     else store_pair(yg[0], yg[1], vop0 + (unsigned)(h * 64 + mt * 16) * p.ldc * 2u, 0);
                     __builtin_amdgcn_sched_barrier(0);       // one (half, row tile) at a time

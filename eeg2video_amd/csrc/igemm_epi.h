@@ -26,6 +26,20 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// The same gate in the bf16-activation mode, where the product value * gelu(gate) is rounded to bf16 (2^-9 relative) on its way out:
+// gelu(x) = x Phi(x) with the normal CDF as a logistic of an odd cubic, Phi(x) ~ 1 / (1 + exp(-(a x + b x^3))), a = 1.60031415,
+// b = 0.06940179 (minimax fit of x Phi(x) over the real line; monotone, so no clamp): |gelu error| <= 2.8e-4 = 1/14 of the rounding
+// of a bf16 value near 1 (bound restated in tests/test_oracle_anchors.py).  Five plain vector instructions + v_exp_f32 + v_rcp_f32 instead
+// of thirteen + two: the GEGLU 320 -> 2560 tiles of a B = 32 pass spent as long in this epilogue (64 gates per lane) as in their five
+// K steps.  fp32 mode keeps gelu_erf above.
+__device__ __forceinline__ float gelu_bf16_grade(float x) {
+    const float u = x * x;
+    const float t = x * fmaf(-0.06940179f * 1.44269504088896340736f, u, -1.60031415f * 1.44269504088896340736f);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+}
+// (fast: wave-uniform, IgemmArgs::a_bf16 -- the arithmetic mode, never the kernel or the batch, picks the form)
+__device__ __forceinline__ float gelu_gate(float x, const bool fast) { return fast ? gelu_bf16_grade(x) : gelu_erf(x); }
+
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -57,7 +71,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
                         f32x4 y;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_erf(acc[mi][1][4 * g + e] * p.alpha + bg[e]);
+                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + bg[e], p.a_bf16 != 0);
                         *reinterpret_cast<f32x4*>(st + mrow * SLD + 8 * g + nq) = y;
                     }
 #pragma unroll
@@ -171,7 +185,7 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
                         f32x4 y;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_erf(acc[mi][1][4 * g + e] * p.alpha + bg[e]);
+                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + bg[e], p.a_bf16 != 0);
                         *reinterpret_cast<f32x4*>(st + mrow * SLD + 8 * g + nq) = y;
                     }
 #pragma unroll
@@ -362,7 +376,7 @@ struct BgEpilogue {
                         f32x4 y;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + gv[g][e]) * gelu_erf(acc[mi][1][4 * g + e] * p.alpha + gg[g][e]);
+                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + gv[g][e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + gg[g][e], p.a_bf16 != 0);
                         *reinterpret_cast<f32x4*>(st + mrow * 32 + (((2 * g + (lane >> 5)) ^ wsw) << 2)) = y;
                     }
 #pragma unroll

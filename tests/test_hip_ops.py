@@ -327,6 +327,12 @@ def rb(t):
     return t.to(torch.bfloat16).float()
 
 
+def gelu_bf16_grade(x):
+    """The GEGLU gate of the bf16-activation mode as the kernels evaluate it (igemm_epi.h: gelu_bf16_grade): x / (1 + exp(-(a x + b x^3))),
+    |error| <= 2.8e-4 against the exact erf form (bounded in tests/test_oracle_anchors.py)."""
+    return x / (1.0 + torch.exp(-(1.60031415 * x + 0.06940179 * x ** 3)))
+
+
 def test_bf16_conv_and_linear(bf):
     n, c, h, w = 2, 64, 9, 12
     x, wt, b = rnd(n, c, h, w, seed=60), rnd(128, c, 3, 3, seed=61, scale=0.1), rnd(128, seed=62)
@@ -337,7 +343,9 @@ def test_bf16_conv_and_linear(bf):
     close(bf.op_linear(xl.cuda(), wl.cuda(), bl.cuda(), r.cuda()), F.linear(rb(xl), rb(wl), bl) + r, rtol=1e-4, atol=1e-4)
     xg, wg, bg = rnd(200, 64, seed=67), rnd(512, 64, seed=68, scale=0.1), rnd(512, seed=69)
     hh, gg = F.linear(rb(xg), rb(wg), bg).chunk(2, dim=-1)
-    close(bf.op_linear(xg.cuda(), wg.cuda(), bg.cuda(), geglu=True), hh * F.gelu(gg), rtol=1e-4, atol=1e-4)
+    yg = bf.op_linear(xg.cuda(), wg.cuda(), bg.cuda(), geglu=True)
+    close(yg, hh * gelu_bf16_grade(gg), rtol=1e-4, atol=1e-4)           # the kernel's own gate formula: summation order only
+    close(yg, hh * F.gelu(gg), rtol=4e-4, atol=4e-4)                    # the exact erf form: + |value| x 2.8e-4 of the gate approximation
     # input channels not a multiple of 8 (conv_in: 4 latent channels): zero-padded to the 16-byte granule, still bf16
     x4, w4 = rnd(1, 4, 5, 6, seed=70), rnd(64, 4, 3, 3, seed=71)
     close(from_cl(bf.op_conv3x3(to_cl(x4).cuda(), w4.cuda(), n_img=1, Hs=5, Ws=6), 1, 5, 6), F.conv2d(rb(x4), rb(w4), padding=1),
@@ -617,7 +625,8 @@ def test_bf16_t256_geglu(bf256, m, k, n):
             outs.append(bf.op_linear(x.cuda(), w.cuda(), b.cuda(), geglu=True))
         finally:
             bf.set_knob("E2V_BGEMM_T256P", 1)
-    close(outs[0], hh * F.gelu(gg), rtol=1e-4, atol=1e-4)
+    close(outs[0], hh * gelu_bf16_grade(gg), rtol=1e-4, atol=1e-4)
+    close(outs[0], hh * F.gelu(gg), rtol=4e-4, atol=4e-4)
     assert torch.equal(outs[0], outs[1])
 
 

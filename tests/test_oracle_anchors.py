@@ -95,6 +95,13 @@ def test_geglu_is_erf_gelu_and_the_kernel_erf_is_within_its_bound():
     erf_as = 1.0 - poly * np.exp(-z * z)
     erf_exact = np.array([math.erf(v) for v in z[::100]])
     assert np.max(np.abs(erf_as[::100] - erf_exact)) <= 1.5e-7
+    # bf16-activation mode: the gate as a logistic of an odd cubic (igemm_epi.h: gelu_bf16_grade), restated in fp64: within 2.8e-4 of
+    # x Phi(x) on the whole line (1/14 of the rounding of a bf16 value near 1), exact limits 0 and x at -inf / +inf
+    xs = np.linspace(-40.0, 40.0, 800001)
+    fast = xs / (1.0 + np.exp(-(1.60031415 * xs + 0.06940179 * xs ** 3)))
+    exact = 0.5 * xs * (1.0 + np.array([math.erf(v / math.sqrt(2.0)) for v in xs]))
+    assert np.max(np.abs(fast - exact)) <= 2.8e-4
+    assert abs(fast[0]) < 1e-30 and fast[-1] == xs[-1]
 
 
 @pytest.mark.parametrize("t", [1, 501, 981])
