@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 #include <mutex>
 
 #include "../../include/eeg2video_hip_ops.h"
@@ -17,7 +18,7 @@ std::string g_create_error;
 template <typename Fn>
 e2v_status guarded(e2v_ctx* ctx, Fn&& fn) {
     try {
-        if (ctx) {
+        if (ctx && !dry_run()) {                             // (a dry run -- e2v_op_describe_dispatch -- makes no HIP call)
             E2V_REQUIRE(ctx->device >= 0, E2V_ESTATE, "host-only context (device = -1): no GPU work possible");
             E2V_HIP(hipSetDevice(ctx->device));
         }
@@ -551,6 +552,43 @@ e2v_status e2v_generate(e2v_ctx* c, const float* latents, const float* cond, con
         }
         E2V_HIP(hipGetLastError());
     });
+}
+
+// ---- which kernel and tile every launch of a configuration takes, without a GPU -----------------------------------------------------
+// Runs e2v_generate (one DDIM step with guidance + decode) of B clips of [4, F, h, w] latents as a DRY RUN on a host-only ctx: the
+// graph walker, the launch rules of every launcher and the per-layer decisions execute exactly as in a real call, no HIP call is
+// made, and every launch leaves one record "class shape -> kernel tile".  Output: one line per distinct record in first-occurrence
+// order, "<count>x <record>\n".  A rule change shows up as a diff of this text (tests/golden/dispatch_sd_v1_4.json).
+e2v_status e2v_op_describe_dispatch(e2v_ctx* c, int dtype, int B, int F, int h, int w, int T, char* buf, int64_t cap, int64_t* needed) {
+    if (!c || !needed || (dtype != E2V_F32 && dtype != E2V_BF16) || B <= 0 || F <= 0 || h <= 0 || w <= 0 || T <= 0 || (cap > 0 && !buf)) return E2V_EINVAL;
+    if (c->device >= 0) { c->err = "e2v_op_describe_dispatch runs on a host-only context (e2v_create(..., device = -1, ...))"; return E2V_ESTATE; }
+    struct Dry {
+        Dry() { dry_run() = true; dry_log().clear(); }
+        ~Dry() { dry_run() = false; dry_log().clear(); }
+    } dry;
+    e2v_status st = guarded(c, [&] {
+        if (!c->unet_ready || !c->vae_ready) c->finalize(3);
+    });
+    if (st != E2V_OK) return st;
+    const bool was_bf16 = c->bf16_compute;
+    c->bf16_compute = dtype == E2V_BF16;
+    dry_log().clear();
+    const float* fake = dry_fake_ptr(1 << 20);
+    st = e2v_generate(c, fake, fake, fake, 1, B, F, h, w, T, 1, 12.5f, 0.0f, dry_fake_ptr(1 << 20), nullptr, nullptr);
+    c->bf16_compute = was_bf16;
+    if (st != E2V_OK) return st;
+    std::vector<std::pair<std::string, long>> agg;
+    std::unordered_map<std::string, size_t> at;
+    for (const std::string& r : dry_log()) {
+        auto it = at.find(r);
+        if (it == at.end()) { at.emplace(r, agg.size()); agg.emplace_back(r, 1); }
+        else agg[it->second].second += 1;
+    }
+    std::string out;
+    for (const auto& kv : agg) out += std::to_string(kv.second) + "x " + kv.first + "\n";
+    *needed = (int64_t)out.size() + 1;
+    if (cap >= *needed) std::memcpy(buf, out.c_str(), out.size() + 1);
+    return E2V_OK;
 }
 
 // ---- building blocks of the schedulers other than DDIM (pipeline_tuneeeg2video.py:48-55) -----------

@@ -56,6 +56,12 @@ static inline unsigned attn_grid(const AttnArgs& a) {
     return 8u * ((a.n * a.F + 7) / 8) * (unsigned)a.heads * nqb;
 }
 
+// shape tag of a launch for the detailed profile / the dispatch record
+std::string attn_shape_tag(const AttnArgs& a) {
+    return " D" + std::to_string(a.D) + " Nq" + std::to_string(a.Nq) + " Nk" + std::to_string(a.Nk) + " n" + std::to_string(a.n) + " F" + std::to_string(a.F) +
+           " h" + std::to_string(a.heads);
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs p) {
     constexpr int LD = D + 4;               // padded LDS row: conflict-free ds_read_b128 of 16 rows
@@ -783,13 +789,16 @@ static bool launch_cross_resident(const AttnArgs& a, hipStream_t s) {
     const int chunks = (tiles + 4 * tpw - 1) / (4 * tpw);
     const unsigned grid = 8u * ((a.n + 7) / 8) * (unsigned)(a.heads * chunks);
     const double probs = (double)a.n * a.F * a.heads;
-    ProfScope ps("flash_attn_bf16_cross", 4.0 * probs * a.Nq * a.Nk * D, 2.0 * probs * D * (2.0 * a.Nq + 2.0 * (double)a.Nk / a.F), s);
+    std::string pname = "flash_attn_bf16_cross";
+    if (prof_detail()) pname += attn_shape_tag(a);
+    ProfScope ps(pname.c_str(), 4.0 * probs * a.Nq * a.Nk * D, 2.0 * probs * D * (2.0 * a.Nq + 2.0 * (double)a.Nk / a.F), s);
+    dry_tag(" -> cross_attn_resident_kernel tpw" + std::to_string(tpw));
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_resident_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         configured = true;
     }
-    hipLaunchKernelGGL(cross_attn_resident_kernel<D>, dim3(grid), dim3(256), smem, s, a, tpw, chunks);
+    E2V_KLAUNCH(cross_attn_resident_kernel<D>, dim3(grid), dim3(256), smem, s, a, tpw, chunks);
     return true;
 }
 
@@ -800,27 +809,32 @@ static void launch_flash_b16io(const AttnArgs& a, hipStream_t s) {
     auto stage_bytes = [](const int kt) { return ((size_t)kt * (DP * 2 + 16) + (size_t)kt * VROW + 15) / 16 * 16; };
     if (launch_cross_resident<D>(a, s)) return;
     if (flash_attention_q64(a, s)) return;               // 64 queries per wave (attn_q64.hip): d = 40 / 80 self-attention
-    static const int* const fold = knob("E2V_ATTN_FOLD", 1);     // 0: the plain form (scale and maximum applied by vector FMAs)
+    static const int* const fold = E2V_AB_KNOB("E2V_ATTN_FOLD", 1);     // 0: the plain form (scale and maximum applied by vector FMAs)
     static const int* const kt64 = knob("E2V_ATTN_KT64", 1);     // 0: 32-key stages (one barrier per 32 keys)
     dim3 grid(attn_grid(a), 1, 1);
     const double nk = a.mode == 0 ? 2.0 * a.Nk : (double)a.Nk;
     const double probs = (double)a.n * a.F * a.heads;
-    ProfScope ps(a.mode == 0 ? "flash_attn_bf16_sparse_causal" : "flash_attn_bf16_cross", 4.0 * probs * a.Nq * nk * D,
+    std::string pname = a.mode == 0 ? "flash_attn_bf16_sparse_causal" : "flash_attn_bf16_cross";
+    if (prof_detail()) pname += attn_shape_tag(a);
+    ProfScope ps(pname.c_str(), 4.0 * probs * a.Nq * nk * D,
                  2.0 * probs * D * (2.0 * a.Nq + 2.0 * (a.mode == 0 ? a.Nk : (double)a.Nk / a.F)), s);
     auto go = [&](auto kern, const int kt) {
+        dry_tag(std::string(" -> flash_attn_b16io_kernel") + (*fold ? " fold" : "") + " kt" + std::to_string(kt));
         static bool configured = false;
         const size_t smem = 2 * stage_bytes(kt);
         if (!configured) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * stage_bytes(64)));
             configured = true;
         }
-        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+        E2V_KLAUNCH(kern, grid, dim3(256), smem, s, a);
     };
     // 64-key stages halve the barriers per key, but at D = 160 two such stages are 84 KB and only one block fits a CU (measured: 224 vs
     // 344 TFLOP/s at the 12x12 level) -- keep them to the head sizes where three blocks still fit
     const bool wide = *kt64 && a.Nk > 32 && 2 * stage_bytes(64) <= 52 * 1024;
     if (*fold) { if (wide) go(flash_attn_b16io_kernel<D, true, 64>, 64); else go(flash_attn_b16io_kernel<D, true, 32>, 32); }
+#ifdef E2V_AB              // the plain form (scale and maximum by vector FMAs): the other arm of the A/B that adopted the fold
     else       { if (wide) go(flash_attn_b16io_kernel<D, false, 64>, 64); else go(flash_attn_b16io_kernel<D, false, 32>, 32); }
+#endif
 }
 
 // =====================================================================================================
@@ -1103,7 +1117,7 @@ static void launch_flash_x3(const AttnArgs& a, hipStream_t s) {
     const double probs = (double)a.n * a.F * a.heads;
     ProfScope ps(a.mode == 0 ? "flash_attn_f32x3_sparse_causal" : "flash_attn_f32x3_cross", 4.0 * probs * a.Nq * nk * D,
                  4.0 * probs * D * (2.0 * a.Nq + 2.0 * (a.mode == 0 ? a.Nk : (double)a.Nk / a.F)), s);
-    hipLaunchKernelGGL((flash_attn_x3_kernel<D>), grid, dim3(256), smem, s, a);
+    E2V_KLAUNCH((flash_attn_x3_kernel<D>), grid, dim3(256), smem, s, a);
 }
 
 template <int D>
@@ -1118,9 +1132,12 @@ static void launch_flash(const AttnArgs& a, hipStream_t s) {
     dim3 grid(attn_grid(a), 1, 1);
     const double nk = a.mode == 0 ? 2.0 * a.Nk : (double)a.Nk;       // the reference attends to 2N concatenated keys
     const double probs = (double)a.n * a.F * a.heads;
-    ProfScope ps(a.mode == 0 ? "flash_attn_sparse_causal" : "flash_attn_cross", 4.0 * probs * a.Nq * nk * D,
+    std::string pname = a.mode == 0 ? "flash_attn_sparse_causal" : "flash_attn_cross";
+    if (prof_detail()) pname += attn_shape_tag(a);
+    ProfScope ps(pname.c_str(), 4.0 * probs * a.Nq * nk * D,
                  4.0 * probs * D * (2.0 * a.Nq + 2.0 * (a.mode == 0 ? a.Nk : (double)a.Nk / a.F)), s);
-    hipLaunchKernelGGL((flash_attn_kernel<D>), grid, dim3(256), smem, s, a);
+    dry_tag(" -> flash_attn_kernel");
+    E2V_KLAUNCH((flash_attn_kernel<D>), grid, dim3(256), smem, s, a);
 }
 
 bool flash_attention_supports(int D) {
@@ -1383,7 +1400,7 @@ __global__ __launch_bounds__(256) void temporal_attn_wave_kernel(const T* __rest
     const T* base = qkv + ((size_t)(smp * F) * HW + pix) * ld + head * D + (c < CH ? c : 0) * 8;
     const size_t fs = (size_t)HW * ld;
     typedef float f8 __attribute__((ext_vector_type(8)));
-    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     auto ld16 = [&](const T* p) -> u4 { return on ? *reinterpret_cast<const u4*>(p) : u4{0u, 0u, 0u, 0u}; };
     auto ld8f = [&](const T* p) -> f8 {
@@ -1494,7 +1511,7 @@ static bool temporal_wave_launch(const T* qkv, int ld, T* out, int ldo, int n, i
     if (F != 6 || lpp > 256 || 256 % lpp || (ld % 8) || (ldo % 8)) return false;
     const long npix = (long)n * HW;
     const int ppb = 256 / lpp;
-    hipLaunchKernelGGL((temporal_attn_wave_kernel<T, 6, D>), dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, s, qkv, ld, out, ldo, HW, npix, heads,
+    E2V_KLAUNCH((temporal_attn_wave_kernel<T, 6, D>), dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, s, qkv, ld, out, ldo, HW, npix, heads,
                        scale);
     return true;
 }
@@ -1507,7 +1524,9 @@ void temporal_attention(const float* qkv, int ld, float* out, int ldo, int n, in
                         hipStream_t s, int bf16) {
     const size_t total = (size_t)n * HW * heads * F;
     if (!total) return;
-    ProfScope ps("temporal_attn", 4.0 * total * F * D, 4.0 * (bf16 ? 2.0 : 4.0) * (double)n * F * HW * heads * D, s);
+    std::string pname = "temporal_attn";
+    if (prof_detail()) pname += " n" + std::to_string(n) + " F" + std::to_string(F) + " HW" + std::to_string(HW) + " h" + std::to_string(heads) + " D" + std::to_string(D);
+    ProfScope ps(pname.c_str(), 4.0 * total * F * D, 4.0 * (bf16 ? 2.0 : 4.0) * (double)n * F * HW * heads * D, s);
     if (bf16)
         temporal_attention_launch(reinterpret_cast<const __bf16*>(qkv), ld, reinterpret_cast<__bf16*>(out), ldo, n, F, HW, heads, D, scale, s);
     else
@@ -1532,8 +1551,9 @@ static void temporal_attention_launch(const T* qkv, int ld, T* out, int ldo, int
             case 160: done = temporal_wave_launch<T, 160>(qkv, ld, out, ldo, n, F, HW, heads, scale, s); break;
             default: break;
         }
-        if (done) return;
+        if (done) { dry_tag(" -> temporal_attn_wave_kernel"); return; }
     }
+    dry_tag(" -> temporal_attn_lds_kernel");
     // slab of whole heads and pixel count such that the staged q/k/v (fp32 in LDS whatever the storage type) fit 16 KB: with
     // 48 KB (3 blocks of 2 waves per CU) the load phase had too little in flight -- 0.60 -> 0.33 ms at level 0
     static const size_t budget = [] { const char* e = std::getenv("E2V_TATTN_LDS_KB"); return (size_t)(e ? std::atoi(e) : 16) * 1024; }();
@@ -1545,12 +1565,12 @@ static void temporal_attention_launch(const T* qkv, int ld, T* out, int ldo, int
     PB = PB < 1 ? 1 : (PB > 8 ? 8 : PB);
     const size_t smem = (size_t)F * PB * 3 * CS * 4;
     if (smem > 64 * 1024) {           // does not fit the default LDS window: per-thread global version
-        hipLaunchKernelGGL(temporal_attn_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv, ld, out, ldo, n, F, HW,
+        E2V_KLAUNCH(temporal_attn_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv, ld, out, ldo, n, F, HW,
                            heads, D, scale);
         return;
     }
     const int npg = (HW + PB - 1) / PB;
-    hipLaunchKernelGGL(temporal_attn_lds_kernel<T>, dim3((unsigned)(n * npg), C / CS), dim3(128), smem, s, qkv, ld, out, ldo, F, HW, C,
+    E2V_KLAUNCH(temporal_attn_lds_kernel<T>, dim3((unsigned)(n * npg), C / CS), dim3(128), smem, s, qkv, ld, out, ldo, F, HW, C,
                        D, scale, PB, CS, npg);
 }
 
@@ -1591,7 +1611,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
 void softmax_rows(float* x, int ld, int rows, int cols, hipStream_t s, void* out_bf16) {
     if (rows <= 0) return;
     ProfScope ps("softmax_rows", 8.0 * rows * cols, (out_bf16 ? 10.0 : 12.0) * rows * (double)cols, s);
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, x, ld, rows, cols, static_cast<__bf16*>(out_bf16));
+    E2V_KLAUNCH(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, x, ld, rows, cols, static_cast<__bf16*>(out_bf16));
 }
 
 }  // namespace e2v

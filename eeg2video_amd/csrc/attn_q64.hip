@@ -21,6 +21,7 @@
 #include "runtime.h"
 
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 
 namespace e2v {
@@ -71,6 +72,7 @@ struct Q64Layout {
     static constexpr int STAGE = (KBYTES + VBYTES + 15) / 16 * 16;
 };
 
+#ifdef E2V_AB          // the phase-by-phase form (E2V_ATTN_Q64P = 0; d = 80 with E2V_ATTN_Q64 = 2): the other arm of the A/B
 template <int D, int NW>
 __global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnArgs p) {
     static_assert(D % 32 != 0 && D % 8 == 0, "the denominator rides in a spare row of the last O^T tile");
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnAr
         }
     }
 }
+#endif
 
 
 // ---- software-pipelined form (d = 40) -------------------------------------------------------------------------------------------
@@ -613,9 +616,10 @@ static void launch_q64p(const AttnArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_b16q64p_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         configured = true;
     }
-    hipLaunchKernelGGL((flash_attn_b16q64p_kernel<NW>), dim3(q64_grid(a, 64 * NW)), dim3(64 * NW), smem, s, a);
+    E2V_KLAUNCH((flash_attn_b16q64p_kernel<NW>), dim3(q64_grid(a, 64 * NW)), dim3(64 * NW), smem, s, a);
 }
 
+#ifdef E2V_AB
 template <int D, int NW>
 static void launch_q64(const AttnArgs& a, hipStream_t s) {
     typedef Q64Layout<D> L;
@@ -625,8 +629,9 @@ static void launch_q64(const AttnArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_b16q64_kernel<D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         configured = true;
     }
-    hipLaunchKernelGGL((flash_attn_b16q64_kernel<D, NW>), dim3(q64_grid(a, 64 * NW)), dim3(64 * NW), smem, s, a);
+    E2V_KLAUNCH((flash_attn_b16q64_kernel<D, NW>), dim3(q64_grid(a, 64 * NW)), dim3(64 * NW), smem, s, a);
 }
+#endif
 
 // Which (if any) instance of the 64-queries-per-wave kernel serves the call: waves per workgroup, 0 = none (the caller falls back to
 // flash_attn_b16io_kernel).  A rule of the SHAPE only (never of the batch: the two kernels round differently, and a clip's bits must
@@ -634,9 +639,14 @@ static void launch_q64(const AttnArgs& a, hipStream_t s) {
 int flash_attention_q64_waves(const AttnArgs& a) {
     // 0: every bf16 self-attention through flash_attn_b16io_kernel; 1: d = 40 here; 2: d = 80 as well (287+ registers: one wave per SIMD)
     static const int* const on = knob("E2V_ATTN_Q64", 1);
-    if (!*on || !a.io_bf16 || a.mode != 0 || !(a.D == 40 || (a.D == 80 && *on >= 2)) || a.Nk <= 32) return 0;
+#ifdef E2V_AB
+    const bool d80 = a.D == 80 && *on >= 2;
+#else
+    const bool d80 = false;
+#endif
+    if (!*on || !a.io_bf16 || a.mode != 0 || !(a.D == 40 || d80) || a.Nk <= 32) return 0;
     if (a.Nq < 128) return 0;
-    static const int* const force_nw = knob("E2V_ATTN_Q64_NW", 0);     // 2..4: that many waves per workgroup whatever the padding (A/B)
+    static const int* const force_nw = E2V_AB_KNOB("E2V_ATTN_Q64_NW", 0);     // 2..4: that many waves per workgroup whatever the padding (A/B)
     if (*force_nw >= 2 && *force_nw <= 4) return *force_nw;
     int best = 0, waste = 1 << 30;
     for (int nw = 4; nw >= 2; --nw) {                              // least padding of the last query block; ties: the larger workgroup
@@ -650,11 +660,16 @@ bool flash_attention_q64(const AttnArgs& a, hipStream_t s) {
     const int nw = flash_attention_q64_waves(a);
     if (!nw) return false;
     const double probs = (double)a.n * a.F * a.heads;
-    ProfScope ps("flash_attn_bf16_sparse_causal", 4.0 * probs * a.Nq * 2.0 * a.Nk * a.D, 2.0 * probs * a.D * (2.0 * a.Nq + 2.0 * a.Nk), s);
-    static const int* const pipelined = knob("E2V_ATTN_Q64P", 1);      // 0: the phase-by-phase form of the 64-query kernel
+    std::string pname = "flash_attn_bf16_sparse_causal";
+    if (prof_detail()) pname += attn_shape_tag(a);
+    ProfScope ps(pname.c_str(), 4.0 * probs * a.Nq * 2.0 * a.Nk * a.D, 2.0 * probs * a.D * (2.0 * a.Nq + 2.0 * a.Nk), s);
+    static const int* const pipelined = E2V_AB_KNOB("E2V_ATTN_Q64P", 1);      // 0: the phase-by-phase form of the 64-query kernel
+    dry_tag(std::string(a.D == 40 && *pipelined ? " -> flash_attn_b16q64p_kernel" : " -> flash_attn_b16q64_kernel") + " w" + std::to_string(nw));
     if (a.D == 40 && *pipelined) { if (nw == 4) launch_q64p<4>(a, s); else if (nw == 3) launch_q64p<3>(a, s); else launch_q64p<2>(a, s); }
+#ifdef E2V_AB
     else if (a.D == 40) { if (nw == 4) launch_q64<40, 4>(a, s); else if (nw == 3) launch_q64<40, 3>(a, s); else launch_q64<40, 2>(a, s); }
     else           { if (nw == 4) launch_q64<80, 4>(a, s); else if (nw == 3) launch_q64<80, 3>(a, s); else launch_q64<80, 2>(a, s); }
+#endif
     return true;
 }
 

@@ -14,6 +14,7 @@
 // Tiles 128x128 and 128x64 (4 waves as 2x2), dealt to the XCDs by the same schedule as the fp32 kernel (igemm.hip).
 #include "igemm_epi.h"
 #include "prof.h"
+#include "runtime.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -41,7 +42,13 @@ bool set_knob(const char* name, int value) {
     auto& t = knob_table();
     auto it = t.find(name);
     if (it == t.end()) {
-        static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_S3", "E2V_BGEMM_256LIN", "E2V_BGEMM_256_MINROUNDS", "E2V_BGEMM_256", "E2V_BGEMM_LIN", "E2V_BGEMM_T256", "E2V_BGEMM_T256_MINK", "E2V_BGEMM_T256_MINTILES", "E2V_BGEMM_T256P", "E2V_BGEMM_T256P_MAXK", "E2V_BGEMM_T256P_MINTILES", "E2V_BGEMM_T256_TAIL", "E2V_BGEMM_T256P_BIAS_LDS", "E2V_ATTN_FOLD", "E2V_ATTN_KT64", "E2V_ATTN_Q64", "E2V_ATTN_Q64P", "E2V_ATTN_Q64_NW", "E2V_ATTN_CROSS_RESIDENT", "E2V_TATTN_WAVE", "E2V_GN_ROWS", "E2V_GN_GROUP_MB", "E2V_GN_CHUNK_ROWS", "E2V_GN_CHUNK_ROWS_SMALL", "E2V_LN_ROWS", "E2V_BGEMM_UP2X"
+        static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_256LIN", "E2V_BGEMM_256_MINROUNDS", "E2V_BGEMM_256", "E2V_BGEMM_T256",
+                                            "E2V_BGEMM_T256_MINK", "E2V_BGEMM_T256_MINTILES", "E2V_BGEMM_T256P", "E2V_BGEMM_T256P_MAXK", "E2V_BGEMM_T256P_MINTILES",
+                                            "E2V_BGEMM_T256P_BIAS_LDS", "E2V_ATTN_KT64", "E2V_ATTN_Q64", "E2V_ATTN_CROSS_RESIDENT", "E2V_TATTN_WAVE",
+                                            "E2V_GN_CHUNK_ROWS", "E2V_GN_CHUNK_ROWS_SMALL", "E2V_LN_ROWS", "E2V_BGEMM_UP2X"
+#ifdef E2V_AB                                // variants measured and not adopted / the other arm of an A/B: `make AB=1` builds only
+                                            , "E2V_BGEMM_S3", "E2V_BGEMM_LIN", "E2V_BGEMM_T256_TAIL", "E2V_ATTN_FOLD", "E2V_ATTN_Q64P", "E2V_ATTN_Q64_NW", "E2V_GN_ROWS", "E2V_GN_GROUP_MB"
+#endif
 #ifdef E2V_ABLATE
                                             , "E2V_BGEMM_ABLATE"
 #endif
@@ -838,6 +845,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const IgemmArgs p) {
 }
 
 // 256-row tiles: 8 waves (4 x 2, the same 64 x 64 wave tile), 256 x 128 and 256 x 64, 48 KB stages, one workgroup per CU.
+#ifdef E2V_AB          // the two-stage form of the 256-row tile (E2V_BGEMM_S3 = 0): the other arm of the A/B that adopted the three-stage ring
 template <bool LIN>
 __global__ __launch_bounds__(512) void bgemm256_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_bg256[];
@@ -859,6 +867,7 @@ __global__ __launch_bounds__(512) void bgemm256_kernel(const IgemmArgs p) {
         bgemm_tile<256, 64, 4, 2, ST, LIN>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_bg256);
     }
 }
+#endif
 
 // (A variant with one A stage per KERNEL ROW -- the input pixels under output pixels m0-1 .. m0+256 fetched once per ky and read at
 // LDS rows r + kx by the three taps of that row, image-row ends zeroed in registers: activations fetched 3x instead of 9x, L2
@@ -941,12 +950,12 @@ void bgemm_launch(const IgemmArgs& a_in, int ntiles, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         configured = true;
     }
-    static const int* const lean = knob("E2V_BGEMM_LIN", 1);        // 0: linears through the gather path
+    static const int* const lean = E2V_AB_KNOB("E2V_BGEMM_LIN", 1);        // 0: linears through the gather path
     const bool lin = a.taps == 1 && *lean;
     const double K = (double)a.taps * (a.c0 + a.c1);
     const double rows_in = a.taps == 1 ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
     std::string pname = "igemm_bf16";
-    if (profiler().on && profiler().detail)
+    if (prof_detail())
         pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t" + std::to_string(a.taps) +
                  (a.stride > 1 ? " s2" : "") + (a.upsample ? " up" : "") + (a.c1 ? " cat" : "") + (a.geglu ? " geglu" : "") +
                  (a.batch > 1 ? " b" + std::to_string(a.batch) : "");
@@ -978,11 +987,12 @@ void bgemm_launch(const IgemmArgs& a_in, int ntiles, hipStream_t s) {
             cfgp = true;
         }
         const int grid = ntiles < 512 ? ntiles : 512;                                             // two workgroups per CU
-        if (lin) hipLaunchKernelGGL(bgemm_pers_kernel<true>, dim3(grid, 1, 1), dim3(256), smem_p, s, a);
-        else hipLaunchKernelGGL(bgemm_pers_kernel<false>, dim3(grid, 1, 1), dim3(256), smem_p, s, a);
+        dry_tag(" -> bgemm_pers_kernel 128x128");
+        if (lin) E2V_KLAUNCH(bgemm_pers_kernel<true>, dim3(grid, 1, 1), dim3(256), smem_p, s, a);
+        else E2V_KLAUNCH(bgemm_pers_kernel<false>, dim3(grid, 1, 1), dim3(256), smem_p, s, a);
         return;
     }
-    static const int* const s3p = knob("E2V_BGEMM_S3", 1);          // 256-row tiles on a three-stage ring
+    static const int* const s3p = E2V_AB_KNOB("E2V_BGEMM_S3", 1);          // 256-row tiles on a three-stage ring
     if (a.bm256 && *s3p && (a.taps == 9 || lin)) {
         constexpr size_t smem256s3 = (size_t)3 * (256 + 128) * 128 + 9 * 256 * sizeof(unsigned);
         static bool cfg256s3 = false;
@@ -991,10 +1001,12 @@ void bgemm_launch(const IgemmArgs& a_in, int ntiles, hipStream_t s) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm256s3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem256s3);
             cfg256s3 = true;
         }
-        if (lin) hipLaunchKernelGGL(bgemm256s3_kernel<true>, dim3(ntiles, 1, 1), dim3(512), smem256s3, s, a);
-        else hipLaunchKernelGGL(bgemm256s3_kernel<false>, dim3(ntiles, 1, 1), dim3(512), smem256s3, s, a);
+        dry_tag(" -> bgemm256s3_kernel 256x128");
+        if (lin) E2V_KLAUNCH(bgemm256s3_kernel<true>, dim3(ntiles, 1, 1), dim3(512), smem256s3, s, a);
+        else E2V_KLAUNCH(bgemm256s3_kernel<false>, dim3(ntiles, 1, 1), dim3(512), smem256s3, s, a);
         return;
     }
+#ifdef E2V_AB
     if (a.bm256) {
         constexpr size_t smem256 = (size_t)2 * (256 + 128) * 128 + 9 * 256 * sizeof(unsigned);
         static bool cfg256 = false;
@@ -1003,10 +1015,14 @@ void bgemm_launch(const IgemmArgs& a_in, int ntiles, hipStream_t s) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem256);
             cfg256 = true;
         }
-        if (lin) hipLaunchKernelGGL(bgemm256_kernel<true>, dim3(ntiles, 1, 1), dim3(512), smem256, s, a);
-        else hipLaunchKernelGGL(bgemm256_kernel<false>, dim3(ntiles, 1, 1), dim3(512), smem256, s, a);
+        dry_tag(" -> bgemm256_kernel 256x128");
+        if (lin) E2V_KLAUNCH(bgemm256_kernel<true>, dim3(ntiles, 1, 1), dim3(512), smem256, s, a);
+        else E2V_KLAUNCH(bgemm256_kernel<false>, dim3(ntiles, 1, 1), dim3(512), smem256, s, a);
         return;
     }
+#else
+    if (a.bm256) throw Error(E2V_EINVAL, "bf16 GEMM: 256-row tiles serve taps = 1 and taps = 9 only");
+#endif
     if (a.rb1 == 0 && !a.geglu) {          // every row block is cut into 128 x 64 tiles only
         constexpr size_t smem64 = (size_t)2 * (128 + 64) * 128 + 9 * 128 * sizeof(unsigned);
         static bool cfg64 = false;
@@ -1020,12 +1036,14 @@ void bgemm_launch(const IgemmArgs& a_in, int ntiles, hipStream_t s) {
             const int nrb = (int)(((long)(x + 1) * a.nbm) >> 3) - (int)(((long)x * a.nbm) >> 3);
             nt = nrb * a.s2 > nt ? nrb * a.s2 : nt;
         }
-        if (lin) hipLaunchKernelGGL(bgemm_n64_kernel<true>, dim3(nt * 8, 1, 1), dim3(256), smem64, s, a);
-        else hipLaunchKernelGGL(bgemm_n64_kernel<false>, dim3(nt * 8, 1, 1), dim3(256), smem64, s, a);
+        dry_tag(" -> bgemm_n64_kernel 128x64");
+        if (lin) E2V_KLAUNCH(bgemm_n64_kernel<true>, dim3(nt * 8, 1, 1), dim3(256), smem64, s, a);
+        else E2V_KLAUNCH(bgemm_n64_kernel<false>, dim3(nt * 8, 1, 1), dim3(256), smem64, s, a);
         return;
     }
-    if (lin) hipLaunchKernelGGL(bgemm_kernel<true>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
-    else hipLaunchKernelGGL(bgemm_kernel<false>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
+    dry_tag(" -> bgemm_kernel 128x128" + std::string(a.rb1 < a.nbm ? "+128x64" : ""));
+    if (lin) E2V_KLAUNCH(bgemm_kernel<true>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
+    else E2V_KLAUNCH(bgemm_kernel<false>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
 }
 
 }  // namespace e2v

@@ -509,6 +509,7 @@ __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
     t256_body<NT, LIN>(p, blockIdx.x, p.col_off);
 }
 
+#ifdef E2V_AB          // measured, not adopted
 // The tail split's two tile widths in ONE launch (two launches on a stream run one after the other, each a third of the chip):
 // groups of eight workgroups alternate between 256 x 192 tiles at column offset col_off and 256 x 128 tiles at col_off2; the low
 // three bits of the block index -- the XCD -- stay what they are.
@@ -518,6 +519,7 @@ __global__ __launch_bounds__(512) void bgemm_t256_tail_kernel(const IgemmArgs p)
     if ((blockIdx.x >> 3) & 1) t256_body<2, LIN>(p, vblock, p.col_off2);
     else t256_body<3, LIN>(p, vblock, p.col_off);
 }
+#endif
 
 // ---- persistent form for the linears (taps = 1) ----------------------------------------------------------------------------------
 // A short-K tile (K = 320: five K steps, ~6 us of MFMAs) of the kernel above pays, around them: the workgroup launch, the latency
@@ -993,7 +995,7 @@ static void t256_launch_part(IgemmArgs a, const int cols, const int rb0, const i
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * (256 + 320) * 128));
             cfg = true;
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, a);
+        E2V_KLAUNCH(kern, dim3(grid), dim3(512), smem, s, a);
     };
     // linears: the persistent form (E2V_BGEMM_T256P: 0 never, 2 every linear, 1 launches of at least E2V_BGEMM_T256P_MINTILES tiles).
     // Same-box A/B over the linears of a B = 32 UNet step (tools/shape_ab.py): with the first register epilogue (8-byte stores, the
@@ -1020,7 +1022,8 @@ static void t256_launch_part(IgemmArgs a, const int cols, const int rb0, const i
             }
             const int per = per_xcd * nct;                   // tiles of the largest XCD share
             const int slots = per < 32 ? per : 32;
-            hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), smem + (blds ? (size_t)a.N * 4 : (size_t)0), s, a);
+            dry_tag(std::string(" -> bgemm_t256p_kernel 256x") + std::to_string(cols) + (blds ? " bias-lds" : ""));
+            E2V_KLAUNCH(kern, dim3(8 * slots), dim3(512), smem + (blds ? (size_t)a.N * 4 : (size_t)0), s, a);
         };
         const bool f32io = a.out_f32 != 0;
         auto pick = [&](auto ntc, auto gc) {
@@ -1034,10 +1037,15 @@ static void t256_launch_part(IgemmArgs a, const int cols, const int rb0, const i
         else pick(std::integral_constant<int, 4>{}, std::false_type{});
         return;
     }
+    dry_tag(nt == 0 ? std::string(" -> bgemm_t256_tail_kernel 256x192+256x128") : std::string(" -> bgemm_t256_kernel 256x") + std::to_string(64 * nt));
     switch (nt) {
         case 5: if (lin) go(bgemm_t256_kernel<5, true>); else go(bgemm_t256_kernel<5, false>); break;
         case 4: if (lin) go(bgemm_t256_kernel<4, true>); else go(bgemm_t256_kernel<4, false>); break;
+#ifdef E2V_AB
         default: if (lin) go(bgemm_t256_tail_kernel<true>); else go(bgemm_t256_tail_kernel<false>); break;
+#else
+        default: throw Error(E2V_EINVAL, "bgemm_t256: no kernel instance for this tile width");
+#endif
     }
 }
 
@@ -1051,7 +1059,7 @@ bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
     const double K = (double)a.taps * (a.c0 + a.c1);
     const double rows_in = lin ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
     std::string pname = "igemm_bf16";
-    if (profiler().on && profiler().detail)
+    if (prof_detail())
         pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t" + std::to_string(a.taps) +
                  (a.stride > 1 ? " s2" : "") + (a.c1 ? " cat" : "") + (a.geglu ? " geglu" : "") + " T" + std::to_string(cols);
     const double out_b = a.out_f32 ? 4.0 : 2.0;
@@ -1064,7 +1072,7 @@ bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
     // (tests/test_hip_ops.py::test_bf16_t256_tail_split).  MEASURED (same-process A/B over a B = 32 UNet step): the level-2 convs -3 %
     // (not the -9 % of the round count: the narrow tiles' phases are 8-12 MFMAs long and run at half the efficiency), 320 -> 320 at
     // level 0 +3 % (its persistent launch loses 128 tiles to a non-persistent one), 198.6 -> 198.4 ms per step: not worth a default.
-    static const int* const tailp = knob("E2V_BGEMM_T256_TAIL", 0);
+    static const int* const tailp = E2V_AB_KNOB("E2V_BGEMM_T256_TAIL", 0);
     const long T = (long)nbm * nct, full = T / 256, tail = T - 256 * full;
     if (*tailp && cols == 320 && !a.geglu && full >= 1 && tail > 0 && 2 * tail <= 256 && (256 * full) % nct == 0) {
         const int r1 = (int)(256 * full / nct);
@@ -1110,7 +1118,7 @@ int conv_up2x_packed_ld(int cin) { return (cin + 63) / 64 * 4 * 64; }
 void pack_conv_up2x(const float* w, float* o, int cout, int cin, hipStream_t s) {
     const size_t total = 4 * (size_t)cout * conv_up2x_packed_ld(cin);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_conv_up2x_kernel, dim3(blocks), dim3(256), 0, s, w, o, cout, cin);
+    E2V_KLAUNCH(pack_conv_up2x_kernel, dim3(blocks), dim3(256), 0, s, w, o, cout, cin);
 }
 
 static IgemmArgs up2x_parity_args(const IgemmArgs& g, const int a, const int b) {

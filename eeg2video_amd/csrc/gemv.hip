@@ -119,8 +119,8 @@ void gemv_rows(const float* x, int ldx, const void* w, int ldw, int w_bf16, cons
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             cfg = true;
         }
-        if (B <= 4) hipLaunchKernelGGL(k4, grid, dim3(256), smem, s, x, ldx, static_cast<const __bf16*>(w), ldw, bias, out, ldo, B, N, K, relu, 1);
-        else hipLaunchKernelGGL(k16, grid, dim3(256), smem, s, x, ldx, static_cast<const __bf16*>(w), ldw, bias, out, ldo, B, N, K, relu, 1);
+        if (B <= 4) E2V_KLAUNCH(k4, grid, dim3(256), smem, s, x, ldx, static_cast<const __bf16*>(w), ldw, bias, out, ldo, B, N, K, relu, 1);
+        else E2V_KLAUNCH(k16, grid, dim3(256), smem, s, x, ldx, static_cast<const __bf16*>(w), ldw, bias, out, ldo, B, N, K, relu, 1);
     } else {
         auto k4 = gemv_rows_kernel<float, 4, RW>;
         auto k16 = gemv_rows_kernel<float, 16, RW>;
@@ -130,8 +130,8 @@ void gemv_rows(const float* x, int ldx, const void* w, int ldw, int w_bf16, cons
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             cfg = true;
         }
-        if (B <= 4) hipLaunchKernelGGL(k4, grid, dim3(256), smem, s, x, ldx, static_cast<const float*>(w), ldw, bias, out, ldo, B, N, K, relu, 0);
-        else hipLaunchKernelGGL(k16, grid, dim3(256), smem, s, x, ldx, static_cast<const float*>(w), ldw, bias, out, ldo, B, N, K, relu, 0);
+        if (B <= 4) E2V_KLAUNCH(k4, grid, dim3(256), smem, s, x, ldx, static_cast<const float*>(w), ldw, bias, out, ldo, B, N, K, relu, 0);
+        else E2V_KLAUNCH(k16, grid, dim3(256), smem, s, x, ldx, static_cast<const float*>(w), ldw, bias, out, ldo, B, N, K, relu, 0);
     }
 }
 

@@ -503,14 +503,14 @@ static void launch_igemm_x3(const IgemmArgs& a, int ntiles, hipStream_t s) {
     }
     const double K = (double)(a.c0 + a.c1);
     std::string pname = "igemm_f32x3";
-    if (profiler().on && profiler().detail)
+    if (prof_detail())
         pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) +
                  (a.geglu ? " geglu" : "") + (a.batch > 1 ? " b" + std::to_string(a.batch) : "");
     ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
                  4.0 * a.batch * ((double)a.M * K + 1.5 * a.N * K + (double)a.M * (a.geglu ? a.N / 2 : a.N)), s);
-    if (ablx == 1) hipLaunchKernelGGL(igemm_x3_kernel<1>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
-    else if (ablx == 2) hipLaunchKernelGGL(igemm_x3_kernel<2>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
-    else hipLaunchKernelGGL(igemm_x3_kernel<0>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
+    if (ablx == 1) E2V_KLAUNCH(igemm_x3_kernel<1>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
+    else if (ablx == 2) E2V_KLAUNCH(igemm_x3_kernel<2>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
+    else E2V_KLAUNCH(igemm_x3_kernel<0>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -709,14 +709,15 @@ static void launch_igemm(const IgemmArgs& a, int ntiles, const char* cls, hipStr
     const double K = (double)a.taps * (a.c0 + a.c1);
     const double rows_in = a.taps == 1 ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
     std::string pname = cls;
-    if (profiler().on && profiler().detail)
+    if (prof_detail())
         pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t" +
                  std::to_string(a.taps) + (a.stride > 1 ? " s2" : "") + (a.upsample ? " up" : "") + (a.c1 ? " cat" : "") +
                  (a.geglu ? " geglu" : "") + (a.batch > 1 ? " b" + std::to_string(a.batch) : "") + " rb1=" +
                  std::to_string(a.rb1) + " w" + std::to_string(a.w1) + " s" + std::to_string(a.s1);
     ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
                  4.0 * a.batch * (rows_in * (a.c0 + a.c1) + (double)a.N * K + (double)a.M * (a.geglu ? a.N / 2 : a.N)), s);
-    hipLaunchKernelGGL((igemm_kernel<ABL>), grid, dim3(256), smem, s, a);
+    dry_tag(" -> igemm_kernel 128x128x32");
+    E2V_KLAUNCH((igemm_kernel<ABL>), grid, dim3(256), smem, s, a);
 }
 
 void igemm(const IgemmArgs& a_in, hipStream_t s) {
@@ -803,12 +804,13 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
         }
         const double K = (double)(a.c0 + a.c1);
         std::string pname = cls;
-        if (profiler().on && profiler().detail)
+        if (prof_detail())
             pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t1" + (a.c1 ? " cat" : "") +
                      (a.geglu ? " geglu" : "") + (a.batch > 1 ? " b" + std::to_string(a.batch) : "") + " k16";
         ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K * a.batch,
                      4.0 * a.batch * ((double)a.M * K + (double)a.N * K + (double)a.M * (a.geglu ? a.N / 2 : a.N)), s);
-        hipLaunchKernelGGL(igemm_k16_kernel, dim3(ntiles, 1, 1), dim3(256), smem16, s, a);
+        dry_tag(" rb1=" + std::to_string(a.rb1) + " w" + std::to_string(a.w1) + " s" + std::to_string(a.s1) + " -> igemm_k16_kernel 128x128x16");
+        E2V_KLAUNCH(igemm_k16_kernel, dim3(ntiles, 1, 1), dim3(256), smem16, s, a);
         return;
     }
     if (abl == 1) launch_igemm<1>(a, ntiles, cls, s);
@@ -837,7 +839,7 @@ int conv3x3_packed_ld(int cin, int bke) { return (cin + bke - 1) / bke * 9 * bke
 void pack_conv3x3(const float* w, float* o, int cout, int cin, int bke, hipStream_t s) {
     const size_t total = (size_t)cout * conv3x3_packed_ld(cin, bke);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(256), 0, s, w, o, cout, cin, bke);
+    E2V_KLAUNCH(pack_conv3x3_kernel, dim3(blocks), dim3(256), 0, s, w, o, cout, cin, bke);
 }
 
 // fp32 -> three bf16 planes by truncation: x = p0 + p1 + p2 exactly (planes `plane` elements apart)
@@ -856,7 +858,7 @@ __global__ void split_bf16x3_kernel(const float* __restrict__ in, unsigned short
 void split_bf16x3(const float* in, void* out, size_t n, size_t plane, hipStream_t s) {
     if (!n) return;
     const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(blocks), dim3(256), 0, s, in, static_cast<unsigned short*>(out), n, plane);
+    E2V_KLAUNCH(split_bf16x3_kernel, dim3(blocks), dim3(256), 0, s, in, static_cast<unsigned short*>(out), n, plane);
 }
 
 __global__ void to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n) {
@@ -865,7 +867,7 @@ __global__ void to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict_
 void to_bf16(const float* in, void* out, size_t n, hipStream_t s) {
     if (!n) return;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(to_bf16_kernel, dim3(blocks), dim3(256), 0, s, in, static_cast<__bf16*>(out), n);
+    E2V_KLAUNCH(to_bf16_kernel, dim3(blocks), dim3(256), 0, s, in, static_cast<__bf16*>(out), n);
 }
 
 __global__ void copy_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows,
@@ -880,7 +882,7 @@ void copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int col
     const size_t total = (size_t)rows * cols;
     if (!total) return;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(blocks), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
+    E2V_KLAUNCH(copy_rows_kernel, dim3(blocks), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
 }
 
 }  // namespace e2v

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <string>
 
 namespace e2v {
 
@@ -61,7 +62,16 @@ void igemm(const IgemmArgs& a, hipStream_t s);
 // Run-time switches: an int per name, initialised from the environment variable of that name on first use
 // and settable through e2v_op_set_knob for A/B comparisons inside one process.  The returned pointer stays valid.
 int* knob(const char* name, int dflt);
-bool set_knob(const char* name, int value);      // false: no kernel has asked for a knob of that name yet and it is not a known one
+bool set_knob(const char* name, int value);
+// Switches of variants that were MEASURED AND NOT ADOPTED (or are kept only as the other arm of a same-process A/B) exist in an
+// `make AB=1` build (-DE2V_AB) only: the shipped library carries neither their kernels nor their switches (set_knob refuses the
+// names, the environment variables are not read), and the launch rules read the default.
+template <int V> inline const int* ab_const() { static const int v = V; return &v; }
+#ifdef E2V_AB
+#define E2V_AB_KNOB(name, dflt) ::e2v::knob(name, dflt)
+#else
+#define E2V_AB_KNOB(name, dflt) ::e2v::ab_const<dflt>()
+#endif      // false: no kernel has asked for a knob of that name yet and it is not a known one
 void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s);
 bool bgemm_all_n64(const IgemmArgs& a);
 bool bgemm_t256_launch(const IgemmArgs& a, hipStream_t s);                 // bgemm256.hip: true = the layer was eligible and has been launched
@@ -149,6 +159,7 @@ void flash_attention(const AttnArgs& a, hipStream_t s);      // throws Error(E2V
 bool flash_attention_supports(int D);
 // attn_q64.hip: bf16 sparse-causal attention with 64 queries per wave (head dims 40 / 80).  _waves: waves per workgroup of the instance
 // that would serve the call, 0 = not served (flash_attention falls back to flash_attn_b16io_kernel); the second launches it.
+std::string attn_shape_tag(const AttnArgs& a);                // " D.. Nq.. Nk.. n.. F.. h.." for profile names
 int flash_attention_q64_waves(const AttnArgs& a);
 bool flash_attention_q64(const AttnArgs& a, hipStream_t s);
 // temporal self-attention over the F frames of every pixel (attention.py:261-267), qkv = [n*F*HW][3C]

@@ -30,10 +30,10 @@ __global__ void ncfhw_to_cl_kernel(const float* __restrict__ in, T* __restrict__
 void ncfhw_to_cl(const float* in, float* out, int n, int C, int Cpad, int FHW, float scale, hipStream_t s, int out_bf16) {
     const size_t total = (size_t)n * FHW * Cpad;
     if (out_bf16)
-        hipLaunchKernelGGL(ncfhw_to_cl_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s, in, reinterpret_cast<__bf16*>(out), n, C, Cpad,
+        E2V_KLAUNCH(ncfhw_to_cl_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s, in, reinterpret_cast<__bf16*>(out), n, C, Cpad,
                            FHW, scale);
     else
-        hipLaunchKernelGGL(ncfhw_to_cl_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, in, out, n, C, Cpad, FHW, scale);
+        E2V_KLAUNCH(ncfhw_to_cl_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, in, out, n, C, Cpad, FHW, scale);
 }
 
 // in [n][FHW][ld] (first C channels) -> out [n][C][FHW]; y = x*mul + add, optional clamp to [0,1]
@@ -53,7 +53,7 @@ __global__ void cl_to_ncfhw_kernel(const float* __restrict__ in, int ld, float* 
 void cl_to_ncfhw(const float* in, int ld, float* out, int n, int C, int FHW, float mul, float add, int clamp, float lo,
                  float hi, hipStream_t s) {
     const size_t total = (size_t)n * C * FHW;
-    hipLaunchKernelGGL(cl_to_ncfhw_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, ld, out, n, C, FHW, mul, add, clamp, lo,
+    E2V_KLAUNCH(cl_to_ncfhw_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, ld, out, n, C, FHW, mul, add, clamp, lo,
                        hi);
 }
 
@@ -76,7 +76,7 @@ __global__ void frames_to_ncfhw_kernel(const float* __restrict__ in, int ld, flo
 void nchw_frames_to_ncfhw(const float* in, int ld, float* out, int n, int F, int C, int HW, float mul, float add, int clamp01,
                           hipStream_t s) {
     const size_t total = (size_t)n * C * F * HW;
-    hipLaunchKernelGGL(frames_to_ncfhw_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, ld, out, n, F, C, HW, mul, add,
+    E2V_KLAUNCH(frames_to_ncfhw_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, ld, out, n, F, C, HW, mul, add,
                        clamp01);
 }
 
@@ -99,10 +99,10 @@ __global__ void timestep_sinusoid_kernel(const TT* __restrict__ t, int nt, float
 }
 void timestep_sinusoid(const long long* t, int nt, float* out, int n, int dim, int flip, float shift, hipStream_t s, int t_is_f32) {
     if (t_is_f32)       // fractional timesteps of the sigma-space schedulers (Euler, LMS): the fp32 value the reference's .float() makes
-        hipLaunchKernelGGL(timestep_sinusoid_kernel<float>, dim3(grid_for((size_t)n * dim / 2)), dim3(256), 0, s,
+        E2V_KLAUNCH(timestep_sinusoid_kernel<float>, dim3(grid_for((size_t)n * dim / 2)), dim3(256), 0, s,
                            reinterpret_cast<const float*>(t), nt, out, n, dim, flip, shift);
     else
-        hipLaunchKernelGGL(timestep_sinusoid_kernel<long long>, dim3(grid_for((size_t)n * dim / 2)), dim3(256), 0, s, t, nt, out, n, dim,
+        E2V_KLAUNCH(timestep_sinusoid_kernel<long long>, dim3(grid_for((size_t)n * dim / 2)), dim3(256), 0, s, t, nt, out, n, dim,
                            flip, shift);
 }
 
@@ -114,7 +114,7 @@ __global__ void silu_kernel(const float* __restrict__ in, float* __restrict__ ou
 }
 void silu(const float* in, float* out, long long count, hipStream_t s) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(silu_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, s, in, out, (size_t)count);
+    E2V_KLAUNCH(silu_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, s, in, out, (size_t)count);
 }
 
 // out[b][c][r] = in[b][r][c], 32x32 LDS tiles
@@ -140,10 +140,10 @@ void transpose2d(const float* in, int ld_in, float* out, int ld_out, int rows, i
                  long long sb_out, hipStream_t s, int bf16) {
     dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
     if (bf16)
-        hipLaunchKernelGGL(transpose_kernel<__bf16>, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(in), ld_in,
+        E2V_KLAUNCH(transpose_kernel<__bf16>, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(in), ld_in,
                            reinterpret_cast<__bf16*>(out), ld_out, rows, cols, sb_in, sb_out);
     else
-        hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, s, in, ld_in, out, ld_out, rows, cols, sb_in, sb_out);
+        E2V_KLAUNCH(transpose_kernel<float>, grid, dim3(256), 0, s, in, ld_in, out, ld_out, rows, cols, sb_in, sb_out);
 }
 
 // pipeline_tuneeeg2video.py:320-325 fused: guidance, then DDIM (eta = 0):
@@ -162,7 +162,7 @@ void ddim_cfg_step(const float* eps_u, const float* eps_c, const float* x, float
                    float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_p, float sqrt_1m_a_p, hipStream_t s) {
     if (count <= 0) return;
     ProfScope ps("ddim_cfg_step", 8.0 * count, 4.0 * count * (eps_c ? 4.0 : 3.0), s);
-    hipLaunchKernelGGL(ddim_cfg_step_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, s, eps_u, eps_c, x, x_out,
+    E2V_KLAUNCH(ddim_cfg_step_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, s, eps_u, eps_c, x, x_out,
                        (size_t)count, guidance, sqrt_a_t, sqrt_1m_a_t, sqrt_a_p, sqrt_1m_a_p);
 }
 
@@ -184,7 +184,7 @@ void lincomb(int n, const float* const* xs, const float* coefs, float* out, long
     a.n = n;
     for (int k = 0; k < n; ++k) { a.x[k] = xs[k]; a.c[k] = coefs[k]; }
     ProfScope ps("lincomb", 2.0 * n * count, 4.0 * count * (n + 1), s);
-    hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, s, a, out, (size_t)count);
+    E2V_KLAUNCH(lincomb_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, s, a, out, (size_t)count);
 }
 __global__ void cfg_combine_kernel(const float* __restrict__ eu, const float* __restrict__ ec, float g, float* __restrict__ out,
                                    size_t count) {
@@ -196,7 +196,7 @@ __global__ void cfg_combine_kernel(const float* __restrict__ eu, const float* __
 void cfg_combine(const float* eu, const float* ec, float g, float* out, long long count, hipStream_t s) {
     if (count <= 0) return;
     ProfScope ps("cfg_combine", 3.0 * count, 12.0 * count, s);
-    hipLaunchKernelGGL(cfg_combine_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, s, eu, ec, g, out, (size_t)count);
+    E2V_KLAUNCH(cfg_combine_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, s, eu, ec, g, out, (size_t)count);
 }
 
 // ---- SURVEY 8(f) rows ---------------------------------------------------------------------------------------
@@ -221,7 +221,7 @@ void dana_noise(const float* x0, const float* eps_div, const float* eps_same, co
     const size_t total = (size_t)B * C * F * HW;
     if (!total) return;
     ProfScope ps("dana_noise", 6.0 * total, 4.0 * total * 3.2, s);
-    hipLaunchKernelGGL(dana_kernel, dim3(grid_for(total)), dim3(256), 0, s, x0, eps_div, eps_same, coef, sqrt_1m_beta, sqrt_beta,
+    E2V_KLAUNCH(dana_kernel, dim3(grid_for(total)), dim3(256), 0, s, x0, eps_div, eps_same, coef, sqrt_1m_beta, sqrt_beta,
                        out, B, F, C, HW);
 }
 
@@ -240,7 +240,7 @@ __global__ void frames_to_u8_kernel(const float* __restrict__ in, unsigned char*
 void frames_to_u8(const float* in, unsigned char* out, long long count, hipStream_t s) {
     if (count <= 0) return;
     ProfScope ps("frames_to_u8", 1.0 * count, 5.0 * count, s);
-    hipLaunchKernelGGL(frames_to_u8_kernel, dim3(grid_for((size_t)count / 4 + 1)), dim3(256), 0, s, in, out, (size_t)count);
+    E2V_KLAUNCH(frames_to_u8_kernel, dim3(grid_for((size_t)count / 4 + 1)), dim3(256), 0, s, in, out, (size_t)count);
 }
 
 template <typename T>
@@ -255,10 +255,10 @@ __global__ void pad_cols_kernel(const float* __restrict__ in, int cols, T* __res
 void pad_cols(const float* in, int cols, float* out, int cols_pad, long long rows, hipStream_t s, int out_bf16) {
     if (rows <= 0) return;
     if (out_bf16)
-        hipLaunchKernelGGL(pad_cols_kernel<__bf16>, dim3(grid_for((size_t)rows * cols_pad)), dim3(256), 0, s, in, cols,
+        E2V_KLAUNCH(pad_cols_kernel<__bf16>, dim3(grid_for((size_t)rows * cols_pad)), dim3(256), 0, s, in, cols,
                            reinterpret_cast<__bf16*>(out), cols_pad, (size_t)rows);
     else
-        hipLaunchKernelGGL(pad_cols_kernel<float>, dim3(grid_for((size_t)rows * cols_pad)), dim3(256), 0, s, in, cols, out, cols_pad, (size_t)rows);
+        E2V_KLAUNCH(pad_cols_kernel<float>, dim3(grid_for((size_t)rows * cols_pad)), dim3(256), 0, s, in, cols, out, cols_pad, (size_t)rows);
 }
 
 // strided row copy with a storage-type change: out[r][c] = in[r][c] for c < cols, 0 for cols <= c < cols_out
@@ -276,13 +276,13 @@ void cvt_rows(const void* in, int ld_in, int in_bf16, void* out, int ld_out, int
     if (rows <= 0 || cols_out <= 0) return;
     const dim3 g(grid_for((size_t)rows * cols_out)), b(256);
     if (in_bf16 && out_bf16)
-        hipLaunchKernelGGL((cvt_rows_kernel<__bf16, __bf16>), g, b, 0, s, static_cast<const __bf16*>(in), ld_in, static_cast<__bf16*>(out), ld_out, (size_t)rows, cols, cols_out);
+        E2V_KLAUNCH((cvt_rows_kernel<__bf16, __bf16>), g, b, 0, s, static_cast<const __bf16*>(in), ld_in, static_cast<__bf16*>(out), ld_out, (size_t)rows, cols, cols_out);
     else if (in_bf16)
-        hipLaunchKernelGGL((cvt_rows_kernel<__bf16, float>), g, b, 0, s, static_cast<const __bf16*>(in), ld_in, static_cast<float*>(out), ld_out, (size_t)rows, cols, cols_out);
+        E2V_KLAUNCH((cvt_rows_kernel<__bf16, float>), g, b, 0, s, static_cast<const __bf16*>(in), ld_in, static_cast<float*>(out), ld_out, (size_t)rows, cols, cols_out);
     else if (out_bf16)
-        hipLaunchKernelGGL((cvt_rows_kernel<float, __bf16>), g, b, 0, s, static_cast<const float*>(in), ld_in, static_cast<__bf16*>(out), ld_out, (size_t)rows, cols, cols_out);
+        E2V_KLAUNCH((cvt_rows_kernel<float, __bf16>), g, b, 0, s, static_cast<const float*>(in), ld_in, static_cast<__bf16*>(out), ld_out, (size_t)rows, cols, cols_out);
     else
-        hipLaunchKernelGGL((cvt_rows_kernel<float, float>), g, b, 0, s, static_cast<const float*>(in), ld_in, static_cast<float*>(out), ld_out, (size_t)rows, cols, cols_out);
+        E2V_KLAUNCH((cvt_rows_kernel<float, float>), g, b, 0, s, static_cast<const float*>(in), ld_in, static_cast<float*>(out), ld_out, (size_t)rows, cols, cols_out);
 }
 
 }  // namespace e2v

@@ -141,6 +141,7 @@ void e2v_ctx::expected_keys() {
 float* e2v_ctx::dev_alloc(size_t floats) {
     void* p = nullptr;
     const size_t bytes = std::max<size_t>(floats, 1) * sizeof(float);
+    if (dry_run()) return dry_fake_ptr(bytes);               // e2v_op_describe_dispatch: an address nobody dereferences, not owned
     E2V_HIP(hipMalloc(&p, bytes));
     (alloc_part >= 0 ? owned_part[alloc_part] : owned).push_back(static_cast<float*>(p));
     owned_bytes[p] = bytes;
@@ -241,6 +242,10 @@ struct Packer {
     const WTensor& t(const std::string& k) {
         auto it = c->raw.find(k);
         E2V_REQUIRE(it != c->raw.end(), E2V_ENOWEIGHT, "unknown key " + k);
+        if (dry_run()) {                                     // shapes only: the dispatch of a configuration does not depend on values
+            if (!it->second.d) it->second.d = dry_fake_ptr(it->second.numel * sizeof(float));
+            return it->second;
+        }
         E2V_REQUIRE(it->second.loaded, E2V_ENOWEIGHT, "state-dict key not loaded: " + k);
         return it->second;
     }
@@ -450,6 +455,11 @@ void e2v_ctx::finalize(int which) {
     alloc_part = -1;
     E2V_HIP(hipStreamSynchronize(nullptr));
     E2V_HIP(hipGetLastError());
+    if (dry_run()) {                                         // nothing was allocated: nothing to drop
+        if (which & 1) unet_ready = true;
+        if (which & 2) vae_ready = true;
+        return;
+    }
     // the torch-layout copies of re-laid-out tensors are no longer needed
     auto drop = [&](const std::string& k) {
         auto it = raw.find(k);

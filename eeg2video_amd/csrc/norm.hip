@@ -11,6 +11,7 @@
 #include "kernels.h"
 #include "prof.h"
 #include "act_io.h"
+#include <string>
 #include <type_traits>
 
 namespace e2v {
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256) void gn_partial8_kernel(const __bf16* __restri
     }
 }
 
+#ifdef E2V_AB          // the flat-index apply pass (E2V_GN_ROWS = 0): the other arm of the A/B that adopted the row-tiled one
 __global__ __launch_bounds__(256) void gn_apply8_kernel(const __bf16* __restrict__ x0, const __bf16* __restrict__ x1, int c0, int c1,
                                                         int ld0, int ld1, const float* __restrict__ scsh, __bf16* __restrict__ out,
                                                         int ldo, int P, size_t rows, int act) {
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(256) void gn_apply8_kernel(const __bf16* __restrict
         st8(out + row * ldo + c, lo, hi);
     }
 }
+#endif
 
 // Row-tiled form of the pass above: grid (chunks, slabs) like the statistics pass, thread -> (row r of R at a time, octet q of OT side by
 // side), the scale / shift pairs of the thread's eight channels held in registers over the rows of the chunk, four rows in flight
@@ -327,31 +330,40 @@ static int gn_chunk_rows(const int P) {
     return v < GN_ROWS_PER_CHUNK ? GN_ROWS_PER_CHUNK : v;
 }
 
+static std::string gn_shape_tag(const GroupNormArgs& a) {
+    return " S" + std::to_string(a.samples) + " P" + std::to_string(a.P) + " C" + std::to_string(a.c0) + (a.c1 ? "+" + std::to_string(a.c1) : "") + " g" +
+           std::to_string(a.groups);
+}
+
 static void groupnorm_stats_launch(const GroupNormArgs& a, hipStream_t s) {
     const int Ctot = a.c0 + a.c1;
     const int crows = gn_chunk_rows(a.P);
     const int chunks = (a.P + crows - 1) / crows;
+    dry_tag(std::string(" -> ") + (a.bf16 && a.c0 % 8 == 0 && a.c1 % 8 == 0 && ((a.ld0 | a.ld1) & 7) == 0 ? "gn_partial8_kernel" : "gn_partial_kernel") + " rows" +
+            std::to_string(crows) + " + gn_finalize_kernel");
     auto part = [&](const float* x, int ld, int C, int coff) {
         const int qt = quad_tile(C / 4);
         if (a.bf16 && C % 8 == 0 && ld % 8 == 0)
-            hipLaunchKernelGGL(gn_partial8_kernel, dim3(chunks, a.samples), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), ld, C, a.P,
+            E2V_KLAUNCH(gn_partial8_kernel, dim3(chunks, a.samples), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), ld, C, a.P,
                                chunks, a.ws_part, Ctot, coff, oct_tile(C / 8), crows);
         else if (a.bf16)
-            hipLaunchKernelGGL(gn_partial_kernel<__bf16>, dim3(chunks, a.samples), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), ld, C,
+            E2V_KLAUNCH(gn_partial_kernel<__bf16>, dim3(chunks, a.samples), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), ld, C,
                                a.P, chunks, a.ws_part, Ctot, coff, qt, crows);
         else
-            hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(chunks, a.samples), dim3(256), 0, s, x, ld, C, a.P, chunks, a.ws_part, Ctot,
+            E2V_KLAUNCH(gn_partial_kernel<float>, dim3(chunks, a.samples), dim3(256), 0, s, x, ld, C, a.P, chunks, a.ws_part, Ctot,
                                coff, qt, crows);
     };
     part(a.x0, a.ld0, a.c0, 0);
     if (a.c1 > 0) part(a.x1, a.ld1, a.c1, a.c0);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.samples), dim3(64), 0, s, a.ws_part, chunks, Ctot, a.groups,
+    E2V_KLAUNCH(gn_finalize_kernel, dim3(a.groups, a.samples), dim3(64), 0, s, a.ws_part, chunks, Ctot, a.groups,
                        a.P, a.eps, a.gamma, a.beta, a.ws_scale);
 }
 
 void groupnorm_stats(const GroupNormArgs& a, hipStream_t s) {
     const double elems = (double)a.samples * a.P * (a.c0 + a.c1);
-    ProfScope ps("groupnorm_stats", 3.0 * elems, (a.bf16 ? 2.0 : 4.0) * elems, s);              // algorithmic: one read
+    std::string pname = "groupnorm_stats";
+    if (prof_detail()) pname += gn_shape_tag(a);
+    ProfScope ps(pname.c_str(), 3.0 * elems, (a.bf16 ? 2.0 : 4.0) * elems, s);              // algorithmic: one read
     groupnorm_stats_launch(a, s);
 }
 
@@ -359,7 +371,7 @@ static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t
 
 // bf16 rows, 16-byte accesses: statistics and apply of one run of samples
 static void groupnorm_bf16_launch(const GroupNormArgs& a, hipStream_t s) {
-    static const int* const rowsp = knob("E2V_GN_ROWS", 1);        // 0: the flat-index apply pass
+    static const int* const rowsp = E2V_AB_KNOB("E2V_GN_ROWS", 1);        // 0: the flat-index apply pass
     groupnorm_stats_launch(a, s);
     const int Ctot = a.c0 + a.c1;
     const size_t rows = (size_t)a.samples * a.P;
@@ -368,23 +380,31 @@ static void groupnorm_bf16_launch(const GroupNormArgs& a, hipStream_t s) {
         const int crows = gn_chunk_rows(a.P);
         const dim3 grid((a.P + crows - 1) / crows, a.samples);
         auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0), reinterpret_cast<const __bf16*>(a.x1), a.c0,
+            E2V_KLAUNCH(kern, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0), reinterpret_cast<const __bf16*>(a.x1), a.c0,
                                a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<__bf16*>(a.out), a.ldo, a.P, ot, crows);
         };
+        dry_tag(" + gn_apply8_rows_kernel rows" + std::to_string(crows));
         if (a.silu) go(gn_apply8_rows_kernel<true>); else go(gn_apply8_rows_kernel<false>);
         return;
     }
+#ifdef E2V_AB
     const size_t tot8 = rows * (Ctot / 8);
     const int blk8 = (int)((tot8 + 255) / 256 < 16384 ? (tot8 + 255) / 256 : 16384);
-    hipLaunchKernelGGL(gn_apply8_kernel, dim3(blk8), dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0),
+    dry_tag(" + gn_apply8_kernel");
+    E2V_KLAUNCH(gn_apply8_kernel, dim3(blk8), dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0),
                        reinterpret_cast<const __bf16*>(a.x1), a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<__bf16*>(a.out), a.ldo,
                        a.P, rows, a.silu);
+#else
+    (void)rows; (void)Ctot;
+#endif
 }
 
 void groupnorm(const GroupNormArgs& a, hipStream_t s) {
     const int Ctot = a.c0 + a.c1;
     const double elems = (double)a.samples * a.P * Ctot;
-    ProfScope ps(a.silu ? "groupnorm_silu" : "groupnorm", 8.0 * elems, 2.0 * (a.bf16 ? 2.0 : 4.0) * elems, s);   // algorithmic: read + write
+    std::string pname = a.silu ? "groupnorm_silu" : "groupnorm";
+    if (prof_detail()) pname += gn_shape_tag(a);
+    ProfScope ps(pname.c_str(), 8.0 * elems, 2.0 * (a.bf16 ? 2.0 : 4.0) * elems, s);   // algorithmic: read + write
     const size_t rows = (size_t)a.samples * a.P;
     const size_t total = rows * (Ctot / 4);
     const int blocks = (int)((total + 511) / 512 < 16384 ? (total + 511) / 512 : 16384);
@@ -396,7 +416,7 @@ void groupnorm(const GroupNormArgs& a, hipStream_t s) {
         // 0.98 ms in runs of 32 MB at 13824 x 320): a run of 7 samples is 378 workgroups per launch and three dependent launches, the
         // chip is never full and the launch gaps cost more than the cache returns.  Default 0 = one run; the switch stays for the
         // measurement.
-        static const int* const group_mb = knob("E2V_GN_GROUP_MB", 0);
+        static const int* const group_mb = E2V_AB_KNOB("E2V_GN_GROUP_MB", 0);
         const double sample_bytes = 2.0 * a.P * Ctot;
         int per = a.samples;
         if (*group_mb > 0 && sample_bytes * a.samples > 1.5e6 * *group_mb) {
@@ -418,12 +438,13 @@ void groupnorm(const GroupNormArgs& a, hipStream_t s) {
         return;
     }
     groupnorm_stats_launch(a, s);
+    dry_tag(" + gn_apply_kernel");
     if (a.bf16)
-        hipLaunchKernelGGL(gn_apply_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0),
+        E2V_KLAUNCH(gn_apply_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0),
                            reinterpret_cast<const __bf16*>(a.x1), a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<__bf16*>(a.out), a.ldo,
                            a.P, rows, a.silu);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(blocks), dim3(256), 0, s, a.x0, a.x1, a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, a.out,
+        E2V_KLAUNCH(gn_apply_kernel<float>, dim3(blocks), dim3(256), 0, s, a.x0, a.x1, a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, a.out,
                            a.ldo, a.P, rows, a.silu);
 }
 
@@ -703,23 +724,30 @@ static void layernorm_launch(const T* x, int ldx, const float* gamma, const floa
                              hipStream_t s) {
     const int blocks = (rows + 3) / 4;
     if (C <= 256)
-        hipLaunchKernelGGL((layernorm_kernel<1, T>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
+        E2V_KLAUNCH((layernorm_kernel<1, T>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
     else if (C <= 768)
-        hipLaunchKernelGGL((layernorm_kernel<3, T>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
+        E2V_KLAUNCH((layernorm_kernel<3, T>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
     else
-        hipLaunchKernelGGL((layernorm_kernel<5, T>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
+        E2V_KLAUNCH((layernorm_kernel<5, T>), dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, C, eps);
 }
 
 void layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* out, int ldo, int rows, int C,
                float eps, hipStream_t s, int bf16) {
-    ProfScope ps("layernorm", 8.0 * rows * C, 2.0 * (bf16 ? 2.0 : 4.0) * rows * C, s);
+    std::string pname = "layernorm";
+    if (prof_detail()) pname += " rows" + std::to_string(rows) + " C" + std::to_string(C);
+    ProfScope ps(pname.c_str(), 8.0 * rows * C, 2.0 * (bf16 ? 2.0 : 4.0) * rows * C, s);
     static const int* const rowsp = knob("E2V_LN_ROWS", 1);         // 0: one wave per row group of four rows
+    if (dry_run()) {
+        const bool shared = *rowsp && (C == 320 || C == 640 || C == 1280) && ldx % (bf16 ? 8 : 4) == 0 && ldo % (bf16 ? 8 : 4) == 0;
+        dry_tag(std::string(" -> ") + (shared ? (bf16 ? "layernorm_bf16_rows_kernel" : "layernorm_f32_rows_kernel")
+                                       : (bf16 && C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && C <= 1536 ? "layernorm_bf16_kernel" : "layernorm_kernel")));
+    }
     if (bf16 && *rowsp && (C == 320 || C == 640 || C == 1280) && ldx % 8 == 0 && ldo % 8 == 0) {
         const __bf16* xi = reinterpret_cast<const __bf16*>(x);
         __bf16* xo = reinterpret_cast<__bf16*>(out);
         auto go = [&](auto kern, const int rows_per_wave) {
             const int blocks = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, eps);
+            E2V_KLAUNCH(kern, dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, eps);
         };
         if (C == 320) go(layernorm_bf16_rows_kernel<8, 2>, 16);
         else if (C == 640) go(layernorm_bf16_rows_kernel<16, 2>, 8);
@@ -729,15 +757,15 @@ void layernorm(const float* x, int ldx, const float* gamma, const float* beta, f
         const int blocks = (rows + 4 * R - 1) / (4 * R);
         const __bf16* xi = reinterpret_cast<const __bf16*>(x);
         __bf16* xo = reinterpret_cast<__bf16*>(out);
-        if (C <= 512) hipLaunchKernelGGL((layernorm_bf16_kernel<1, R>), dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, C, eps);
-        else if (C <= 1024) hipLaunchKernelGGL((layernorm_bf16_kernel<2, R>), dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, C, eps);
-        else hipLaunchKernelGGL((layernorm_bf16_kernel<3, R>), dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, C, eps);
+        if (C <= 512) E2V_KLAUNCH((layernorm_bf16_kernel<1, R>), dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, C, eps);
+        else if (C <= 1024) E2V_KLAUNCH((layernorm_bf16_kernel<2, R>), dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, C, eps);
+        else E2V_KLAUNCH((layernorm_bf16_kernel<3, R>), dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, C, eps);
     } else if (bf16)
         layernorm_launch(reinterpret_cast<const __bf16*>(x), ldx, gamma, beta, reinterpret_cast<__bf16*>(out), ldo, rows, C, eps, s);
     else if (*rowsp && (C == 320 || C == 640 || C == 1280) && ldx % 4 == 0 && ldo % 4 == 0) {
         auto go = [&](auto kern, const int rows_per_wave) {
             const int blocks = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, eps);
+            E2V_KLAUNCH(kern, dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, out, ldo, rows, eps);
         };
         if (C == 320) go(layernorm_f32_rows_kernel<16, 2>, 8);
         else if (C == 640) go(layernorm_f32_rows_kernel<32, 2>, 4);

@@ -4,8 +4,34 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <string>
 #include <vector>
+
+namespace e2v {
+
+// Dry run (e2v_op_describe_dispatch): the graph walker, the launch rules and every launcher run as usual on a host-only ctx, but no
+// HIP call is made -- launches and E2V_HIP calls are skipped, workspace and weight "allocations" hand out distinct fake addresses --
+// and every ProfScope records its (shape- and kernel-tagged) name instead of timing: the list IS the dispatch of that configuration.
+inline bool& dry_run() { static thread_local bool on = false; return on; }
+inline std::vector<std::string>& dry_log() { static thread_local std::vector<std::string> log; return log; }
+inline void dry_tag(const std::string& tag) {               // a launcher's decision, appended to the record its ProfScope made
+    if (dry_run() && !dry_log().empty()) dry_log().back() += tag;
+}
+inline float* dry_fake_ptr(size_t bytes) {                  // distinct, 256-byte aligned, never dereferenced
+    static thread_local uintptr_t next = (uintptr_t)1 << 40;
+    const uintptr_t p = next;
+    next += (bytes + 255) / 256 * 256 + 256;
+    return reinterpret_cast<float*>(p);
+}
+
+}  // namespace e2v
+
+// every kernel launch of the library goes through this (skipped in a dry run)
+#define E2V_KLAUNCH(...)                                          \
+    do {                                                          \
+        if (!::e2v::dry_run()) { hipLaunchKernelGGL(__VA_ARGS__); } \
+    } while (0)
 
 namespace e2v {
 
@@ -23,12 +49,15 @@ struct Profiler {
     std::string end_json();      // synchronises, aggregates per kernel class, frees the events
 };
 Profiler& profiler();
+// shape / kernel tags on a launcher's profile name: the detailed profile (tools/shape_profile.py) and every dry run
+inline bool prof_detail() { return dry_run() || (profiler().on && profiler().detail); }
 
 struct ProfScope {
     hipStream_t s;
     bool live;
     size_t idx = 0;
     ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : s(stream), live(profiler().on) {
+        if (dry_run()) { dry_log().push_back(name); live = false; return; }      // e2v_op_describe_dispatch: the name is the record
         if (!live) return;
         ProfEntry e{name, flops, bytes, nullptr, nullptr};
         (void)hipEventCreate(&e.a);

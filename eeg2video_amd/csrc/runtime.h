@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/eeg2video_hip.h"
+#include "prof.h"
 
 namespace e2v {
 
@@ -23,6 +24,7 @@ struct Error : std::runtime_error {
 
 #define E2V_HIP(expr)                                                                                   \
     do {                                                                                                \
+        if (::e2v::dry_run()) break;                                                                    \
         hipError_t _e = (expr);                                                                         \
         if (_e != hipSuccess)                                                                           \
             throw ::e2v::Error(E2V_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
@@ -42,6 +44,7 @@ public:
     float* get(size_t floats) {
         size_t bytes = ((floats * sizeof(float) + 255) / 256) * 256;
         if (bytes == 0) bytes = 256;
+        if (dry_run()) return dry_fake_ptr(bytes);           // (put() does not know the address and ignores it)
         auto it = free_.lower_bound(bytes);
         if (it != free_.end() && it->first <= bytes + bytes / 4) {
             void* p = it->second;

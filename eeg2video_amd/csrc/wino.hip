@@ -337,8 +337,8 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
 void wino_pack_weights(const float* w_oihw, float* U, int cout, int cin, int m, hipStream_t s) {
     const size_t total = (size_t)cout * cin;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    if (m == 4) hipLaunchKernelGGL(wino4_weight_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, U, cout, cin);
-    else hipLaunchKernelGGL(wino_weight_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, U, cout, cin);
+    if (m == 4) E2V_KLAUNCH(wino4_weight_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, U, cout, cin);
+    else E2V_KLAUNCH(wino_weight_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, U, cout, cin);
 }
 
 static inline size_t wino_tiles(const WinoArgs& a, int nimg) {
@@ -368,12 +368,12 @@ void wino_conv3x3(const WinoArgs& a, float* ws, int chunk_images, hipStream_t s)
             const size_t total = T * (Ctot / 4);
             const double px = (double)a.m * a.m;                  // output pixels per tile
             std::string nm = a.gn_scsh ? "wino_in_gn_silu" : "wino_in";
-            if (profiler().on && profiler().detail)
+            if (prof_detail())
                 nm += " T" + std::to_string(T) + " C" + std::to_string(Ctot) + " m" + std::to_string(a.m) + (a.c1 ? " cat" : "") + (a.upsample ? " up" : "");
             ProfScope ps(nm.c_str(), 2.0 * P * T * Ctot, 4.0 * ((px + P) * T * Ctot), s);
             const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-            if (a.m == 4) hipLaunchKernelGGL(wino4_in_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, V);
-            else hipLaunchKernelGGL(wino_in_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, V);
+            if (a.m == 4) E2V_KLAUNCH(wino4_in_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, V);
+            else E2V_KLAUNCH(wino_in_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, V);
         }
         IgemmArgs g;
         g.a0 = V; g.c0 = Ctot; g.lda0 = Ctot; g.w = a.U; g.ldw = Ctot; g.ldw16 = Ctot;
@@ -385,12 +385,12 @@ void wino_conv3x3(const WinoArgs& a, float* ws, int chunk_images, hipStream_t s)
             const size_t total = T * (a.N / 4);
             const double px = (double)a.m * a.m;
             std::string nm = "wino_out";
-            if (profiler().on && profiler().detail)
+            if (prof_detail())
                 nm += " T" + std::to_string(T) + " N" + std::to_string(a.N) + " m" + std::to_string(a.m) + (a.resid ? " res" : "") + (a.rowbias ? " temb" : "");
             ProfScope ps(nm.c_str(), 1.5 * P * T * a.N, 4.0 * (P * T * a.N + px * T * a.N * (a.resid ? 2 : 1)), s);
             const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-            if (a.m == 4) hipLaunchKernelGGL(wino4_out_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, Mb);
-            else hipLaunchKernelGGL(wino_out_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, Mb);
+            if (a.m == 4) E2V_KLAUNCH(wino4_out_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, Mb);
+            else E2V_KLAUNCH(wino_out_kernel, dim3(blocks), dim3(256), 0, s, a, lo, n, Mb);
         }
     }
 }

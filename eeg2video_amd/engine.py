@@ -443,3 +443,31 @@ class Engine:
         self._check(self.lib.e2v_op_temporal_attention(self.ctx, qkv.data_ptr(), out.data_ptr(), n, F, HW, heads, D,
                                                        float(scale), _stream()))
         return out
+
+
+def describe_dispatch(dtype: str = "bf16", batch: int = 32, frames: int = 6, h: int = 36, w: int = 64, tokens: int = 77, config=None):
+    """Which kernel and tile every launch of ``e2v_generate`` (one guided DDIM step + decode of ``batch`` clips) takes, as a list of
+    ``"<launches>x <class> <shape> -> <kernel> <tile>"`` lines -- ``e2v_op_describe_dispatch`` on a host-only context: no GPU, no
+    weights (``tests/test_dispatch_golden.py`` pins the SD-v1-4 table)."""
+    lib = _lib.load()
+    cfg = _lib.E2VConfig()
+    lib.e2v_default_config(C.byref(cfg))
+    if config is not None:
+        for k, v in config.items():
+            setattr(cfg, k, v)
+    ctx = C.c_void_p()
+    if lib.e2v_create(C.byref(cfg), -1, C.byref(ctx)) != _lib.E2V_OK:
+        raise RuntimeError("e2v_create(host-only) failed")
+    try:
+        code = {"fp32": _lib.E2V_F32, "bf16": _lib.E2V_BF16}[dtype]
+        need = C.c_int64(0)
+        st = lib.e2v_op_describe_dispatch(ctx, code, batch, frames, h, w, tokens, None, 0, C.byref(need))
+        if st != _lib.E2V_OK:
+            raise RuntimeError(f"e2v_op_describe_dispatch: {(lib.e2v_last_error(ctx) or b'').decode()}")
+        buf = C.create_string_buffer(need.value)
+        st = lib.e2v_op_describe_dispatch(ctx, code, batch, frames, h, w, tokens, buf, need.value, C.byref(need))
+        if st != _lib.E2V_OK:
+            raise RuntimeError(f"e2v_op_describe_dispatch: {(lib.e2v_last_error(ctx) or b'').decode()}")
+        return buf.value.decode().splitlines()
+    finally:
+        lib.e2v_destroy(ctx)

@@ -69,6 +69,14 @@ e2v_status e2v_op_unet_forward_taps(e2v_ctx* ctx, const float* sample, const int
                                     int F, int H, int W, int T, float* out, float* taps, int64_t taps_cap, int64_t* shapes,
                                     int* n_taps, e2v_stream stream);
 
+/* Which kernel and tile would every launch of a configuration take?  On a HOST-ONLY context (e2v_create(cfg, -1, &ctx): no GPU, no
+ * weights) this runs e2v_generate -- one guided DDIM step + VAE decode of B clips of [4, F, h, w] latents with T conditioning tokens, the
+ * walk of UNet3DConditionModel.forward (EEG2Video/models/unet.py:278-413) and AutoencoderKL.decode -- as a dry run: every launch rule
+ * executes, nothing is launched, and each launch leaves a record "class shape -> kernel tile".  `buf` receives one line per distinct
+ * record in first-occurrence order, "<count>x <record>\n" (NUL-terminated); *needed = bytes required (call with cap = 0 to size).
+ * dtype: E2V_F32 or E2V_BF16.  E2V_ESTATE on a context that owns a device.  No reference counterpart. */
+e2v_status e2v_op_describe_dispatch(e2v_ctx* ctx, int dtype, int B, int F, int h, int w, int T, char* buf, int64_t cap, int64_t* needed);
+
 /* Test / profiling aid: set one of the run-time switches of DESIGN.md section 10 (the integer an environment variable of the
  * same name would give it at first use), for same-process A/B comparisons of kernel variants -- e.g. "E2V_BGEMM_PERS" 0/1.
  * Process-wide; E2V_EINVAL for an unknown name.  No reference counterpart. */

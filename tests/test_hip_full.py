@@ -418,3 +418,36 @@ def test_configs4_sweep_full_size_one_concept_bf16(full, capsys):
     assert mean <= 1.5 * meanp and far <= 2.0 * farp + 1e-3 and diff <= max(40.0, 2.0 * diffp), (diff, mean, far, diffp, meanp, farp)
     assert meanp < 3.0, meanp                                  # (and the bf16 frames are the fp32 frames to about a level)
     assert a.float().std() > 1.0          # not a constant image
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_dispatch_description_matches_a_real_run(full, mode, monkeypatch):
+    """tests/test_dispatch_golden.py pins what e2v_op_describe_dispatch says on a host-only context; this checks that it says what a REAL
+    call does: e2v_generate (B = 1, one guided DDIM step + decode) under the shape-tagged profiler launches exactly the described
+    classes / shapes / tile tags, the same number of times each (the '-> kernel' part of a record exists only in the description)."""
+    import re
+    from eeg2video_amd.engine import describe_dispatch
+    monkeypatch.setenv("E2V_PROFILE_DETAIL", "1")
+    pipe = full[0]
+    eng = pipe.unet.engine
+    lat = _t(counter_normal(1234, "latent", (1, 4, 6, 36, 64))).cuda()
+    cond = _t(counter_normal(1235, "cond", (1, 77, 768))).cuda()
+    unc = _t(counter_normal(1236, "uncond", (1, 77, 768))).cuda()
+    try:
+        eng.set_compute_dtype(mode)
+        eng.generate(lat, cond, unc, 1, 12.5, 0.0, decode=True)            # first use builds the weight forms (packing launches)
+        eng.profile_begin()
+        eng.generate(lat, cond, unc, 1, 12.5, 0.0, decode=True)
+        table = eng.profile_end()
+    finally:
+        eng.set_compute_dtype("fp32")
+    strip = lambda k: re.sub(r" rb1=\d+ w\d+ s\d+", "", k)
+    real = {}
+    for k, v in table.items():
+        real[strip(k)] = real.get(strip(k), 0) + int(v["launches"])
+    said = {}
+    for line in describe_dispatch(mode, 1):
+        count, rec = line.split("x ", 1)
+        name = strip(rec.split(" -> ")[0])
+        said[name] = said.get(name, 0) + int(count)
+    assert said == real, {k: (said.get(k), real.get(k)) for k in set(said) | set(real) if said.get(k) != real.get(k)}

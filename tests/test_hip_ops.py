@@ -327,6 +327,17 @@ def rb(t):
     return t.to(torch.bfloat16).float()
 
 
+def ab_build(eng):
+    """True when the library was built with `make AB=1` (-DE2V_AB): the variants that were measured and not adopted and the other arms of
+    same-process A/Bs exist together with their switches.  The shipped build refuses those switch names; the tests below then check
+    the shipped arm only."""
+    try:
+        eng.set_knob("E2V_ATTN_FOLD", 1)
+        return True
+    except ValueError:
+        return False
+
+
 def gelu_bf16_grade(x):
     """The GEGLU gate of the bf16-activation mode as the kernels evaluate it (igemm_epi.h: gelu_bf16_grade): x / (1 + exp(-(a x + b x^3))),
     |error| <= 2.8e-4 against the exact erf form (bounded in tests/test_oracle_anchors.py)."""
@@ -456,9 +467,11 @@ def test_bf16_groupnorm_row_tiled_and_sample_runs(bf, c0, c1, groups, silu):
     ref = (F.silu(ref) if silu else ref).permute(0, 2, 1).reshape(samples * P, c0 + c1)
     run = lambda: bf.op_groupnorm(a.cuda(), g.cuda(), be.cuda(), samples=samples, P=P, groups=groups, eps=1e-5, silu=silu,
                                   x1=s.cuda() if c1 else None)
+    whole = run()
+    close(whole, ref, rtol=8e-3, atol=8e-3)
+    if not ab_build(bf):
+        return                                                # (the two other arms exist in `make AB=1` builds only)
     try:
-        bf.set_knob("E2V_GN_ROWS", 1); bf.set_knob("E2V_GN_GROUP_MB", 0)
-        whole = run()
         bf.set_knob("E2V_GN_GROUP_MB", 1)                     # 0.45 .. 2.7 MB per sample -> runs of one or two samples
         runs = run()
         bf.set_knob("E2V_GN_ROWS", 0)
@@ -466,7 +479,6 @@ def test_bf16_groupnorm_row_tiled_and_sample_runs(bf, c0, c1, groups, silu):
     finally:
         bf.set_knob("E2V_GN_ROWS", 1); bf.set_knob("E2V_GN_GROUP_MB", 0)
     assert torch.equal(whole, runs)
-    close(whole, ref, rtol=8e-3, atol=8e-3)
     close(whole, flat, rtol=8e-3, atol=8e-3)
 
 
@@ -674,6 +686,8 @@ def test_bf16_t256_tail_split(bf256):
     launch of 256 x 192 and 256 x 128 tiles (bgemm_t256_tail_kernel).  Same k order per output: bit-identical to the unsplit launch.
     Linear (persistent main part, residual) and 3x3 conv (time-embedding rows, residual, a ragged last row block)."""
     bf = bf256
+    if not ab_build(bf):
+        pytest.skip("the tail split was measured and not adopted: its kernel exists in `make AB=1` builds only")
     m, k, n = 256 * 66 + 40, 320, 1280                     # 67 row blocks x 4 column tiles = 268 tiles: one full round + 12
     x, w, b, r = rnd(m, k, seed=190), rnd(n, k, seed=191, scale=0.05), rnd(n, seed=192), rnd(m, n, seed=193)
     nimg, c, cout, h, wd = 118, 64, 1280, 9, 16             # M = 16 992 = 66.4 row blocks
@@ -754,20 +768,25 @@ def test_bf16_attention_64_queries_per_wave(eng, d, nq, f, n):
         eng.set_compute_dtype("bf16")
         g = qkv.cuda()
         run = lambda: eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5)
+        ab = ab_build(eng)
         y = run()                                         # the software-pipelined form (the default at d = 40)
-        eng.set_knob("E2V_ATTN_Q64P", 0)
-        yp = run()                                        # the phase-by-phase form
+        if ab:
+            eng.set_knob("E2V_ATTN_Q64P", 0)
+            yp = run()                                    # the phase-by-phase form (`make AB=1` builds only)
         eng.set_knob("E2V_ATTN_Q64", 0)
         y32 = run()
     finally:
-        eng.set_knob("E2V_ATTN_Q64", 1); eng.set_knob("E2V_ATTN_Q64P", 1)
+        eng.set_knob("E2V_ATTN_Q64", 1)
+        if ab:
+            eng.set_knob("E2V_ATTN_Q64P", 1)
         eng.set_compute_dtype("fp32")
-    # phase form: same MFMA sequence per (query, key tile) and the same maximum decisions per 32-query block as the 32-query kernel
-    assert torch.equal(yp, y32)
     # pipelined form: the reference maximum is a bf16 number carried in Q, so P rounds differently: same softmax, other roundings
     assert not torch.equal(y, y32)
     close(y.reshape(n * f, nq, c), ref, rtol=1e-2, atol=1e-2)            # bf16 rounding of P and of the output
-    close(yp.reshape(n * f, nq, c), ref, rtol=1e-2, atol=1e-2)
+    close(y32.reshape(n * f, nq, c), ref, rtol=1e-2, atol=1e-2)
+    close(y, y32, rtol=1e-2, atol=1e-2)
+    if ab:      # phase form: same MFMA sequence per (query, key tile) and the same maximum decisions per 32-query block as the 32-query kernel
+        assert torch.equal(yp, y32)
 
 
 @pytest.mark.parametrize("boost", [3.0, 25.0])
@@ -792,15 +811,21 @@ def test_bf16_attention_deferred_maximum_branches(eng, boost):
         eng.set_compute_dtype("bf16")
         g = qkv.cuda()
         outs = []
-        for q64, q64p, fold in ((1, 1, 1), (1, 0, 1), (0, 0, 1), (0, 0, 0)):   # 64 queries per wave (attn_q64.hip: pipelined, phase form), then the 32-query kernel's two forms
+        ab = ab_build(eng)
+        # 64 queries per wave (attn_q64.hip, pipelined), the 32-query kernel; `make AB=1` builds: + the phase form and the plain (no fold) form
+        arms = ((1, 1, 1), (0, 1, 1)) + (((1, 0, 1), (0, 0, 0)) if ab else ())
+        for q64, q64p, fold in arms:
             eng.set_knob("E2V_ATTN_Q64", q64)
-            eng.set_knob("E2V_ATTN_Q64P", q64p)
-            eng.set_knob("E2V_ATTN_FOLD", fold)
+            if ab:
+                eng.set_knob("E2V_ATTN_Q64P", q64p)
+                eng.set_knob("E2V_ATTN_FOLD", fold)
             outs.append(eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5))
     finally:
-        eng.set_knob("E2V_ATTN_FOLD", 1)
-        eng.set_knob("E2V_ATTN_Q64", 1); eng.set_knob("E2V_ATTN_Q64P", 1)
+        eng.set_knob("E2V_ATTN_Q64", 1)
+        if ab:
+            eng.set_knob("E2V_ATTN_FOLD", 1); eng.set_knob("E2V_ATTN_Q64P", 1)
         eng.set_compute_dtype("fp32")
-    assert torch.equal(outs[1], outs[2])                     # both sides of the threshold: the phase form and the 32-query kernel decide and round alike
+    if ab:
+        assert torch.equal(outs[2], outs[1])                 # both sides of the threshold: the phase form and the 32-query kernel decide and round alike
     for y in outs:
         close(y.reshape(n * f, nq, c), ref, rtol=2e-2, atol=2e-2)

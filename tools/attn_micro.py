@@ -29,7 +29,13 @@ def run(mode, n, variants):
         print(f"{mode} {name} n={n}: " + "  ".join(f"[{v or 'default'}] {best[v]:.3f} ms {alg/best[v]/1e9:.0f} TF" for v in variants))
 run("fp32", 16, [""])
 if os.environ.get("OLD_VARIANTS"):
-    run("bf16", 64, ["E2V_ATTN_Q64=0,E2V_ATTN_FOLD=0,E2V_ATTN_KT64=0", "E2V_ATTN_Q64=0,E2V_ATTN_FOLD=1,E2V_ATTN_KT64=0", "E2V_ATTN_Q64=0,E2V_ATTN_FOLD=0,E2V_ATTN_KT64=1"])
-run("bf16", 64, ["E2V_ATTN_Q64=0,E2V_ATTN_FOLD=1,E2V_ATTN_KT64=1", "E2V_ATTN_Q64=1,E2V_ATTN_Q64P=0", "E2V_ATTN_Q64=1,E2V_ATTN_Q64P=1"] + [v for v in os.environ.get("EXTRA_VARIANTS", "").split(";") if v])
-eng.set_knob("E2V_ATTN_Q64", 1); eng.set_knob("E2V_ATTN_Q64P", 1); eng.set_knob("E2V_ATTN_Q64_NW", 0)
+    run("bf16", 64, ["E2V_ATTN_Q64=0,E2V_ATTN_FOLD=0,E2V_ATTN_KT64=0", "E2V_ATTN_Q64=0,E2V_ATTN_FOLD=1,E2V_ATTN_KT64=0", "E2V_ATTN_Q64=0,E2V_ATTN_FOLD=0,E2V_ATTN_KT64=1"])   # (AB=1 build)
+try:                                   # `make AB=1` builds carry the other arms (phase form, plain softmax, forced workgroup sizes)
+    eng.set_knob("E2V_ATTN_Q64P", 1); AB = True
+except ValueError:
+    AB = False
+run("bf16", 64, ["E2V_ATTN_Q64=0", "E2V_ATTN_Q64=1"] + (["E2V_ATTN_Q64=1,E2V_ATTN_Q64P=0"] if AB else []) + [v for v in os.environ.get("EXTRA_VARIANTS", "").split(";") if v])
+eng.set_knob("E2V_ATTN_Q64", 1)
+if AB:
+    eng.set_knob("E2V_ATTN_Q64P", 1); eng.set_knob("E2V_ATTN_Q64_NW", 0)
 eng.set_compute_dtype("fp32")
