@@ -781,6 +781,16 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
             if (tail > 0 && tail * per_rb <= 0.5 * xslots) a.rb1 = nbm - 8 * tail < 0 ? 0 : nbm - 8 * tail;
         }
     }
+    // Launches of only a few rounds (the level-2 linears of a B = 8 pass: 1080 tiles of 128 x 128 on 768 slots = 1.4 rounds) leave the
+    // chip part idle in their last round.  E2V_IGEMM_HALF_BELOW = r x 100 > 0: a launch of fewer than r rounds of full-size tiles runs
+    // ENTIRELY as 128 x 64 tiles (twice the workgroups at half the work: the round granularity halves; same k order per output, so
+    // bit-identical).  Same-process A/B: profiles/r04_shape_ab_fp32_tail.log.
+    static const int* const half_below = knob("E2V_IGEMM_HALF_BELOW", 0);
+    if (!a.a_bf16 && *half_below > 0 && !a.geglu && a.w1 > 0 && a.rb1 > 0) {
+        const double per_rb = a.w1 + 0.5 * a.s1;
+        const double rounds = per_rb * ((nbm + 7) / 8) / (slots / 8);
+        if (rounds * 100.0 < (double)*half_below) a.rb1 = 0;
+    }
     if (a.a_bf16 && bgemm_all_n64(a)) a.rb1 = 0;
     a.nbm = nbm;
     a.tail_rb = (nbm - a.rb1 + 7) / 8;                       // per XCD chunk (rb1 == 0: every row block is "tail")
