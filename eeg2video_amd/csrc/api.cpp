@@ -576,6 +576,7 @@ e2v_status e2v_op_describe_dispatch(e2v_ctx* c, int dtype, int B, int F, int h, 
     const float* fake = dry_fake_ptr(1 << 20);
     st = e2v_generate(c, fake, fake, fake, 1, B, F, h, w, T, 1, 12.5f, 0.0f, dry_fake_ptr(1 << 20), nullptr, nullptr);
     c->bf16_compute = was_bf16;
+    (void)hipGetLastError();          // nothing the dry run touched may linger as the thread's "last error" of a later real call
     if (st != E2V_OK) return st;
     std::vector<std::pair<std::string, long>> agg;
     std::unordered_map<std::string, size_t> at;

@@ -517,14 +517,14 @@ struct Runner {
         const size_t need_s = (size_t)samples * C * 2;
         if (need_p > c->gn_part_floats) {
             E2V_HIP(hipStreamSynchronize(s));
-            if (c->gn_part) (void)hipFree(c->gn_part);
+            if (c->gn_part && !dry_run()) (void)hipFree(c->gn_part);
             E2V_HIP(hipMalloc((void**)&c->gn_part, need_p * sizeof(float)));
             if (dry_run()) c->gn_part = dry_fake_ptr(need_p * sizeof(float));       // (pointers steer the graph: a null workspace reads as "no GroupNorm in front")
             c->gn_part_floats = need_p;
         }
         if (need_s > c->gn_scale_floats) {
             E2V_HIP(hipStreamSynchronize(s));
-            if (c->gn_scale) (void)hipFree(c->gn_scale);
+            if (c->gn_scale && !dry_run()) (void)hipFree(c->gn_scale);
             E2V_HIP(hipMalloc((void**)&c->gn_scale, need_s * sizeof(float)));
             if (dry_run()) c->gn_scale = dry_fake_ptr(need_s * sizeof(float));
             c->gn_scale_floats = need_s;

@@ -353,8 +353,13 @@ static void groupnorm_stats_launch(const GroupNormArgs& a, hipStream_t s) {
             E2V_KLAUNCH(gn_partial_kernel<float>, dim3(chunks, a.samples), dim3(256), 0, s, x, ld, C, a.P, chunks, a.ws_part, Ctot,
                                coff, qt, crows);
     };
-    part(a.x0, a.ld0, a.c0, 0);
-    if (a.c1 > 0) part(a.x1, a.ld1, a.c1, a.c0);
+    // timing experiment (make ab): E2V_GN_SKIP_PARTIAL = 1 drops the statistics pass over the tensor -- RESULTS ARE WRONG -- to measure
+    // the ceiling of what statistics taken in the producers' epilogues could save (profiles/r04_gn_stats_ceiling.log)
+    static const int* const skip_partial = E2V_AB_KNOB("E2V_GN_SKIP_PARTIAL", 0);
+    if (!*skip_partial) {
+        part(a.x0, a.ld0, a.c0, 0);
+        if (a.c1 > 0) part(a.x1, a.ld1, a.c1, a.c0);
+    }
     E2V_KLAUNCH(gn_finalize_kernel, dim3(a.groups, a.samples), dim3(64), 0, s, a.ws_part, chunks, Ctot, a.groups,
                        a.P, a.eps, a.gamma, a.beta, a.ws_scale);
 }
