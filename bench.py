@@ -279,7 +279,8 @@ def configs2_leg(eng, args, host_frames_u8=None):
         eng.generate(lat, cond, unc, args.ddim_steps, args.guidance, 0.0, decode=True)
         table = eng.profile_end()
         torch.cuda.synchronize()
-        n = args.configs2_steps
+        # 4 timed passes where the driver's 600 s budget has room for them (the whole default run aims at <= 400 s); on a slower box 3
+        n = args.configs2_steps if args.configs2_steps != 4 or process_age_s() < 355.0 else 3
         t0 = time.perf_counter()
         for _ in range(n):
             frames = eng.generate(lat, cond, unc, args.ddim_steps, args.guidance, 0.0, decode=True)

@@ -136,3 +136,27 @@ def test_ddim_step_then_next_step_is_the_identity_for_every_golden_case():
         eps = torch.randn(2, 4, 3, 5, 6, generator=g, dtype=torch.float64)
         back = next_step(eps, t, s.step(eps, t, x), s)
         assert (back - x).abs().max().item() < 1e-10, (n, t)
+
+
+def test_generate_trace_holds_unguided_eps_and_block_taps():
+    """oracle.generate(trace=...): per step the guided eps, the two unguided halves (eps = eps_u + g (eps_c - eps_u), checked) and the
+    latents; with trace["taps_step"] = k also the block outputs of step k's UNet forward (the keys the HIP side's
+    e2v_op_unet_forward_taps returns, shapes of a [2 B, ...] guidance pair) -- what the block-granularity GPU tests compare against."""
+    from eeg2video_amd.weights import TINY_UNET, TINY_VAE, counter_normal, synth_state_dict, unet_param_spec, vae_param_spec
+    from oracle import generate
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    usd = {k: t(v) for k, v in synth_state_dict(unet_param_spec(TINY_UNET), seed=42, mode="perturbed").items()}
+    vsd = {k: t(v) for k, v in synth_state_dict(vae_param_spec(TINY_VAE), seed=43, mode="perturbed").items()}
+    lat = t(counter_normal(1, "lat", (1, 4, 3, 8, 12)))
+    cond = t(counter_normal(2, "cond", (1, 7, TINY_UNET.cross_attention_dim)))
+    unc = t(counter_normal(3, "unc", (1, 7, TINY_UNET.cross_attention_dim)))
+    trace = {"taps_step": 1}
+    with torch.no_grad():
+        generate(usd, TINY_UNET, vsd, TINY_VAE, lat, cond, unc, 2, 12.5, trace=trace, decode=False)
+    assert len(trace["eps"]) == len(trace["eps_u"]) == len(trace["eps_c"]) == len(trace["latents"]) == 2
+    for e, u, c in zip(trace["eps"], trace["eps_u"], trace["eps_c"]):
+        assert torch.equal(e, u + 12.5 * (c - u))
+    taps = trace["taps"]
+    assert tuple(taps) == ("emb", "down0", "down1", "down2", "down3", "mid", "up0", "up1", "up2", "up3")
+    boc = TINY_UNET.block_out_channels
+    assert taps["emb"].shape == (2, 4 * boc[0]) and taps["down0"].shape[:3] == (2, boc[0], 3) and taps["up3"].shape == (2, boc[0], 3, 8, 12)
