@@ -77,7 +77,7 @@ def test_committed_bench_lines_keep_the_contract_and_quote_the_committed_pmc_tra
     import json
     prof = os.path.join(ROOT, "profiles")
     pmc = json.load(open(os.path.join(prof, "pmc_dominant_kernel.json")))
-    d = json.load(open(os.path.join(prof, "r03_bench_default.json")))
+    d = json.load(open(os.path.join(prof, "r04_bench_default.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
         assert k in d, k
@@ -91,7 +91,7 @@ def test_committed_bench_lines_keep_the_contract_and_quote_the_committed_pmc_tra
     c2 = d["configs2"]
     assert c2["dtype"] == "bf16" and c2["value"] > 0 and c2["roofline"]["kernel"] == "igemm_bf16"
     assert c2["roofline"]["traffic"] == pmc["igemm_bf16"]["hbm_bytes_per_launch"] and pmc["igemm_bf16"]["batch"] == 32
-    b = json.load(open(os.path.join(prof, "r03_bench_bf16_b32.json")))
+    b = json.load(open(os.path.join(prof, "r04_bench_bf16_b32.json")))
     assert b["dtype"] == "bf16" and b["roofline"]["traffic"] == pmc["igemm_bf16"]["hbm_bytes_per_launch"]
     wp = b["roofline"]["whole_path"]
     assert abs(wp["achieved_tflops"] - b["value"] * wp["algorithmic_tflop_per_clip"]) < 1e-6 and abs(wp["frac"] - wp["achieved_tflops"] / wp["peak"]) < 1e-9
