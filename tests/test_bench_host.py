@@ -71,7 +71,7 @@ def test_gather_options_and_budget_guard_parse(bench):
 
 
 def test_committed_bench_lines_keep_the_contract_and_quote_the_committed_pmc_traffic():
-    """profiles/r03_bench_*.json are the lines `bench.py` printed on the GPU box: the driver's contract keys, the `roofline` and
+    """profiles/r04_bench_*.json are the lines `bench.py` printed on the GPU box: the driver's contract keys, the `roofline` and
     `cpu_baseline` objects, the `configs2` leg in the default line -- and `roofline.traffic` must be the figure of
     profiles/pmc_dominant_kernel.json for that batch / dtype (the PMC passes and the bench lines are regenerated together)."""
     import json
