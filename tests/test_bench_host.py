@@ -93,5 +93,9 @@ def test_committed_bench_lines_keep_the_contract_and_quote_the_committed_pmc_tra
     assert c2["roofline"]["traffic"] == pmc["igemm_bf16"]["hbm_bytes_per_launch"] and pmc["igemm_bf16"]["batch"] == 32
     b = json.load(open(os.path.join(prof, "r04_bench_bf16_b32.json")))
     assert b["dtype"] == "bf16" and b["roofline"]["traffic"] == pmc["igemm_bf16"]["hbm_bytes_per_launch"]
+    # README / DESIGN quote the bf16 parity figure of THIS committed line (it moves with every change of a rounding)
+    quoted = f"{b['parity']['frames_max_abs']:.1e}".replace("e-0", "e-")
+    for doc in ("README.md", "DESIGN.md"):
+        assert quoted in open(os.path.join(ROOT, doc)).read(), (doc, quoted)
     wp = b["roofline"]["whole_path"]
     assert abs(wp["achieved_tflops"] - b["value"] * wp["algorithmic_tflop_per_clip"]) < 1e-6 and abs(wp["frac"] - wp["achieved_tflops"] / wp["peak"]) < 1e-9
