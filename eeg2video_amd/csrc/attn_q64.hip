@@ -396,7 +396,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 for (int e = 0; e < 8; ++e) a[e] = (__bf16)((float)a[e] * qs);
                 qf[b][s] = a;
             }
-            if (h) qf[b][KS - 1][1] = (__bf16)-32768.0f;            // slot D + 1: times the marker column of a key past its segment's end
+            if (h) qf[b][KS - 1][2] = (__bf16)-32768.0f;            // slot D + 2: times the marker column of a key past its segment's end
         }
     }
 
@@ -432,8 +432,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             vreg[e] = __builtin_bit_cast(qf32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
         }
     };
-    // Keys past the end of a segment (its ragged last stage) are masked by the MATRIX pipe as well: column D + 1 of their K rows holds
-    // 1.0 (0 in every real key's row) and slot D + 1 of every query's Q fragment holds -2^15, so their scores come out of the MFMA
+    // Keys past the end of a segment (its ragged last stage) are masked by the MATRIX pipe as well: column D + 2 of their K rows holds
+    // 1.0 (0 in every real key's row) and slot D + 2 of every query's Q fragment holds -2^15, so their scores come out of the MFMA
     // near -32768 and exponentiate to zero -- no select in the loop, no second instance of its body.  The thread that stores the
     // first piece of a K row rewrites the row's two marker columns with every stage (the ring reuses the buffer).
     auto store_stage = [&](const int buf, const int left) {     // left: valid keys from the stage's first on
@@ -444,7 +444,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             if (tid + NT * e < NP) {
                 *reinterpret_cast<qf32x4*>(Kl + ld_row[e] * KROW + ld_c8[e] * 16) = kreg[e];
                 *reinterpret_cast<qf32x4*>(Vl + ld_row[e] * VROW + ld_c8[e] * 16) = vreg[e];
-                if (ld_c8[e] == 0) *reinterpret_cast<unsigned*>(Kl + ld_row[e] * KROW + D * 2) = ld_row[e] < left ? 0x00003F80u : 0x3F803F80u;
+                if (ld_c8[e] == 0) {                            // columns D, D + 1: 1.0 (the two maximum slots); D + 2: the marker; D + 3: 0
+                    unsigned* mk = reinterpret_cast<unsigned*>(Kl + ld_row[e] * KROW + D * 2);
+                    mk[0] = 0x3F803F80u;
+                    mk[1] = ld_row[e] < left ? 0u : 0x00003F80u;
+                }
             }
         }
     };
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][t][r] = 0.f;
-    float mref[2] = {0.f, 0.f};                   // the reference maximum of the lane's query (a bf16 number)
+    float mref[2] = {0.f, 0.f};                   // the reference maximum of the lane's query (the sum of two bf16 numbers)
 
     load_stage(0);
     store_stage(0, stage_keys(0));
@@ -498,7 +502,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             constexpr float DEFER = 8.0f;
             const float d = first ? mt : (mt > DEFER ? mt : 0.f);
-            const float mnew = (float)(__bf16)(mref[b] + d);
+            // the new reference as TWO bf16 numbers (16 mantissa bits: within 2^-16 of the wanted value at any magnitude, so that a row
+            // of huge scores neither overflows its probabilities nor underflows them all)
+            const float want = mref[b] + d;
+            const __bf16 m_hi = (__bf16)want;
+            const __bf16 m_lo = (__bf16)(want - (float)m_hi);
+            const float mnew = (float)m_hi + (float)m_lo;
             const float delta = mnew - mref[b];
             mref[b] = mnew;
             const float alpha = __builtin_amdgcn_exp2f(-delta);
@@ -510,8 +519,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[b][t][r] *= alpha;
             }
-            const __bf16 slot = (__bf16)(-mnew);
-            qf[b][KS - 1][0] = h ? slot : qf[b][KS - 1][0];      // k = D lives in the upper half-wave's fragment of the last k-step
+            qf[b][KS - 1][0] = h ? (__bf16)(-(float)m_hi) : qf[b][KS - 1][0];      // k = D, D + 1 live in the upper half-wave's fragment of the last k-step
+            qf[b][KS - 1][1] = h ? (__bf16)(-(float)m_lo) : qf[b][KS - 1][1];
         }
     };
     // One iteration: scores of the NEXT tile into Sn (from the K fragment registers), softmax numerators and PV of THIS tile (scores

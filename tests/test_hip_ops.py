@@ -789,6 +789,31 @@ def test_bf16_attention_64_queries_per_wave(eng, d, nq, f, n):
         assert torch.equal(yp, y32)
 
 
+def test_bf16_attention_64_queries_per_wave_huge_scores(eng):
+    """The pipelined 64-query kernel carries a row's reference maximum in Q as the sum of two bf16 numbers.  Queries scaled 400x put
+    the scores in the thousands (one bf16 number would be off by up to 16 there and a far larger factor beyond): the softmax is then
+    nearly one-hot, must stay finite, and must pick the same keys as the fp32 reference on the bf16-rounded operands."""
+    heads, d, n, f, nq = 8, 40, 1, 3, 256
+    c = heads * d
+    qkv = rnd(n * f * nq, 3 * c, seed=281)
+    qkv[:, :c] *= 400.0
+    qs = d ** -0.5 * 1.4426950408889634
+    q = (rb(rb(qkv[:, :c]) * qs) / qs).reshape(n * f, nq, c)
+    k, v = (rb(qkv[:, i * c:(i + 1) * c]).reshape(n * f, nq, c) for i in (1, 2))
+    former = torch.arange(f) - 1
+    former[0] = 0
+    gather = lambda t: torch.cat([t.reshape(n, f, nq, c)[:, [0] * f], t.reshape(n, f, nq, c)[:, former]], dim=2).reshape(n * f, 2 * nq, c)
+    ref = _unheads(_ref_attn(_heads(q, heads), _heads(gather(k), heads), _heads(gather(v), heads), d ** -0.5), heads)
+    try:
+        eng.set_compute_dtype("bf16")
+        g = qkv.cuda()
+        y = eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5)
+    finally:
+        eng.set_compute_dtype("fp32")
+    assert torch.isfinite(y).all()
+    close(y.reshape(n * f, nq, c), ref, rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("boost", [3.0, 25.0])
 def test_bf16_attention_deferred_maximum_branches(eng, boost):
     """bf16 attention keeps a row's reference maximum until a score exceeds it by more than 2^8 (the rescale of the accumulators is
