@@ -88,6 +88,7 @@ SIGNATURES = {
     "e2v_op_to_channels_last": (_i, [_ctx, _p, _p, _i, _i, _i, _i, _stream]),
     "e2v_op_from_channels_last": (_i, [_ctx, _p, _i, _p, _i, _i, _i, _stream]),
     "e2v_op_set_knob": (_i, [C.c_char_p, _i]),
+    "e2v_op_rowblock_sums": (_i, [_ctx, _p, _i64, _i, _p, _stream]),
     "e2v_op_describe_dispatch": (_i, [_ctx, _i, _i, _i, _i, _i, _i, C.c_char_p, _i64, c_int64_p]),
     "e2v_op_unet_forward_taps": (_i, [_ctx, _p, c_int64_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i64, c_int64_p, C.POINTER(_i), _stream]),
 }

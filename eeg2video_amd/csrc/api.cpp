@@ -854,6 +854,20 @@ e2v_status e2v_op_layernorm(e2v_ctx* c, const float* x, int64_t rows, int C, con
     });
 }
 
+// Test aid: the canonical row-block sums a GroupNorm takes instead of its statistics pass (norm.hip rowblock_sums; what the staged
+// epilogue of bgemm_t256_kernel leaves with a conv's output): x is rounded to bf16 first, out[rows / 64][C][2] = (sum, sum of squares).
+e2v_status e2v_op_rowblock_sums(e2v_ctx* c, const float* x, int64_t rows, int C, float* out, e2v_stream stream) {
+    if (!c) return E2V_EINVAL;
+    return guarded(c, [&] {
+        E2V_REQUIRE(x && out && rows > 0 && rows % 64 == 0 && C > 0 && C % 8 == 0, E2V_EINVAL, "rowblock_sums: rows must be a multiple of 64, C of 8");
+        hipStream_t s = S(c, stream);
+        Act b(c->pool, rows, C, true);
+        cvt_rows(x, C, 0, b.p, C, 1, rows, C, C, s);
+        rowblock_sums(b.p, C, C, rows, rbsum_rows_per_pass(C), out, s);
+        E2V_HIP(hipGetLastError());
+    });
+}
+
 e2v_status e2v_op_attention(e2v_ctx* c, const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,
                             int n, int F, int heads, int D, int Nq, int Nk, int mode, float scale, e2v_stream stream) {
     if (!c) return E2V_EINVAL;

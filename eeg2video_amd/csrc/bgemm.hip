@@ -47,7 +47,7 @@ bool set_knob(const char* name, int value) {
                                             "E2V_BGEMM_T256P_BIAS_LDS", "E2V_ATTN_KT64", "E2V_ATTN_Q64", "E2V_ATTN_CROSS_RESIDENT", "E2V_TATTN_WAVE",
                                             "E2V_GN_CHUNK_ROWS", "E2V_GN_CHUNK_ROWS_SMALL", "E2V_IGEMM_HALF_BELOW", "E2V_LN_ROWS", "E2V_BGEMM_UP2X"
 #ifdef E2V_AB                                // variants measured and not adopted / the other arm of an A/B: `make AB=1` builds only
-                                            , "E2V_BGEMM_S3", "E2V_BGEMM_LIN", "E2V_BGEMM_T256_TAIL", "E2V_ATTN_FOLD", "E2V_ATTN_Q64P", "E2V_ATTN_Q64_NW", "E2V_GN_ROWS", "E2V_GN_GROUP_MB", "E2V_GN_SKIP_PARTIAL"
+                                            , "E2V_BGEMM_S3", "E2V_BGEMM_LIN", "E2V_BGEMM_T256_TAIL", "E2V_ATTN_FOLD", "E2V_ATTN_Q64P", "E2V_ATTN_Q64_NW", "E2V_GN_ROWS", "E2V_GN_GROUP_MB", "E2V_GN_SKIP_PARTIAL", "E2V_GN_RB", "E2V_GN_RB_EPILOGUE"
 #endif
 #ifdef E2V_ABLATE
                                             , "E2V_BGEMM_ABLATE"

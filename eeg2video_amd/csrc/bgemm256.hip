@@ -48,7 +48,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t t256_rsrc(const void* ptr, con
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, records, 0x00020000);
 }
 
-template <int NT, bool LIN>
+template <int NT, bool LIN, bool RB = false>      // RB: the launch leaves row-block sums for a following GroupNorm (IgemmArgs::rbsum)
 __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, const int col_off) {
     constexpr int BM = 256, WN = 16 * NT, BN = 4 * WN;
     constexpr int N0 = (NT + 1) / 2, N1 = NT / 2;            // column tiles of a wave: first group (phases 0, 3), second group (phases 1, 2)
@@ -502,11 +502,83 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
         if (c + 1 < 4) stage(c + 1);
         __builtin_amdgcn_sched_barrier(0);
     }
+    // ---- row-block sums for a following GroupNorm (IgemmArgs::rbsum; RB instances only).  Taken AFTER the epilogue, from the stored
+    // tile: every lane reads back the 8-column pieces IT has just written (its own stores, still in the L2 of its XCD) and adds them
+    // in the canonical order of rowblock_sums (norm.hip) -- per 32-row chunk pass by pass (plain add; squares by fma), chunk 0 + chunk
+    // 1 of a 64-row half, then the rpi lanes of a piece in lane order through LDS; the first of them stores the piece's 16 numbers.
+    // Adding them inside rows() instead cost nothing in time but 16 live values at the epilogue's register peak, and the allocator
+    // answered with reloads -- each a vmcnt(0) behind the DMA -- INSIDE the K loop; here every accumulator is dead and nothing
+    // new lives across the loop (the lane's values are rebuilt from an opaque copy of the lane id).
+    if constexpr (RB) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile's stores have left the wave
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));
+        const int lpr2 = WN / 8, rpi2 = 64 / lpr2;
+        const int ocol2 = (l2 % lpr2) * 8, orow2 = l2 / lpr2;
+        const int nn2 = n0 + wc * WN + ocol2;
+        const bool on2 = orow2 < rpi2 && nn2 < p.N;
+        float* const rbl = reinterpret_cast<float*>(smem) + wave * 32 * SLD + l2 * 16;   // inside the wave's OWN staging block (dead now; the other waves' may not be)
+        const __bf16* const outp = reinterpret_cast<const __bf16*>(p.out);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 hs0 = {0.f, 0.f, 0.f, 0.f}, hs1 = hs0, hq0 = hs0, hq1 = hs0;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int m0 = bm * BM + wr * 128 + half * 64 + cc * 32;
+                bf16x8 v[ITER_N];
+#pragma unroll
+                for (int it = 0; it < ITER_N; ++it) {
+                    const int r = orow2 + it * rpi2;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[it][e] = (__bf16)0.f;
+                    if (on2 && r < 32 && m0 + r < p.M) v[it] = *reinterpret_cast<const bf16x8*>(outp + (size_t)(m0 + r) * p.ldc + nn2);
+                }
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, q0 = s0, q1 = s0;
+#pragma unroll
+                for (int it = 0; it < ITER_N; ++it) {
+                    const int r = orow2 + it * rpi2;
+                    if (on2 && r < 32 && m0 + r < p.M) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v0 = (float)v[it][e], v1 = (float)v[it][4 + e];
+                            s0[e] += v0; s1[e] += v1;
+                            q0[e] = __builtin_fmaf(v0, v0, q0[e]); q1[e] = __builtin_fmaf(v1, v1, q1[e]);
+                        }
+                    }
+                }
+                if (cc == 0) { hs0 = s0; hs1 = s1; hq0 = q0; hq1 = q1; }
+                else { hs0 += s0; hs1 += s1; hq0 += q0; hq1 += q1; }
+            }
+            asm volatile("" ::: "memory");                   // (the other lanes' reads of the previous half are done: LDS is in order per wave)
+            *reinterpret_cast<f32x4*>(rbl) = hs0; *reinterpret_cast<f32x4*>(rbl + 4) = hs1;
+            *reinterpret_cast<f32x4*>(rbl + 8) = hq0; *reinterpret_cast<f32x4*>(rbl + 12) = hq1;
+            // the reads below fetch what OTHER lanes of the wave have just written: the compiler sees one base pointer with disjoint
+            // offsets and would hoist them over the stores
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const long long mh = (long long)bm * BM + wr * 128 + half * 64;
+            if (orow2 == 0 && nn2 < p.N && mh < p.M) {
+                f32x4 t0 = hs0, t1 = hs1, u0 = hq0, u1 = hq1;
+                for (int jj = 1; jj < rpi2; ++jj) {
+                    const float* o = rbl + jj * lpr2 * 16;
+                    t0 += *reinterpret_cast<const f32x4*>(o); t1 += *reinterpret_cast<const f32x4*>(o + 4);
+                    u0 += *reinterpret_cast<const f32x4*>(o + 8); u1 += *reinterpret_cast<const f32x4*>(o + 12);
+                }
+                float* d = p.rbsum + ((size_t)(mh >> 6) * p.N + nn2) * 2;
+                *reinterpret_cast<f32x4*>(d) = f32x4{t0[0], u0[0], t0[1], u0[1]};
+                *reinterpret_cast<f32x4*>(d + 4) = f32x4{t0[2], u0[2], t0[3], u0[3]};
+                *reinterpret_cast<f32x4*>(d + 8) = f32x4{t1[0], u1[0], t1[1], u1[1]};
+                *reinterpret_cast<f32x4*>(d + 12) = f32x4{t1[2], u1[2], t1[3], u1[3]};
+            }
+        }
+    }
 }
 
-template <int NT, bool LIN>
+template <int NT, bool LIN, bool RB = false>
 __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
-    t256_body<NT, LIN>(p, blockIdx.x, p.col_off);
+    t256_body<NT, LIN, RB>(p, blockIdx.x, p.col_off);
 }
 
 #ifdef E2V_AB          // measured, not adopted
@@ -1010,7 +1082,7 @@ static void t256_launch_part(IgemmArgs a, const int cols, const int rb0, const i
     // (the epilogue reads the residual in the output's type: fp32 with fp32 at the test entry points, bf16 with bf16 in the graph)
     const bool io_ok = !a.resid || (a.out_f32 ? !a.resid_bf16 : a.resid_bf16 != 0);
     // (the persistent epilogue adds no per-sample row bias: such a launch -- none in the graph today -- stays on the tile kernel)
-    if (allow_persistent && lin && io_ok && !a.rowbias && *persp && (*persp == 2 || (a.c0 + a.c1 <= *pmaxk && ntiles >= *pmint))) {
+    if (allow_persistent && lin && io_ok && !a.rowbias && !a.rbsum && *persp && (*persp == 2 || (a.c0 + a.c1 <= *pmaxk && ntiles >= *pmint))) {
         // bias in LDS where it fits behind the operand buffers (160 KB per CU) and the epilogue loads nothing else (no residual)
         static const int* const bldsp = knob("E2V_BGEMM_T256P_BIAS_LDS", 1);
         const bool blds = *bldsp && !a.resid && smem + (size_t)a.N * 4 <= (size_t)160 * 1024;      // (no bias: the LDS copy is zeros)
@@ -1039,14 +1111,28 @@ static void t256_launch_part(IgemmArgs a, const int cols, const int rb0, const i
     }
     dry_tag(nt == 0 ? std::string(" -> bgemm_t256_tail_kernel 256x192+256x128") : std::string(" -> bgemm_t256_kernel 256x") + std::to_string(64 * nt));
     switch (nt) {
+#ifdef E2V_AB              // (the instances that leave row-block sums: measured and not adopted)
+        case 5: if (lin) go(bgemm_t256_kernel<5, true>); else if (a.rbsum) go(bgemm_t256_kernel<5, false, true>); else go(bgemm_t256_kernel<5, false>); break;
+        case 4: if (lin) go(bgemm_t256_kernel<4, true>); else if (a.rbsum) go(bgemm_t256_kernel<4, false, true>); else go(bgemm_t256_kernel<4, false>); break;
+#else
         case 5: if (lin) go(bgemm_t256_kernel<5, true>); else go(bgemm_t256_kernel<5, false>); break;
         case 4: if (lin) go(bgemm_t256_kernel<4, true>); else go(bgemm_t256_kernel<4, false>); break;
+#endif
 #ifdef E2V_AB
         default: if (lin) go(bgemm_t256_tail_kernel<true>); else go(bgemm_t256_tail_kernel<false>); break;
 #else
         default: throw Error(E2V_EINVAL, "bgemm_t256: no kernel instance for this tile width");
 #endif
     }
+}
+
+// Will bgemm_t256_launch(a) leave the row-block sums?  Only the staged epilogue does: bf16 output, no GEGLU, no scatter, whole 64-row
+// blocks, and the launch must be one this file takes at all.
+bool bgemm_t256_writes_rbsum(const IgemmArgs& a) {
+#ifndef E2V_AB
+    if (a.rbsum) return false;       // (the shipped build has no instance that writes them)
+#endif
+    return a.rbsum != nullptr && a.taps == 9 && a.a_bf16 && !a.out_f32 && !a.geglu && !a.osy && a.M % 64 == 0 && t256_tile_cols(a, false) != 0;
 }
 
 bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
@@ -1074,7 +1160,7 @@ bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
     // level 0 +3 % (its persistent launch loses 128 tiles to a non-persistent one), 198.6 -> 198.4 ms per step: not worth a default.
     static const int* const tailp = E2V_AB_KNOB("E2V_BGEMM_T256_TAIL", 0);
     const long T = (long)nbm * nct, full = T / 256, tail = T - 256 * full;
-    if (*tailp && cols == 320 && !a.geglu && full >= 1 && tail > 0 && 2 * tail <= 256 && (256 * full) % nct == 0) {
+    if (*tailp && cols == 320 && !a.geglu && !a.rbsum && full >= 1 && tail > 0 && 2 * tail <= 256 && (256 * full) % nct == 0) {
         const int r1 = (int)(256 * full / nct);
         t256_launch_part(a, cols, 0, r1, 0, 0, 0, 5, true, s);
         t256_launch_part(a, cols, r1, nbm - r1, 0, 320, nct, 0, false, s);      // nt = 0: the tail kernel (192- and 128-column tiles)

@@ -720,6 +720,18 @@ static void launch_igemm(const IgemmArgs& a, int ntiles, const char* cls, hipStr
     E2V_KLAUNCH((igemm_kernel<ABL>), grid, dim3(256), smem, s, a);
 }
 
+bool igemm_writes_rbsum(const IgemmArgs& a_in) {
+    if (!a_in.rbsum || !a_in.a_bf16 || a_in.M <= 0 || a_in.N <= 0) return false;
+    IgemmArgs a = a_in;
+    if (a.taps == 1) {
+        a.Ho = a.Hi = a.Hs = 1;
+        a.Wo = a.Wi = a.Ws = a.M;
+        a.stride = 1; a.pad = 0; a.upsample = 0;
+    }
+    a.ldw = a.ldw16;
+    return bgemm_t256_writes_rbsum(a);
+}
+
 void igemm(const IgemmArgs& a_in, hipStream_t s) {
     if (a_in.M <= 0 || a_in.N <= 0) return;
     IgemmArgs a = a_in;

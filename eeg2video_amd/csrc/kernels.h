@@ -57,8 +57,20 @@ struct IgemmArgs {
     int ablate = 0;                // timing experiments only (E2V_BGEMM_ABLATE): 1 = no output stores, 2 = A loads read zeros, 3 = both
     int rb1 = 0, w1 = 0, s1 = 0, s2 = 0, nbm = 0, nbm_per = 0, tail_rb = 0;   // filled by the launcher: tile schedule (see igemm_kernel)
     int rb0 = 0, col_off = 0, col_off2 = 0, col_stride = 0, nct_l = 0;   // filled by bgemm256.hip's launcher: first row block / column tiling of a partial launch (tail split)
+    // GroupNorm statistics from the PRODUCER (bf16 mode): rbsum != null asks the launch to leave, beside the tensor, the sums a
+    // following GroupNorm needs -- rbsum[m / 64][n][2] = (sum, sum of squares) of the STORED (bf16-rounded) outputs of rows
+    // 64 b .. 64 b + 63, column n, in the canonical order of rowblock_sums (norm.hip).  Only the staged epilogue of bgemm_t256_kernel
+    // writes it (igemm_writes_rbsum says whether a launch will); anything else leaves it untouched and the caller runs
+    // rowblock_sums over the tensor instead -- same sums, bit for bit, so that which kernel serves a layer (a function of the
+    // batch) never shows in a result.
+    float* rbsum = nullptr;
 };
 void igemm(const IgemmArgs& a, hipStream_t s);
+bool igemm_writes_rbsum(const IgemmArgs& a);       // will igemm(a) fill a.rbsum?  (same rules as the launch itself)
+// rows per lane pass of the canonical order: the staged epilogue of a 256 x 320 tile finishes 6 rows per pass, of a 256 x 256 tile 8
+inline int rbsum_rows_per_pass(int N) { return N % 320 == 0 ? 6 : 8; }
+// could a tensor [M][N] carry row-block sums at all (a property of the layer, never of the batch)?
+inline bool rbsum_capable(long long M, int N) { return M % 64 == 0 && (N % 320 == 0 || N % 256 == 0); }
 // Run-time switches: an int per name, initialised from the environment variable of that name on first use
 // and settable through e2v_op_set_knob for A/B comparisons inside one process.  The returned pointer stays valid.
 int* knob(const char* name, int dflt);
@@ -74,6 +86,7 @@ template <int V> inline const int* ab_const() { static const int v = V; return &
 #endif      // false: no kernel has asked for a knob of that name yet and it is not a known one
 void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s);
 bool bgemm_all_n64(const IgemmArgs& a);
+bool bgemm_t256_writes_rbsum(const IgemmArgs& a);                         // bgemm256.hip: would that launch fill a.rbsum?
 bool bgemm_t256_launch(const IgemmArgs& a, hipStream_t s);                 // bgemm256.hip: true = the layer was eligible and has been launched
 // Exact 2x nearest resize in front of a stride-1, pad-1 3x3 conv as four 2x2 convs on the SOURCE map (one per output parity; weights
 // summed over the taps that read the same source pixel: 4 / 9 of the multiplies).  `g` describes the conv as igemm() takes it.
@@ -131,7 +144,13 @@ struct GroupNormArgs {
     int bf16 = 0;                  // 1: x0 / x1 / out are bf16 (statistics, scale / shift and the arithmetic stay fp32)
     float* ws_part = nullptr;      // workspace: samples*chunks*(c0+c1)*2 floats
     float* ws_scale = nullptr;     // workspace: samples*(c0+c1)*2 floats
+    // row-block sums that came with a source tensor (IgemmArgs::rbsum / rowblock_sums: [rows / 64][c_i][2]): the statistics pass
+    // over that source is skipped and the fold reads them (needs P % 64 == 0; bf16 mode)
+    const float* rb0 = nullptr; const float* rb1 = nullptr;
 };
+// the canonical row-block sums of a stored bf16 tensor x[rows][C] (rows % 64 == 0): out[rows / 64][C][2], bit-identical to what the
+// staged epilogue of bgemm_t256_kernel leaves for a tensor of the same width (rpp = rbsum_rows_per_pass(C))
+void rowblock_sums(const void* x_bf16, int ld, int C, long long rows, int rpp, float* out, hipStream_t s);
 int  groupnorm_chunks(int P);
 void groupnorm(const GroupNormArgs& a, hipStream_t s);
 // statistics only: leaves per-(slab, channel) (scale, shift) pairs in a.ws_scale for a consumer that applies the affine

@@ -531,8 +531,10 @@ struct Runner {
         }
     }
 
+    // rb0 / rb1: row-block sums that came with the source tensors (Act::rb; null: none) -- the statistics pass over such a source is
+    // skipped (bf16 mode, P a multiple of 64)
     Act gn(const NormW& w, const float* x0, int c0, const float* x1, int c1, int samples, int P, int groups, float eps,
-           bool act) {
+           bool act, const float* rb0 = nullptr, const float* rb1 = nullptr) {
         const int C = c0 + c1;
         E2V_REQUIRE(C == w.c && C % groups == 0 && c0 % 4 == 0 && c1 % 4 == 0, E2V_ESHAPE, "GroupNorm channel mismatch");
         gn_ws(samples, P, C);
@@ -543,6 +545,7 @@ struct Runner {
         a.gamma = w.g; a.beta = w.b; a.out = out.p; a.ldo = C;
         a.samples = samples; a.P = P; a.groups = groups; a.eps = eps; a.silu = act ? 1 : 0;
         a.ws_part = c->gn_part; a.ws_scale = c->gn_scale;
+        if (bf() && P % 64 == 0) { a.rb0 = rb0; a.rb1 = c1 > 0 ? rb1 : nullptr; }
         groupnorm(a, s);
         return out;
     }
@@ -607,7 +610,8 @@ struct Runner {
     // gn_P rows) is applied on the way in -- only valid when winograd() says so
     Act conv3(const ConvW& w, const float* x0, int c0, const float* x1, int c1, Geo geo, int Hi, int Wi, int Ho, int Wo,
               int stride, int pad, const float* rowbias = nullptr, int rows_per_sample = 1, const float* resid = nullptr,
-              int gn_P = 0, int rb_ld = -1, bool out_f32 = false) {   // rb_ld: stride between the samples' rowbias rows (0: one row for all)
+              int gn_P = 0, int rb_ld = -1, bool out_f32 = false, bool want_rb = false) {   // rb_ld: stride between the samples' rowbias rows (0: one row for all)
+        // want_rb: a GroupNorm follows -- leave the row-block sums with the output (Act::rb) where the tensor can carry them
         if (rb_ld < 0) rb_ld = w.cout;
         E2V_REQUIRE(c0 + c1 == (bf() ? w.cin_pad16 : w.cin_pad), E2V_ESHAPE, "conv: input channels do not match the weight");
         Act out(pool(), (int64_t)geo.nimg * Ho * Wo, w.cout, bf() && !out_f32);
@@ -654,14 +658,31 @@ struct Runner {
         }
         c->conv_form(w, bf() ? e2v_ctx::FORM_BF16 : e2v_ctx::FORM_DIRECT32, s);
         g.w = w.w; g.w16 = w.w16;
+        // GroupNorm statistics from the producer -- BUILT, BIT-EXACT, MEASURED AND NOT ADOPTED (`make ab` builds, E2V_GN_RB = 1; DESIGN
+        // section 9, profiles/r04_shape_ab_gn_producer_sums.log): the sums are ALWAYS the canonical ones -- from the epilogue when the
+        // launch runs on the 256-row staged kernel (E2V_GN_RB_EPILOGUE = 0: never, for the bit-identity test), else from rowblock_sums
+        // over the stored tensor -- so a result never depends on which kernel (i.e. which batch size) served the layer.  At B = 32 the
+        // GroupNorms save 4.0 ms per step + decode and the convs that take the sums lose 6.2 (+4..8 % each: the 256-row kernel is one
+        // workgroup per CU, nothing hides a longer tile tail, while the statistics pass it replaces streams at 5 TB/s).
+        static const int* const rb_on = E2V_AB_KNOB("E2V_GN_RB", 0);
+        static const int* const rb_epi = E2V_AB_KNOB("E2V_GN_RB_EPILOGUE", 1);
+        bool epilogue_sums = false;
+        if (*rb_on && want_rb && bf() && !out_f32 && rbsum_capable(out.rows, w.cout)) {
+            out.rb = pool().get((size_t)(out.rows / 64) * w.cout * 2);
+            if (*rb_epi) { g.rbsum = out.rb; epilogue_sums = igemm_writes_rbsum(g); if (!epilogue_sums) g.rbsum = nullptr; }
+        }
         igemm(g, s);
+        if (epilogue_sums) dry_tag(" +rbsum");
+        if (out.rb && !epilogue_sums) rowblock_sums(out.p, w.cout, w.cout, out.rows, rbsum_rows_per_pass(w.cout), out.rb, s);
         return out;
     }
 
     // ResnetBlock3D.forward (resnet.py:174-204); x1 = skip tensor concatenated on channels (may be null).
     // samples x P rows share GroupNorm statistics and one time-embedding row; geo describes the frames.
+    // rb0 / rb1: row-block sums of x0 / x1 (Act::rb of the tensors; null: none).  The output carries its own when P allows.
     Act resnet(const ResW& w, const float* x0, int c0, const float* x1, int c1, int samples, int P, Geo geo, int groups,
-               float eps, const float* temb_silu, int temb_dim) {
+               float eps, const float* temb_silu, int temb_dim, const float* rb0 = nullptr, const float* rb1 = nullptr) {
+        const bool rbw = bf() && P % 64 == 0;            // the GroupNorms that read conv1's / this block's output can use the sums
         E2V_REQUIRE(c0 + c1 == w.cin, E2V_ESHAPE, "resnet: channel mismatch");
         Act tp;
         const float* tpp = nullptr;
@@ -681,9 +702,9 @@ struct Runner {
             gn_stats(w.n1, x0, c0, x1, c1, samples, P, groups, eps);                                  // :177-178
             h1 = conv3(w.c1, x0, c0, x1, c1, geo, geo.H, geo.W, geo.H, geo.W, 1, 1, tpp, P, nullptr, P, tp_ld);   // :180,186
         } else {
-            Act hn = gn(w.n1, x0, c0, x1, c1, samples, P, groups, eps, true);                        // :177-178
+            Act hn = gn(w.n1, x0, c0, x1, c1, samples, P, groups, eps, true, rb0, rb1);              // :177-178
             h1 = conv3(w.c1, hn.p, w.cin, nullptr, 0, geo, geo.H, geo.W, geo.H, geo.W, 1, 1,          // :180,186
-                       tpp, P, nullptr, 0, tp_ld);
+                       tpp, P, nullptr, 0, tp_ld, false, rbw);
         }
         Act sc;
         const float* resid = x0;
@@ -697,9 +718,9 @@ struct Runner {
             gn_stats(w.n2, h1.p, w.cout, nullptr, 0, samples, P, groups, eps);                        // :188,194
             return conv3(w.c2, h1.p, w.cout, nullptr, 0, geo, geo.H, geo.W, geo.H, geo.W, 1, 1, nullptr, 1, resid, P);   // :197,202
         }
-        Act h2 = gn(w.n2, h1.p, w.cout, nullptr, 0, samples, P, groups, eps, true);                  // :188,194
+        Act h2 = gn(w.n2, h1.p, w.cout, nullptr, 0, samples, P, groups, eps, true, h1.rb);           // :188,194
         h1.reset();
-        return conv3(w.c2, h2.p, w.cout, nullptr, 0, geo, geo.H, geo.W, geo.H, geo.W, 1, 1, nullptr, 1, resid);   // :197,202
+        return conv3(w.c2, h2.p, w.cout, nullptr, 0, geo, geo.H, geo.W, geo.H, geo.W, 1, 1, nullptr, 1, resid, 0, -1, false, rbw);   // :197,202
     }
 
     // Transformer3DModel.forward + BasicTransformerBlock.forward (attention.py:89-136, 232-269)
@@ -728,7 +749,7 @@ struct Runner {
         const int io16 = bf() ? 1 : 0;
         Act t;
         {
-            Act hn = gn(w.norm, xp->p, C, nullptr, 0, n1 * F, HW, groups, 1e-6f, false);              // :99 (per frame)
+            Act hn = gn(w.norm, xp->p, C, nullptr, 0, n1 * F, HW, groups, 1e-6f, false, xp->rb);      // :99 (per frame)
             t = linear(w.proj_in, hn.p, C, rows1);                                                    // :101-103
         }
         {   // attn1: sparse-causal self-attention                                                      :234-243
@@ -928,21 +949,22 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
                 x_shared.reset();
                 h = R.transformer(b.attn[j], h, N, F, hs[i] * ws[i], cond, T, heads, groups, N1);
             } else {
-                h = R.resnet(b.res[j], cur->p, cur->C, nullptr, 0, N, P_of(i), geo_of(i), groups, eps, temb_silu.p, temb_dim);
+                h = R.resnet(b.res[j], cur->p, cur->C, nullptr, 0, N, P_of(i), geo_of(i), groups, eps, temb_silu.p, temb_dim, cur->rb);
                 if (!b.attn.empty()) h = R.transformer(b.attn[j], h, N, F, hs[i] * ws[i], cond, T, heads, groups);
             }
             cur = &keep(std::move(h), i);
         }
         if (b.resample) {                                                                            // resnet.py:99-107
-            Act d = R.conv3(b.rs, cur->p, cur->C, nullptr, 0, geo_of(i), hs[i], ws[i], hs[i + 1], ws[i + 1], 2, 1);
+            Act d = R.conv3(b.rs, cur->p, cur->C, nullptr, 0, geo_of(i), hs[i], ws[i], hs[i + 1], ws[i + 1], 2, 1, nullptr, 1, nullptr, 0, -1, false,
+                            R.bf() && P_of(i + 1) % 64 == 0);          // (the next level's first GroupNorm and, as a skip, a later one read it)
             cur = &keep(std::move(d), i + 1);
         }
         if (tap_sink) { const int l = b.resample ? i + 1 : i; tap(*cur, N, cfg.block_out_channels[i], F, hs[l], ws[l]); }       // taps["down{i}"]
     }
     // mid (unet_blocks.py:199-205)
-    Act h = R.resnet(unet.mid_r0, cur->p, cur->C, nullptr, 0, N, P_of(3), geo_of(3), groups, eps, temb_silu.p, temb_dim);
+    Act h = R.resnet(unet.mid_r0, cur->p, cur->C, nullptr, 0, N, P_of(3), geo_of(3), groups, eps, temb_silu.p, temb_dim, cur->rb);
     h = R.transformer(unet.mid_attn, h, N, F, hs[3] * ws[3], cond, T, heads, groups);
-    h = R.resnet(unet.mid_r1, h.p, h.C, nullptr, 0, N, P_of(3), geo_of(3), groups, eps, temb_silu.p, temb_dim);
+    h = R.resnet(unet.mid_r1, h.p, h.C, nullptr, 0, N, P_of(3), geo_of(3), groups, eps, temb_silu.p, temb_dim, h.rb);
     if (tap_sink) tap(h, N, cfg.block_out_channels[3], F, hs[3], ws[3]);                               // taps["mid"]
     // up (unet.py:381-404)
     for (int i = 0; i < 4; ++i) {
@@ -952,7 +974,7 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
             E2V_REQUIRE(!skips.empty() && skips.back().lvl == lvl, E2V_ESTATE, "skip bookkeeping out of step");
             Skip sk = std::move(skips.back());                                                       // unet_blocks.py:485-487
             skips.pop_back();
-            Act o = R.resnet(b.res[j], h.p, h.C, sk.a.p, sk.a.C, N, P_of(lvl), geo_of(lvl), groups, eps, temb_silu.p, temb_dim);
+            Act o = R.resnet(b.res[j], h.p, h.C, sk.a.p, sk.a.C, N, P_of(lvl), geo_of(lvl), groups, eps, temb_silu.p, temb_dim, h.rb, sk.a.rb);
             if (!b.attn.empty()) o = R.transformer(b.attn[j], o, N, F, hs[lvl] * ws[lvl], cond, T, heads, groups);
             h = std::move(o);
         }
@@ -961,7 +983,7 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
         }
         if (tap_sink) { const int l = b.resample ? lvl - 1 : lvl; tap(h, N, cfg.block_out_channels[lvl], F, hs[l], ws[l]); }   // taps["up{i}"]
     }
-    Act hn = R.gn(unet.norm_out, h.p, h.C, nullptr, 0, N, P_of(0), groups, eps, true);                 // :406-407
+    Act hn = R.gn(unet.norm_out, h.p, h.C, nullptr, 0, N, P_of(0), groups, eps, true, h.rb);           // :406-407
     h.reset();
     Act out = R.conv3(unet.conv_out, hn.p, hn.C, nullptr, 0, geo_of(0), H, W, H, W, 1, 1, nullptr, 1, nullptr, 0, -1, true);   // :408 (eps: fp32)
     E2V_HIP(hipGetLastError());

@@ -330,6 +330,105 @@ static int gn_chunk_rows(const int P) {
     return v < GN_ROWS_PER_CHUNK ? GN_ROWS_PER_CHUNK : v;
 }
 
+// ---- GroupNorm statistics that came with the tensor (IgemmArgs::rbsum) ------------------------------------------------------------
+// Canonical row-block sums of a stored bf16 tensor: out[b][c][2] = (sum, sum of squares) of rows 64 b .. 64 b + 63, column c, added in
+// the order the staged epilogue of bgemm_t256_kernel adds them (bgemm256.hip rb_fold): RPP "lanes" j = 0 .. RPP - 1 each take rows
+// j, j + RPP, ... < 32 of the block's first 32-row chunk into one fp32 sum (plain add; squares by fma), likewise of its second chunk,
+// add the two; the lane sums are then added in lane order.  A tensor that the epilogue did not write (small batch: another kernel served the layer) gets
+// its sums from here -- the same bits, so that the batch size never shows in a result.  grid = row blocks; a thread = (8-column
+// piece, lane j).
+__global__ __launch_bounds__(256) void rowblock_sums_kernel(const __bf16* __restrict__ x, int ld, int C, int rpp, float* __restrict__ out) {
+    extern __shared__ float rbs_lds[];                    // [pairs][16]
+    const size_t row0 = (size_t)blockIdx.x * 64;
+    const int pieces = C / 8, pairs = pieces * rpp;
+    for (int i = threadIdx.x; i < pairs; i += 256) {
+        const int q = i / rpp, j = i - q * rpp;
+        f32x4 acc[2][4];
+        for (int c = 0; c < 2; ++c) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, q0 = s0, q1 = s0;
+            for (int r = j; r < 32; r += rpp) {
+                const F8 v = ld8(x + (row0 + 32 * c + r) * ld + q * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s0[e] += v.lo[e]; s1[e] += v.hi[e];
+                    q0[e] = __builtin_fmaf(v.lo[e], v.lo[e], q0[e]); q1[e] = __builtin_fmaf(v.hi[e], v.hi[e], q1[e]);
+                }
+            }
+            acc[c][0] = s0; acc[c][1] = s1; acc[c][2] = q0; acc[c][3] = q1;
+        }
+        const f32x4 s0 = acc[0][0] + acc[1][0], s1 = acc[0][1] + acc[1][1], q0 = acc[0][2] + acc[1][2], q1 = acc[0][3] + acc[1][3];
+        float* l = rbs_lds + (size_t)i * 16;
+        *reinterpret_cast<f32x4*>(l) = s0; *reinterpret_cast<f32x4*>(l + 4) = s1;
+        *reinterpret_cast<f32x4*>(l + 8) = q0; *reinterpret_cast<f32x4*>(l + 12) = q1;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < pieces; q += 256) {
+        const float* l = rbs_lds + (size_t)q * rpp * 16;
+        f32x4 t0 = *reinterpret_cast<const f32x4*>(l), t1 = *reinterpret_cast<const f32x4*>(l + 4);
+        f32x4 u0 = *reinterpret_cast<const f32x4*>(l + 8), u1 = *reinterpret_cast<const f32x4*>(l + 12);
+        for (int j = 1; j < rpp; ++j) {
+            const float* o = l + j * 16;
+            t0 += *reinterpret_cast<const f32x4*>(o); t1 += *reinterpret_cast<const f32x4*>(o + 4);
+            u0 += *reinterpret_cast<const f32x4*>(o + 8); u1 += *reinterpret_cast<const f32x4*>(o + 12);
+        }
+        float* d = out + ((size_t)blockIdx.x * C + q * 8) * 2;
+        *reinterpret_cast<f32x4*>(d) = f32x4{t0[0], u0[0], t0[1], u0[1]};
+        *reinterpret_cast<f32x4*>(d + 4) = f32x4{t0[2], u0[2], t0[3], u0[3]};
+        *reinterpret_cast<f32x4*>(d + 8) = f32x4{t1[0], u1[0], t1[1], u1[1]};
+        *reinterpret_cast<f32x4*>(d + 12) = f32x4{t1[2], u1[2], t1[3], u1[3]};
+    }
+}
+void rowblock_sums(const void* x, int ld, int C, long long rows, int rpp, float* out, hipStream_t s) {
+    if (rows <= 0) return;
+    const size_t smem = (size_t)(C / 8) * rpp * 16 * sizeof(float);
+    static size_t configured = 0;
+    if (smem > configured && smem > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowblock_sums_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        configured = smem;
+    }
+    ProfScope ps("rowblock_sums", 3.0 * rows * C, 2.0 * rows * C, s);
+    E2V_KLAUNCH(rowblock_sums_kernel, dim3((unsigned)(rows / 64)), dim3(256), smem, s, static_cast<const __bf16*>(x), ld, C, rpp, out);
+}
+
+// The fold of gn_finalize_kernel over sources whose partial sums live in different places: source i contributes channels
+// [off_i, off_i + c_i) of the concatenation from part_i[(slab * chunks_i + chunk) * ld_i + (channel - off_i) + coff_i][2] -- the statistics
+// workspace of this call (ld = c0 + c1, coff = off) or row-block sums that came with the tensor (ld = c_i, coff = 0, chunks = P / 64).
+__global__ __launch_bounds__(64) void gn_finalize_mixed_kernel(const float* __restrict__ part0, int chunks0, int ld0, int coff0, int c0,
+                                                               const float* __restrict__ part1, int chunks1, int ld1, int coff1, int Ctot,
+                                                               int groups, int P, float eps, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ scsh) {
+    const int g = blockIdx.x, slab = blockIdx.y, lane = threadIdx.x;
+    const int cpg = Ctot / groups;
+    double s = 0.0, ss = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {           // a group's channels may straddle the seam of the two sources
+        const bool first = c < c0;
+        const float* part = first ? part0 : part1;
+        const int chunks = first ? chunks0 : chunks1, ld = first ? ld0 : ld1;
+        const int col = first ? c + coff0 : c - c0 + coff1;
+        for (int ch = lane; ch < chunks; ch += 64) {
+            const float* e = part + ((size_t)(slab * chunks + ch) * ld + col) * 2;
+            s += (double)e[0];
+            ss += (double)e[1];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        ss += __shfl_xor(ss, off);
+    }
+    const double cnt = (double)cpg * (double)P;
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+        const double ga = (double)gamma[c];
+        float* o = scsh + ((size_t)slab * Ctot + c) * 2;
+        o[0] = (float)(rstd * ga);
+        o[1] = (float)((double)beta[c] - mean * rstd * ga);
+    }
+}
+
 static std::string gn_shape_tag(const GroupNormArgs& a) {
     return " S" + std::to_string(a.samples) + " P" + std::to_string(a.P) + " C" + std::to_string(a.c0) + (a.c1 ? "+" + std::to_string(a.c1) : "") + " g" +
            std::to_string(a.groups);
@@ -339,8 +438,6 @@ static void groupnorm_stats_launch(const GroupNormArgs& a, hipStream_t s) {
     const int Ctot = a.c0 + a.c1;
     const int crows = gn_chunk_rows(a.P);
     const int chunks = (a.P + crows - 1) / crows;
-    dry_tag(std::string(" -> ") + (a.bf16 && a.c0 % 8 == 0 && a.c1 % 8 == 0 && ((a.ld0 | a.ld1) & 7) == 0 ? "gn_partial8_kernel" : "gn_partial_kernel") + " rows" +
-            std::to_string(crows) + " + gn_finalize_kernel");
     auto part = [&](const float* x, int ld, int C, int coff) {
         const int qt = quad_tile(C / 4);
         if (a.bf16 && C % 8 == 0 && ld % 8 == 0)
@@ -353,12 +450,31 @@ static void groupnorm_stats_launch(const GroupNormArgs& a, hipStream_t s) {
             E2V_KLAUNCH(gn_partial_kernel<float>, dim3(chunks, a.samples), dim3(256), 0, s, x, ld, C, a.P, chunks, a.ws_part, Ctot,
                                coff, qt, crows);
     };
+    // sources that came with their row-block sums skip the statistics pass
+    const bool use_rb = a.bf16 && a.P % 64 == 0 && (a.rb0 || (a.c1 > 0 && a.rb1));
+    const bool rb0 = use_rb && a.rb0, rb1 = use_rb && a.c1 > 0 && a.rb1;
+    if (dry_run()) {
+        const std::string pk = std::string(a.bf16 && a.c0 % 8 == 0 && a.c1 % 8 == 0 && ((a.ld0 | a.ld1) & 7) == 0 ? "gn_partial8_kernel" : "gn_partial_kernel") + " rows" + std::to_string(crows);
+        std::string t = " ->";
+        if (!rb0) t += " " + pk + (a.c1 > 0 ? "[0]" : "");
+        if (rb0) t += " sums-from-producer[0]";
+        if (a.c1 > 0) t += rb1 ? " sums-from-producer[1]" : " " + pk + "[1]";
+        dry_tag(t + (use_rb ? " + gn_finalize_mixed_kernel" : " + gn_finalize_kernel"));
+    }
     // timing experiment (make ab): E2V_GN_SKIP_PARTIAL = 1 drops the statistics pass over the tensor -- RESULTS ARE WRONG -- to measure
     // the ceiling of what statistics taken in the producers' epilogues could save (profiles/r04_gn_stats_ceiling.log)
     static const int* const skip_partial = E2V_AB_KNOB("E2V_GN_SKIP_PARTIAL", 0);
     if (!*skip_partial) {
-        part(a.x0, a.ld0, a.c0, 0);
-        if (a.c1 > 0) part(a.x1, a.ld1, a.c1, a.c0);
+        if (!rb0) part(a.x0, a.ld0, a.c0, 0);
+        if (a.c1 > 0 && !rb1) part(a.x1, a.ld1, a.c1, a.c0);
+    }
+    if (use_rb) {
+        const int rbc = a.P / 64;
+        E2V_KLAUNCH(gn_finalize_mixed_kernel, dim3(a.groups, a.samples), dim3(64), 0, s,
+                    rb0 ? a.rb0 : a.ws_part, rb0 ? rbc : chunks, rb0 ? a.c0 : Ctot, 0, a.c0,
+                    rb1 ? a.rb1 : a.ws_part, rb1 ? rbc : chunks, rb1 ? a.c1 : Ctot, rb1 ? 0 : a.c0, Ctot,
+                    a.groups, a.P, a.eps, a.gamma, a.beta, a.ws_scale);
+        return;
     }
     E2V_KLAUNCH(gn_finalize_kernel, dim3(a.groups, a.samples), dim3(64), 0, s, a.ws_part, chunks, Ctot, a.groups,
                        a.P, a.eps, a.gamma, a.beta, a.ws_scale);

@@ -93,6 +93,7 @@ struct Act {
     int C = 0;
     Pool* pool = nullptr;
     bool bf16 = false;
+    float* rb = nullptr;           // row-block sums that came with the tensor (IgemmArgs::rbsum: [rows / 64][C][2]), pool-owned; null: none
     Act() = default;
     Act(Pool& pl, int64_t r, int c, bool half = false)
         : p(pl.get(half ? ((size_t)r * c + 1) / 2 : (size_t)r * c)), rows(r), C(c), pool(&pl), bf16(half) {}
@@ -106,15 +107,16 @@ struct Act {
     Act& operator=(Act&& o) noexcept {
         if (this != &o) {
             reset();
-            p = o.p; rows = o.rows; C = o.C; pool = o.pool; bf16 = o.bf16;
-            o.p = nullptr; o.pool = nullptr;
+            p = o.p; rows = o.rows; C = o.C; pool = o.pool; bf16 = o.bf16; rb = o.rb;
+            o.p = nullptr; o.pool = nullptr; o.rb = nullptr;
         }
         return *this;
     }
     ~Act() { reset(); }
     void reset() {
         if (p && pool) pool->put(p);
-        p = nullptr;
+        if (rb && pool) pool->put(rb);
+        p = nullptr; rb = nullptr;
     }
 };
 

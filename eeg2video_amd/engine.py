@@ -415,6 +415,13 @@ class Engine:
                                            int(geglu), out.data_ptr(), _stream()))
         return out
 
+    def op_rowblock_sums(self, x):
+        """Canonical (sum, sum of squares) per 64-row block and column of ``x`` rounded to bf16: ``[rows / 64, C, 2]``."""
+        rows, c = x.shape
+        out = torch.empty((rows // 64, c, 2), device=self.device, dtype=torch.float32)
+        self._check(self.lib.e2v_op_rowblock_sums(self.ctx, x.data_ptr(), rows, c, out.data_ptr(), _stream()))
+        return out
+
     def op_groupnorm(self, x0, gamma, beta, *, samples, P, groups, eps, silu=False, x1=None):
         c = x0.shape[1] + (x1.shape[1] if x1 is not None else 0)
         out = torch.empty((samples * P, c), device=self.device, dtype=torch.float32)

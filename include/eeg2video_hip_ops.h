@@ -69,6 +69,11 @@ e2v_status e2v_op_unet_forward_taps(e2v_ctx* ctx, const float* sample, const int
                                     int F, int H, int W, int T, float* out, float* taps, int64_t taps_cap, int64_t* shapes,
                                     int* n_taps, e2v_stream stream);
 
+/* Test aid: the row-block sums that a conv of the bf16 mode leaves with its output for the GroupNorm that follows (resnet.py:177,188:
+ * the statistics pass over the tensor is then skipped): x [rows][C] (device fp32, rounded to bf16 first; rows % 64 == 0, C % 8 == 0)
+ * -> out[rows / 64][C][2] = (sum, sum of squares) over each 64-row block, in the library's canonical summation order. */
+e2v_status e2v_op_rowblock_sums(e2v_ctx* ctx, const float* x, int64_t rows, int C, float* out, e2v_stream stream);
+
 /* Which kernel and tile would every launch of a configuration take?  On a HOST-ONLY context (e2v_create(cfg, -1, &ctx): no GPU, no
  * weights) this runs e2v_generate -- one guided DDIM step + VAE decode of B clips of [4, F, h, w] latents with T conditioning tokens, the
  * walk of UNet3DConditionModel.forward (EEG2Video/models/unet.py:278-413) and AutoencoderKL.decode -- as a dry run: every launch rule

@@ -434,6 +434,19 @@ def test_bf16_norms_and_temporal_attention(bf):
     close(y, ref, rtol=8e-3, atol=8e-3)
 
 
+@pytest.mark.parametrize("c,rows", [(320, 128), (640, 192), (1280, 64), (256, 320), (512, 64), (64, 128)])
+def test_rowblock_sums_against_fp64(eng, c, rows):
+    """The row-block sums a conv of the bf16 mode leaves for the GroupNorm behind it (IgemmArgs::rbsum; here from the stand-alone kernel
+    that reproduces the epilogue's summation order): (sum, sum of squares) per 64-row block and channel of the bf16-ROUNDED tensor,
+    against fp64 to fp32 summation accuracy."""
+    x = rnd(rows, c, seed=300) * 3.0 + 0.5
+    y = eng.op_rowblock_sums(x.cuda()).cpu().double()
+    xb = rb(x).double().reshape(rows // 64, 64, c)
+    ref = torch.stack([xb.sum(1), (xb * xb).sum(1)], dim=-1)
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("c,rows", [(320, 77), (320, 16), (640, 45), (1280, 13), (1280, 4)])
 def test_bf16_layernorm_sub_wave_rows(bf, c, rows):
     """The LayerNorm whose rows share a wave (8 / 16 / 32 lanes per row at C = 320 / 640 / 1280, E2V_LN_ROWS), ragged last row group:
