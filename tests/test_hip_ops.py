@@ -802,6 +802,36 @@ def test_bf16_attention_64_queries_per_wave(eng, d, nq, f, n):
         assert torch.equal(yp, y32)
 
 
+def test_bf16_attention_64_queries_per_wave_random_shapes(eng):
+    """A sweep of ragged shapes through the 64-query kernel -- query counts that leave the last workgroup one, two, three or four waves,
+    waves with one query block or none, key counts that end a 64-key stage after 1 .. 63 keys (marker-column masking) or exactly on
+    it, 1 .. 6 frames (one or two key segments), fewer and more than 8 samples (the two XCD mappings) -- each against the 32-query
+    kernel, which the tests above hold against torch: same softmax, other roundings."""
+    import random
+    rng = random.Random(20240)
+    heads, d = 8, 40
+    c = heads * d
+    try:
+        eng.set_compute_dtype("bf16")
+        for case in range(14):
+            nq = rng.choice([128, 129, 191, 192, 193, 255, 256, 257, 320, 383, 448, 511, 577, 640])
+            f = rng.randint(1, 6)
+            n = rng.choice([1, 2, 3, 8, 9, 11])
+            qkv = rnd(n * f * nq, 3 * c, seed=400 + case)
+            g = qkv.cuda()
+            run = lambda: eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5)
+            eng.set_knob("E2V_ATTN_Q64", 1)
+            y = run()
+            eng.set_knob("E2V_ATTN_Q64", 0)
+            y32 = run()
+            assert torch.isfinite(y).all(), (nq, f, n)
+            err = (y - y32).abs().max().item() / (y32.abs().max().item() + 1e-30)
+            assert err < 1e-2, (nq, f, n, err)
+    finally:
+        eng.set_knob("E2V_ATTN_Q64", 1)
+        eng.set_compute_dtype("fp32")
+
+
 def test_bf16_attention_64_queries_per_wave_huge_scores(eng):
     """The pipelined 64-query kernel carries a row's reference maximum in Q as the sum of two bf16 numbers.  Queries scaled 400x put
     the scores in the thousands (one bf16 number would be off by up to 16 there and a far larger factor beyond): the softmax is then
