@@ -92,7 +92,7 @@ class UNet3DConditionModel:
         self._internal_dict = FrozenDict(cfg)
         unsupported = {
             "center_input_sample": center_input_sample, "dual_cross_attention": dual_cross_attention,
-            "use_linear_projection": use_linear_projection, "upcast_attention": upcast_attention,
+            "upcast_attention": upcast_attention,
             "only_cross_attention": only_cross_attention if isinstance(only_cross_attention, bool) else any(only_cross_attention),
         }
         for k, v in unsupported.items():
@@ -111,6 +111,10 @@ class UNet3DConditionModel:
             if len(set(attention_head_dim)) != 1:
                 raise NotImplementedError("per-block attention_head_dim")
             attention_head_dim = attention_head_dim[0]
+        # Transformer3DModel(use_linear_projection=True) (attention.py:60-63,83-86: SD-2.x-shaped checkpoints) applies proj_in / proj_out
+        # as nn.Linear on the tokens instead of a 1x1 Conv2d on the map (attention.py:99-123): with channel-last rows the two are the
+        # same GEMM, so the option only changes the SHAPE those two weights have in a state dict ([C, C] instead of [C, C, 1, 1])
+        self.use_linear_projection = bool(use_linear_projection)
         self.sample_size = sample_size
         self.in_channels = in_channels
         self.ucfg = UNetConfig(sample_size=sample_size or 64, in_channels=in_channels, out_channels=out_channels,
@@ -187,6 +191,11 @@ class UNet3DConditionModel:
     # -- weights -----------------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict: bool = True):
         spec = self.state_dict_spec()
+        if self.use_linear_projection:           # nn.Linear proj_in / proj_out -> the 1x1-conv layout the engine's key scheme holds
+            state_dict = dict(state_dict)
+            for k, v in list(state_dict.items()):
+                if (k.endswith(".proj_in.weight") or k.endswith(".proj_out.weight")) and getattr(v, "ndim", 0) == 2:
+                    state_dict[k] = v.reshape(v.shape[0], v.shape[1], 1, 1)
         missing = [k for k in spec if k not in state_dict]
         unexpected = [k for k in state_dict if k not in spec]
         if strict and (missing or unexpected):

@@ -289,6 +289,30 @@ def tier2(out: dict) -> None:
     out["t2.tr.x"], out["t2.tr.cond"] = xt.numpy(), ct.numpy()
 
 
+def tier2_linear_projection(out: dict) -> None:
+    """Transformer3DModel(use_linear_projection=True) (attention.py:60-63,83-86,99-123: proj_in / proj_out as nn.Linear on the tokens,
+    the SD-2.x form) run unmodified: pins that the mirror's handling of the option -- the two [C, C] weights reshaped to the 1x1-conv
+    layout, same GEMM on channel-last rows -- is what the reference computes."""
+    shim_root = tempfile.mkdtemp(prefix="e2v_dep_standin_")
+    _write_shim(shim_root)
+    sys.path.insert(0, shim_root)
+    sys.path.insert(0, REF)
+    from EEG2Video.models.attention import Transformer3DModel
+    cfg = TINY_UNET
+    tr = Transformer3DModel(8, 8, in_channels=64, num_layers=1, cross_attention_dim=cfg.cross_attention_dim,
+                            norm_num_groups=32, use_linear_projection=True)
+    tr.eval()
+    sd = _load(tr, "t2.trlin.", 17)
+    assert sd["t2.trlin.proj_in.weight"].ndim == 2 and sd["t2.trlin.proj_out.weight"].ndim == 2
+    xt = _t(counter_normal(98, "t2.trlin.x", (2, 64, 3, 5, 6)))
+    ct = _t(counter_normal(98, "t2.trlin.cond", (2, 7, cfg.cross_attention_dim)))
+    with torch.no_grad():
+        out["t2.trlin.out"] = tr(xt, encoder_hidden_states=ct).sample.numpy()
+    out["t2.trlin.x"], out["t2.trlin.cond"] = xt.numpy(), ct.numpy()
+    for k, v in sd.items():                     # every weight travels with the fixture (the Linear-shaped ones have no spec here)
+        out["t2.trlin.w." + k[len("t2.trlin."):]] = v
+
+
 def tier1_extras(out: dict) -> None:
     """`CLIP` (semantic predictor) and DANA `Diffusion`, both import with torch alone."""
     from eeg2video_amd.weights import SemanticConfig, semantic_param_spec
@@ -396,7 +420,15 @@ def main() -> None:
         np.savez_compressed(os.path.join(HERE, "reference_t1_inversion.npz"), **ti)
         print("reference_t1_inversion.npz", os.path.getsize(os.path.join(HERE, "reference_t1_inversion.npz")) // 1024, "KiB")
         return
+    if "--only-linear-projection" in sys.argv:              # add this fixture alone (the others stay byte for byte what they were)
+        tl = {}
+        tier2_linear_projection(tl)
+        np.savez_compressed(os.path.join(HERE, "reference_t2_linear_projection.npz"), **tl)
+        print("reference_t2_linear_projection.npz", os.path.getsize(os.path.join(HERE, "reference_t2_linear_projection.npz")) // 1024, "KiB")
+        return
     t1, t2, tx = {}, {}, {}
+    tier2_linear_projection(tl := {})
+    np.savez_compressed(os.path.join(HERE, "reference_t2_linear_projection.npz"), **tl)
     tier1_inversion(t1i := {})
     np.savez_compressed(os.path.join(HERE, "reference_t1_inversion.npz"), **t1i)
     tier1(t1)

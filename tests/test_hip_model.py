@@ -481,6 +481,27 @@ def test_from_pretrained_2d_inflates_a_2d_checkpoint(tiny, tmp_path):
         UNet3DConditionModel.from_pretrained_2d(root, subfolder="unet", vae_config=vcfg)
 
 
+def test_use_linear_projection_checkpoint_loads_and_matches(tiny):
+    """UNet3DConditionModel(use_linear_projection=True) (unet.py:59, attention.py:60-63,83-86: the SD-2.x shape of a checkpoint, proj_in /
+    proj_out stored as [C, C] nn.Linear weights): the mirror reshapes the two weights to the 1x1-conv layout -- the same GEMM on
+    channel-last rows (pinned against the reference itself in tests/test_oracle_golden.py) -- so the model must load such a state dict
+    and give bit for bit what the conv-shaped one gives."""
+    from eeg2video_amd.unet import UNet3DConditionModel
+    pipe, usd, _ = tiny
+    kw = dict(sample_size=TINY_UNET.sample_size, in_channels=4, out_channels=4, block_out_channels=TINY_UNET.block_out_channels,
+              layers_per_block=TINY_UNET.layers_per_block, cross_attention_dim=TINY_UNET.cross_attention_dim,
+              attention_head_dim=TINY_UNET.attention_head_dim, norm_num_groups=TINY_UNET.norm_num_groups, norm_eps=TINY_UNET.norm_eps)
+    lin_sd = {k: (v.reshape(v.shape[0], v.shape[1]) if k.endswith(("proj_in.weight", "proj_out.weight")) else v) for k, v in usd.items()}
+    assert any(v.ndim == 2 and k.endswith("proj_in.weight") for k, v in lin_sd.items())
+    m = UNet3DConditionModel(use_linear_projection=True, device=0, **kw)
+    m.load_state_dict(lin_sd)
+    x = _t(counter_normal(5, "x", (2, 4, 3, 9, 12))).cuda()
+    cond = _t(counter_normal(6, "c", (2, 11, TINY_UNET.cross_attention_dim))).cuda()
+    assert torch.equal(m(x, 301, cond).sample, pipe.unet(x, 301, cond).sample)
+    with pytest.raises(RuntimeError):                      # the conv-shaped mirror still refuses the Linear-shaped weights
+        UNet3DConditionModel(device=0, **kw).load_state_dict(lin_sd)
+
+
 def test_memory_knobs_of_the_reference_objects_are_accepted(tiny):
     """set_attention_slice (unet.py:209-272), enable_gradient_checkpointing (:274-276), enable_sequential_cpu_offload
     (pipeline_tuneeeg2video.py:121-131): a caller that sets them keeps working; the argument checks and messages of

@@ -96,6 +96,25 @@ def test_t2_transformer3d(t2):
     np.testing.assert_allclose(y.numpy(), t2["t2.tr.out"], rtol=1e-4, atol=1e-4)
 
 
+def test_t2_transformer3d_linear_projection_is_the_same_gemm():
+    """Transformer3DModel(use_linear_projection=True) (attention.py:60-63,83-86,99-123: proj_in / proj_out as nn.Linear on the tokens)
+    run by the REFERENCE itself (tests/golden/reference_t2_linear_projection.npz, make_golden.py --only-linear-projection): the oracle
+    -- and the mirror's UNet3DConditionModel(use_linear_projection=True).load_state_dict -- treat the two [C, C] weights as 1x1 convs
+    ([C, C, 1, 1]); on channel-last rows that is the same GEMM, and the reference's output says so."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_t2_linear_projection.npz"))
+    sd = {}
+    for k in g.files:
+        if k.startswith("t2.trlin.w."):
+            v = _t(g[k])
+            name = k[len("t2.trlin.w."):]
+            if name in ("proj_in.weight", "proj_out.weight"):
+                assert v.ndim == 2
+                v = v.reshape(v.shape[0], v.shape[1], 1, 1)
+            sd["a." + name] = v
+    y = O.transformer3d(sd, "a", _t(g["t2.trlin.x"]), _t(g["t2.trlin.cond"]), heads=8, groups=32)
+    np.testing.assert_allclose(y.numpy(), g["t2.trlin.out"], rtol=1e-4, atol=1e-4)
+
+
 # ---- closed-form known answers for the dependency-owned pieces (SURVEY App. C.3 / C.4) ----
 def test_ddim_timesteps_bit_exact():
     s = DDIMOracle()
