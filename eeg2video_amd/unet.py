@@ -92,7 +92,6 @@ class UNet3DConditionModel:
         self._internal_dict = FrozenDict(cfg)
         unsupported = {
             "center_input_sample": center_input_sample, "dual_cross_attention": dual_cross_attention,
-            "upcast_attention": upcast_attention,
             "only_cross_attention": only_cross_attention if isinstance(only_cross_attention, bool) else any(only_cross_attention),
         }
         for k, v in unsupported.items():
@@ -115,6 +114,10 @@ class UNet3DConditionModel:
         # as nn.Linear on the tokens instead of a 1x1 Conv2d on the map (attention.py:99-123): with channel-last rows the two are the
         # same GEMM, so the option only changes the SHAPE those two weights have in a state dict ([C, C] instead of [C, C, 1, 1])
         self.use_linear_projection = bool(use_linear_projection)
+        # upcast_attention=True (attention.py:232-243 -> CrossAttention: q / k widened to fp32 for the scores and the softmax of a half
+        # model) asks for what this path always does: scores accumulate and the softmax runs in fp32 in BOTH modes (fp32: everything;
+        # bf16: bf16 Q / K operands, fp32 accumulation, fp32 softmax) -- accepted, nothing to switch
+        self.upcast_attention = bool(upcast_attention)
         self.sample_size = sample_size
         self.in_channels = in_channels
         self.ucfg = UNetConfig(sample_size=sample_size or 64, in_channels=in_channels, out_channels=out_channels,

@@ -493,7 +493,7 @@ def test_use_linear_projection_checkpoint_loads_and_matches(tiny):
               attention_head_dim=TINY_UNET.attention_head_dim, norm_num_groups=TINY_UNET.norm_num_groups, norm_eps=TINY_UNET.norm_eps)
     lin_sd = {k: (v.reshape(v.shape[0], v.shape[1]) if k.endswith(("proj_in.weight", "proj_out.weight")) else v) for k, v in usd.items()}
     assert any(v.ndim == 2 and k.endswith("proj_in.weight") for k, v in lin_sd.items())
-    m = UNet3DConditionModel(use_linear_projection=True, device=0, **kw)
+    m = UNet3DConditionModel(use_linear_projection=True, upcast_attention=True, device=0, **kw)   # (fp32 scores / softmax: always the case here)
     m.load_state_dict(lin_sd)
     x = _t(counter_normal(5, "x", (2, 4, 3, 9, 12))).cuda()
     cond = _t(counter_normal(6, "c", (2, 11, TINY_UNET.cross_attention_dim))).cuda()
