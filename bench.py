@@ -57,8 +57,9 @@ def parse_args(argv):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-instrumented pass (A/B timing runs)")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel-class table (JSON) here")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "f32x3"],
-                    help="fp32 = BASELINE configs[1] (default, the metric's configuration); bf16 = configs[2]")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp16", "f32x3"],
+                    help="fp32 = BASELINE configs[1] (default, the metric's configuration); bf16 = configs[2]; fp16 = the reference's own "
+                         "inference dtype (inference_eeg2video.py:69-70: torch_dtype=torch.float16)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--gather", default="fp32", choices=["fp32", "uint8"],
@@ -273,14 +274,15 @@ def configs2_leg(eng, args, host_frames_u8=None):
     host = torch.empty((B, 3, 6, 288, 512), dtype=torch.float32).pin_memory()
     eng.set_compute_dtype("bf16")
     try:
+        # 4 timed passes where the driver's 600 s budget has room for them; the decision is taken HERE, before the leg's first pass
+        # (instrumented pass ~11 s + 4 x ~9.5 s + the parity clip: a leg that starts before 420 s ends before 480 s); later, 3
+        n = args.configs2_steps if args.configs2_steps != 4 or process_age_s() < 420.0 else 3
         # the event-instrumented pass comes FIRST and is the leg's warm-up (it builds the bf16 weight forms; event timings are per
         # kernel, so the one-off packing launches only add their own small classes)
         eng.profile_begin()
         eng.generate(lat, cond, unc, args.ddim_steps, args.guidance, 0.0, decode=True)
         table = eng.profile_end()
         torch.cuda.synchronize()
-        # 4 timed passes where the driver's 600 s budget has room for them (the whole default run aims at <= 400 s); on a slower box 3
-        n = args.configs2_steps if args.configs2_steps != 4 or process_age_s() < 355.0 else 3
         t0 = time.perf_counter()
         for _ in range(n):
             frames = eng.generate(lat, cond, unc, args.ddim_steps, args.guidance, 0.0, decode=True)
@@ -303,6 +305,222 @@ def configs2_leg(eng, args, host_frames_u8=None):
             "roofline": roof}
 
 
+def synthetic_inputs(rank, B, dev, latent_shape=(4, 6, 36, 64), cond_shape=(77, 768)):
+    """Synthetic inputs of one rank, resident on `dev` before the timed region: clip k of rank r is global clip r*B + k (latent seed
+    1234 + r*B + k, conditioning seed 1235 + 7919 (r*B + k)), so that the ranks of an N-GPU job generate N*B DIFFERENT clips."""
+    import numpy as np
+    import torch
+    from eeg2video_amd.weights import counter_normal
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    lat = torch.stack([t(counter_normal(1234 + rank * B + k, "latent", latent_shape)) for k in range(B)]).to(dev)
+    cond = torch.stack([t(counter_normal(1235 + 7919 * (rank * B + k), "cond", cond_shape)) for k in range(B)]).to(dev)
+    unc = t(counter_normal(1236, "uncond", (1,) + tuple(cond_shape))).to(dev)
+    return lat, cond, unc
+
+
+def rank_body(args, rank, world, eng, *, use_dist, B, frame_shape=(3, 6, 288, 512), latent_shape=(4, 6, 36, 64), cond_shape=(77, 768),
+              sync=None, pin=True, cpu_leg=None, configs2=None):
+    """What ONE rank of the benchmark does once its engine exists: inputs -> warm-up -> barrier -> K timed steps -> barrier -> max over
+    ranks -> (rank 0) the JSON object.  Factored out of main() so that the N > 1 bookkeeping -- per-rank seeds, rank 0's host buffer
+    holding world x B clips in rank order, per-rank clocks, the line's contract -- runs under a world-size-2 gloo test with a stub
+    engine (tests/test_bench_ranks_gloo.py); main() passes the HIP engine, `torch.cuda.synchronize` and the CPU-baseline / configs[2]
+    legs.  `eng` needs: device, generate(lat, cond, unc, ddim_steps, guidance, eta, decode=True), frames_to_uint8, profile_begin /
+    profile_end, device_bytes.  Returns {"result": the line's object (rank 0) or None, "finite": bool, "host_frames": rank 0's buffer}."""
+    import torch
+    import torch.distributed as dist
+    from eeg2video_amd.dist import all_gather_frames
+    sync = sync or torch.cuda.synchronize
+    dev = eng.device
+    lat, cond, unc = synthetic_inputs(rank, B, dev, latent_shape, cond_shape)
+    # where the frames end up: the reference's `.cpu().float().numpy()` (pipeline_tuneeeg2video.py:183); rank 0 is the consumer
+    as_u8 = args.gather == "uint8"
+    host_frames = None
+    if rank == 0:
+        host_frames = torch.empty((world * B,) + tuple(frame_shape), dtype=torch.uint8 if as_u8 else torch.float32)
+        if pin:
+            host_frames = host_frames.pin_memory()
+    gather_engine = eng if args.gather_impl == "cabi" else None
+
+    def step():
+        frames = eng.generate(lat, cond, unc, args.ddim_steps, args.guidance, 0.0, decode=True)
+        if use_dist:       # every rank runs B clips: no count exchange, no host sync in front of the collective
+            frames = all_gather_frames(frames, as_uint8=as_u8, force_collective=True, engine=gather_engine, uniform=True)
+        elif as_u8:
+            frames = eng.frames_to_uint8(frames)
+        if host_frames is not None:
+            host_frames.copy_(frames, non_blocking=True)
+        return frames
+
+    # The CPU baseline (the oracle on the host cores, ~1 min) runs on a thread BESIDE THE WARM-UP STEPS and is joined before the timed
+    # region starts: the warm-up is untimed GPU work whose host thread sleeps in the HIP runtime, so the two share nothing, the timed
+    # region never sees the oracle's threads, and the default run is a minute shorter than with the leg at its end.  Without a warm-up
+    # to hide it under, the leg runs ALONE at the very end (after the configs[2] leg: its threads never sit beside a timed region).
+    cpu_wanted = cpu_leg is not None and rank == 0 and world == 1 and not args.no_cpu_baseline
+    cpu_overlap = None
+    if cpu_wanted and args.warmup > 0:
+        cpu_leg.start()
+        cpu_overlap = f"the {args.warmup} untimed warm-up step(s); joined before the timed region started"
+
+    # The LAST warm-up step of rank 0 carries the HIP-event instrumentation (the roofline's table): it is a full pass of the timed
+    # workload either way, and it saves the default run a separate 14 s pass.  (No warm-up, or a different --profile-ddim-steps:
+    # a separate instrumented pass after the timed region, as before.)
+    warm_table = None
+    instr_in_warmup = (rank == 0 and not args.no_roofline and args.warmup > 0 and args.profile_ddim_steps in (0, args.ddim_steps))
+    for i in range(args.warmup):
+        if instr_in_warmup and i == args.warmup - 1:
+            eng.profile_begin()
+            step()
+            warm_table = eng.profile_end()
+        else:
+            step()
+    sync()
+    if cpu_wanted and args.warmup > 0:
+        t_join = time.perf_counter()
+        cpu_leg.join()
+        log(f"cpu_baseline thread joined {time.perf_counter() - t_join:.1f} s after the warm-up ended")
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    t_own = time.perf_counter() - t0
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    own_ms = None
+    if use_dist:
+        # a rank's OWN time for its K steps (up to the sync, before the closing barrier): a straggler shows as a low per-rank rate
+        tt = torch.tensor([t_own], device=dev, dtype=torch.float64)
+        alls = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(alls, tt)
+        own_ms = [1e3 * float(a.item()) / args.steps for a in alls]
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    finite = bool(torch.isfinite(out.float()).all().item())
+    clips = world * B * args.steps
+    value = clips / elapsed
+    host_snapshot = host_frames.clone() if host_frames is not None and not pin else host_frames     # (tests read the timed steps' buffer)
+
+    # the exchange and the D2H on their own (both are inside the timed step above)
+    gather_ms = d2h_ms = None
+    frames1 = eng.generate(lat, cond, unc, 1, args.guidance, 0.0, decode=True)
+    sync()
+    if use_dist:
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            g = all_gather_frames(frames1, as_uint8=as_u8, force_collective=True, engine=gather_engine, uniform=True)
+        sync()
+        gather_ms = 1e3 * (time.perf_counter() - t1) / 3
+    else:
+        g = eng.frames_to_uint8(frames1) if as_u8 else frames1
+    if host_frames is not None:
+        t1 = time.perf_counter()
+        for _ in range(3):
+            host_frames.copy_(g, non_blocking=True)
+        sync()
+        d2h_ms = 1e3 * (time.perf_counter() - t1) / 3
+    rccl_ranks = dist.get_world_size() if use_dist else 0
+    del g, frames1
+
+    result = None
+    if rank == 0:
+        roof = None
+        if not args.no_roofline:
+            if args.profile_ddim_steps <= 0:
+                args.profile_ddim_steps = args.ddim_steps
+            if warm_table is not None:
+                roof, _ = roofline_of(warm_table, args.ddim_steps, B, args.dtype, value / world, args.kernel_table,
+                                      where="the last warm-up step (one e2v_generate pass of the timed workload)")
+            else:
+                roof, _ = instrumented_pass(eng, lat, cond, unc, args.profile_ddim_steps, args.guidance, B, args.dtype, value / world,
+                                            args.kernel_table)
+
+        # ---- BASELINE configs[2] (bf16, B = 32) as a second leg of the default run, inside the driver's wall-clock budget ----
+        c2 = None
+        if configs2 is not None and world == 1 and args.dtype == "fp32" and not args.no_configs2 and not args.no_roofline and not use_dist:
+            age = process_age_s()
+            if age < args.configs2_budget_s:
+                log(f"configs[2] leg: process age {age:.0f} s < {args.configs2_budget_s:.0f} s, running")
+                try:
+                    c2 = configs2(eng, args)
+                except Exception as e:      # the headline line must survive a failure of the extra leg; the reason is reported
+                    c2 = {"skipped": f"failed: {type(e).__name__}: {e}"}
+            else:
+                c2 = {"skipped": f"process age {age:.0f} s >= budget {args.configs2_budget_s:.0f} s (the driver's limit is 600 s)"}
+
+        cpu, parity = None, None
+        if cpu_wanted:
+            if args.warmup <= 0:            # no warm-up to hide it under: alone, after every timed region of the run
+                cpu_leg.start()
+                cpu_leg.join()
+                cpu_overlap = "nothing: run alone after the timed regions (no warm-up steps to hide it under)"
+            cpu, parity = cpu_leg.objects(eng, args, cpu_overlap)
+        dtype_name = {"fp32": "f32", "bf16": "bf16", "fp16": "f16",
+                      "f32x3": "f32 products from 3-way split bf16 operands (6 bf16 MFMAs), f32 accumulate"}[args.dtype]
+        mode_text = {"fp32": "fp32 (BASELINE configs[1])",
+                     "bf16": "bf16 MFMA, bf16 activations in HBM, fp32 accumulate / norm statistics / softmax (BASELINE configs[2])",
+                     "fp16": "fp16 MFMA, fp16 activations in HBM, fp32 accumulate / norm statistics / softmax (the reference's own inference dtype)",
+                     "f32x3": "fp32-equivalent via split bf16 (experimental, opt-in)"}[args.dtype]
+        result = {
+            "metric": "6-frame 288x512 clips/sec (50-step DDIM)", "value": value, "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": dtype_name, "data": "synthetic",
+            "config": {"workload": (f"{world}xMI355X: batch={B}/GPU synthetic latents [B,4,6,36,64] + [B,77,768] cond, "
+                                    f"{args.ddim_steps}-step DDIM, CFG {args.guidance}, 288x512x6 VAE decode, " + mode_text),
+                       "clips_per_gpu": B, "ddim_steps": args.ddim_steps, "guidance_scale": args.guidance,
+                       "unet_samples_per_ddim_step": 2 * B, "weights": "random-init SD-v1-4 architecture, counter RNG seed 42/43",
+                       "timed_region": "e2v_generate (inputs in HBM)" + (" + all-gather of frames" if use_dist else "") +
+                                       f" + D2H of the {args.gather} frames into pinned host memory (rank 0)",
+                       "collective": (f"{args.backend} all-gather of decoded frames ({args.gather}) over {rccl_ranks} rank(s)" if use_dist else "none")},
+            "gather_ms": gather_ms, "d2h_ms": d2h_ms, "rccl_ranks": rccl_ranks if args.backend == "nccl" else 0,
+            "gather": {"dtype": args.gather, "impl": ("e2v_allgather_frames (C ABI, library-owned RCCL communicator)" if args.gather_impl == "cabi"
+                                                      else f"torch.distributed ({args.backend})") if use_dist else "none"},
+            "per_rank_clips_per_s": ({"min": B * 1e3 / max(own_ms), "max": B * 1e3 / min(own_ms), "ms_per_step": own_ms} if own_ms else None),
+            "roofline": roof, "configs2": c2, "cpu_baseline": cpu, "parity": parity, "output_finite": finite,
+            "gpu_over_cpu": (value / cpu["value"]) if cpu and "value" in cpu else None,
+        }
+    return {"result": result, "finite": finite, "host_frames": host_snapshot}
+
+
+class CpuLeg:
+    """The CPU-oracle baseline as a thread (cpu_oracle_run touches no GPU state) + the objects the line carries once it is done."""
+
+    def __init__(self, usd, vsd, ucfg, vcfg, guidance):
+        self.a = (usd, vsd, ucfg, vcfg, guidance)
+        self.out, self.th = {}, None
+
+    def start(self):
+        import threading
+
+        def _leg():
+            try:
+                self.out["run"] = cpu_oracle_run(*self.a)
+            except BaseException as e:          # reported in the line instead of killing the run
+                self.out["error"] = f"{type(e).__name__}: {e}"
+        self.th = threading.Thread(target=_leg, name="cpu_baseline", daemon=True)
+        self.th.start()
+
+    def join(self):
+        if self.th is not None:
+            self.th.join()
+
+    def objects(self, eng, args, overlapped_with):
+        self.join()
+        if "run" not in self.out:
+            return {"skipped": self.out.get("error", "no result")}, None
+        dev = eng.device
+
+        def gpu_gen(l, c, u, n):
+            return eng.generate(l.to(dev), c.to(dev), u.to(dev), n, args.guidance, 0.0, decode=True, return_latents=True)
+        cpu, parity = cpu_baseline(self.out["run"], gpu_gen, args.ddim_steps, args.guidance, overlapped_with)
+        parity["tolerance_frames_max_abs"] = {"bf16": 1e-1, "fp16": 2.5e-2}.get(args.dtype, 1e-3)
+        return cpu, parity
+
+
 def main() -> int:
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -315,7 +533,6 @@ def main() -> int:
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -340,10 +557,8 @@ def main() -> int:
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from eeg2video_amd.dist import all_gather_frames
     from eeg2video_amd.pipeline import build_pipeline
-    from eeg2video_amd.weights import (UNetConfig, VAEConfig, counter_normal, synth_state_dict, unet_param_spec,
-                                       vae_param_spec)
+    from eeg2video_amd.weights import UNetConfig, VAEConfig, synth_state_dict, unet_param_spec, vae_param_spec
 
     t_setup = time.perf_counter()
     if args.dtype == "f32x3":                      # opt-in, experimental: the weights are split at finalize, so select it first
@@ -355,17 +570,7 @@ def main() -> int:
     eng = pipe.unet.engine
     if args.dtype != "f32x3":
         eng.set_compute_dtype(args.dtype)
-    dev = eng.device
-    B = args.batch or (32 if args.dtype == "bf16" else 8)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-    # synthetic inputs, resident in HBM before the timed region (clip k of rank r uses seed 1234 + r*B + k)
-    lat = torch.stack([t(counter_normal(1234 + rank * B + k, "latent", (4, 6, 36, 64))) for k in range(B)]).to(dev)
-    cond = torch.stack([t(counter_normal(1235 + 7919 * (rank * B + k), "cond", (77, 768))) for k in range(B)]).to(dev)
-    unc = t(counter_normal(1236, "uncond", (1, 77, 768))).to(dev)
-    # where the frames end up: the reference's `.cpu().float().numpy()` (pipeline_tuneeeg2video.py:183); rank 0 is the consumer
-    as_u8 = args.gather == "uint8"
-    host_frames = torch.empty((world * B, 3, 6, 288, 512), dtype=torch.uint8 if as_u8 else torch.float32).pin_memory() if rank == 0 else None
-    gather_engine = eng if args.gather_impl == "cabi" else None
+    B = args.batch or (32 if args.dtype in ("bf16", "fp16") else 8)
     if rank == 0:
         log(f"setup {time.perf_counter() - t_setup:.1f} s; device memory held {eng.device_bytes() / 2**30:.2f} GiB")
         if os.environ.get("E2V_LOG_MAPS"):       # profiling aid: where the runtime / tool libraries sit, so that a native backtrace can be attributed
@@ -378,170 +583,14 @@ def main() -> int:
                         seen.add(key)
                         log(f"map {f[0]} {f[5]}")
 
-    def step():
-        frames = eng.generate(lat, cond, unc, args.ddim_steps, args.guidance, 0.0, decode=True)
-        if use_dist:
-            frames = all_gather_frames(frames, as_uint8=as_u8, force_collective=True, engine=gather_engine)
-        elif as_u8:
-            frames = eng.frames_to_uint8(frames)
-        if host_frames is not None:
-            host_frames.copy_(frames, non_blocking=True)
-        return frames
-
-    # The CPU baseline (the oracle on the host cores, ~1 min) runs on a thread BESIDE THE WARM-UP STEPS and is joined before the timed
-    # region starts: the warm-up is untimed GPU work whose host thread sleeps in the HIP runtime, so the two share nothing, the timed
-    # region never sees the oracle's threads, and the default run is a minute shorter than with the leg at its end.
-    cpu_thread, cpu_run, cpu_overlap = None, {}, None
-    cpu_wanted = rank == 0 and world == 1 and not args.no_cpu_baseline
-
-    def start_cpu_leg():
-        import threading
-
-        def _cpu_leg():
-            try:
-                cpu_run["run"] = cpu_oracle_run(usd, vsd, ucfg, vcfg, args.guidance)
-            except BaseException as e:          # reported in the line instead of killing the run
-                cpu_run["error"] = f"{type(e).__name__}: {e}"
-        th = threading.Thread(target=_cpu_leg, name="cpu_baseline", daemon=True)
-        th.start()
-        return th
-
-    if cpu_wanted and args.warmup > 0:
-        cpu_thread = start_cpu_leg()
-        cpu_overlap = f"the {args.warmup} untimed warm-up step(s); joined before the timed region started"
-
-    # The LAST warm-up step of rank 0 carries the HIP-event instrumentation (the roofline's table): it is a full pass of the timed
-    # workload either way, and it saves the default run a separate 14 s pass.  (No warm-up, or a different --profile-ddim-steps:
-    # a separate instrumented pass after the timed region, as before.)
-    warm_table = None
-    instr_in_warmup = (rank == 0 and not args.no_roofline and args.warmup > 0 and args.profile_ddim_steps in (0, args.ddim_steps))
-    for i in range(args.warmup):
-        if instr_in_warmup and i == args.warmup - 1:
-            eng.profile_begin()
-            step()
-            warm_table = eng.profile_end()
-        else:
-            step()
-    torch.cuda.synchronize()
-    if cpu_thread is not None:
-        t_join = time.perf_counter()
-        cpu_thread.join()
-        log(f"cpu_baseline thread joined {time.perf_counter() - t_join:.1f} s after the warm-up ended")
-    if use_dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    t_own = time.perf_counter() - t0
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    own_ms = None
-    if use_dist:
-        # a rank's OWN time for its K steps (up to the sync, before the closing barrier): a straggler shows as a low per-rank rate
-        tt = torch.tensor([t_own], device=dev, dtype=torch.float64)
-        alls = [torch.zeros_like(tt) for _ in range(world)]
-        dist.all_gather(alls, tt)
-        own_ms = [1e3 * float(a.item()) / args.steps for a in alls]
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
-    finite = bool(torch.isfinite(out.float()).all().item())
-    clips = world * B * args.steps
-    value = clips / elapsed
-
-    if cpu_wanted and cpu_thread is None:       # no warm-up to hide it under: beside the GPU-only tail of the run instead
-        cpu_thread = start_cpu_leg()
-        cpu_overlap = "the GPU-only tail of the run (exchange / D2H figures, configs[2] leg); the timed region was over"
-
-    # the exchange and the D2H on their own (both are inside the timed step above)
-    gather_ms = d2h_ms = None
-    frames1 = eng.generate(lat, cond, unc, 1, args.guidance, 0.0, decode=True)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            g = all_gather_frames(frames1, as_uint8=as_u8, force_collective=True, engine=gather_engine)
-        torch.cuda.synchronize()
-        gather_ms = 1e3 * (time.perf_counter() - t1) / 3
-    else:
-        g = eng.frames_to_uint8(frames1) if as_u8 else frames1
-    if host_frames is not None:
-        t1 = time.perf_counter()
-        for _ in range(3):
-            host_frames.copy_(g, non_blocking=True)
-        torch.cuda.synchronize()
-        d2h_ms = 1e3 * (time.perf_counter() - t1) / 3
-    rccl_ranks = dist.get_world_size() if use_dist else 0
-    del g, frames1
-
-    result = None
-    if rank == 0:
-        roof = None
-        if not args.no_roofline:
-            if args.profile_ddim_steps <= 0:
-                args.profile_ddim_steps = args.ddim_steps
-            if warm_table is not None:
-                roof, _ = roofline_of(warm_table, args.ddim_steps, B, args.dtype, value / world, args.kernel_table,
-                                      where="the last warm-up step (one e2v_generate pass of the timed workload)")
-            else:
-                roof, _ = instrumented_pass(eng, lat, cond, unc, args.profile_ddim_steps, args.guidance, B, args.dtype, value / world,
-                                            args.kernel_table)
-
-        # ---- BASELINE configs[2] (bf16, B = 32) as a second leg of the default run, inside the driver's wall-clock budget ----
-        configs2 = None
-        if world == 1 and args.dtype == "fp32" and not args.no_configs2 and not args.no_roofline and not use_dist:
-            age = process_age_s()
-            if age < args.configs2_budget_s:
-                log(f"configs[2] leg: process age {age:.0f} s < {args.configs2_budget_s:.0f} s, running")
-                try:
-                    configs2 = configs2_leg(eng, args)
-                except Exception as e:      # the headline line must survive a failure of the extra leg; the reason is reported
-                    configs2 = {"skipped": f"failed: {type(e).__name__}: {e}"}
-            else:
-                configs2 = {"skipped": f"process age {age:.0f} s >= budget {args.configs2_budget_s:.0f} s (the driver's limit is 600 s)"}
-
-        cpu, parity = None, None
-        if cpu_thread is not None:
-            cpu_thread.join()
-            if "run" in cpu_run:
-                def gpu_gen(l, c, u, n):
-                    return eng.generate(l.to(dev), c.to(dev), u.to(dev), n, args.guidance, 0.0, decode=True, return_latents=True)
-                cpu, parity = cpu_baseline(cpu_run["run"], gpu_gen, args.ddim_steps, args.guidance, cpu_overlap)
-                parity["tolerance_frames_max_abs"] = 1e-1 if args.dtype == "bf16" else 1e-3
-            else:
-                cpu = {"skipped": cpu_run.get("error", "no result")}
-        dtype_name = {"fp32": "f32", "bf16": "bf16", "f32x3": "f32 products from 3-way split bf16 operands (6 bf16 MFMAs), f32 accumulate"}[args.dtype]
-        result = {
-            "metric": "6-frame 288x512 clips/sec (50-step DDIM)", "value": value, "unit": "clips/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype_name, "data": "synthetic",
-            "config": {"workload": (f"{world}xMI355X: batch={B}/GPU synthetic latents [B,4,6,36,64] + [B,77,768] cond, "
-                                    f"{args.ddim_steps}-step DDIM, CFG {args.guidance}, 288x512x6 VAE decode, "
-                                    + {"fp32": "fp32 (BASELINE configs[1])",
-                                       "bf16": "bf16 MFMA, bf16 activations in HBM, fp32 accumulate / norm statistics / softmax (BASELINE configs[2])",
-                                       "f32x3": "fp32-equivalent via split bf16 (experimental, opt-in)"}[args.dtype]),
-                       "clips_per_gpu": B, "ddim_steps": args.ddim_steps, "guidance_scale": args.guidance,
-                       "unet_samples_per_ddim_step": 2 * B, "weights": "random-init SD-v1-4 architecture, counter RNG seed 42/43",
-                       "timed_region": "e2v_generate (inputs in HBM)" + (" + all-gather of frames" if use_dist else "") +
-                                       f" + D2H of the {args.gather} frames into pinned host memory (rank 0)",
-                       "collective": (f"{args.backend} all-gather of decoded frames ({args.gather}) over {rccl_ranks} rank(s)" if use_dist else "none")},
-            "gather_ms": gather_ms, "d2h_ms": d2h_ms, "rccl_ranks": rccl_ranks if args.backend == "nccl" else 0,
-            "gather": {"dtype": args.gather, "impl": ("e2v_allgather_frames (C ABI, library-owned RCCL communicator)" if args.gather_impl == "cabi"
-                                                      else f"torch.distributed ({args.backend})") if use_dist else "none"},
-            "per_rank_clips_per_s": ({"min": B * 1e3 / max(own_ms), "max": B * 1e3 / min(own_ms), "ms_per_step": own_ms} if own_ms else None),
-            "roofline": roof, "configs2": configs2, "cpu_baseline": cpu, "parity": parity, "output_finite": finite,
-            "gpu_over_cpu": (value / cpu["value"]) if cpu and "value" in cpu else None,
-        }
+    r = rank_body(args, rank, world, eng, use_dist=use_dist, B=B, cpu_leg=CpuLeg(usd, vsd, ucfg, vcfg, args.guidance), configs2=configs2_leg)
+    if r["result"] is not None:
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(result) + "\n").encode())
+        os.write(json_fd, (json.dumps(r["result"]) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    return 0 if finite else 1
+    return 0 if r["finite"] else 1
 
 
 if __name__ == "__main__":

@@ -29,8 +29,16 @@ def frames_to_uint8(frames: torch.Tensor) -> torch.Tensor:
     return (frames * 255).to(torch.uint8)
 
 
+def _shard_counts(n: int, device, group) -> list:
+    """The clip count of every rank, exchanged ONCE per call: one stacked tensor, one host read."""
+    world = dist.get_world_size(group)
+    counts = torch.zeros(world, device=device, dtype=torch.int64)
+    dist.all_gather_into_tensor(counts, torch.tensor([n], device=device, dtype=torch.int64), group=group)
+    return counts.tolist()
+
+
 def all_gather_frames(frames: torch.Tensor, group: Optional[dist.ProcessGroup] = None, as_uint8: bool = False,
-                      force_collective: bool = False, engine=None) -> torch.Tensor:
+                      force_collective: bool = False, engine=None, uniform: bool = False) -> torch.Tensor:
     """Every rank contributes ``[b_r, 3, F, H, W]`` (``b_r`` may differ by one between ranks) and receives the
     clips of all ranks in rank order, ``[sum b_r, 3, F, H, W]``.  Single-process: returns the input, unless
     ``force_collective`` asks for the collective to run even over a one-rank group (``bench.py --dist-single``: the RCCL
@@ -38,30 +46,28 @@ def all_gather_frames(frames: torch.Tensor, group: Optional[dist.ProcessGroup] =
 
     ``engine``: run the exchange BELOW the C ABI -- ``e2v_allgather_frames`` on the library's own RCCL communicator
     (``Engine.comm_init``; ``torch.distributed`` then only ships the 128-byte communicator id), with the uint8 conversion fused in
-    front of it.  ``ncclAllGather`` needs the same ``b`` on every rank: the counts are exchanged first (one tiny all-gather) and a
-    ragged set of shards -- the last batch of a sweep -- goes through the padded ``torch.distributed`` path below instead."""
-    if engine is not None and dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective):
-        world = dist.get_world_size(group)
-        dev = frames.device if frames.is_cuda or dist.get_backend(group) != "nccl" else torch.device("cuda")
-        counts = torch.tensor([frames.shape[0]], device=dev, dtype=torch.int64)
-        all_counts = [torch.zeros_like(counts) for _ in range(world)]
-        dist.all_gather(all_counts, counts, group=group)
-        if len({int(c.item()) for c in all_counts}) == 1:
-            engine.comm_init(group)
-            return engine.allgather_frames(frames, as_uint8=as_uint8)
-    x = frames_to_uint8(frames) if as_uint8 else frames
-    if not (dist.is_available() and dist.is_initialized()):
-        return x
-    if dist.get_world_size(group) == 1 and not force_collective:
-        return x
+    front of it.  ``ncclAllGather`` needs the same ``b`` on every rank: the counts are exchanged first (ONE tiny all-gather and one
+    host read per call, shared by both paths) and a ragged set of shards -- the last batch of a sweep -- goes through the padded
+    ``torch.distributed`` path instead.
+
+    ``uniform``: the caller KNOWS every rank holds the same ``b`` (the benchmark, the full batches of a sweep): no count exchange
+    and no host synchronisation in front of the collective."""
+    active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective)
+    if not active:
+        return frames_to_uint8(frames) if as_uint8 else frames
     world = dist.get_world_size(group)
-    counts = torch.tensor([x.shape[0]], device=x.device, dtype=torch.int64)
-    all_counts = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(all_counts, counts, group=group)
-    sizes = [int(c.item()) for c in all_counts]
+    if uniform:
+        sizes = [int(frames.shape[0])] * world
+    else:
+        dev = frames.device if frames.is_cuda or dist.get_backend(group) != "nccl" else torch.device("cuda")
+        sizes = _shard_counts(int(frames.shape[0]), dev, group)
+    same = len(set(sizes)) == 1
+    if engine is not None and same:
+        engine.comm_init(group)
+        return engine.allgather_frames(frames, as_uint8=as_uint8)
+    x = (frames_to_uint8(frames) if as_uint8 else frames).contiguous()
     bmax = max(sizes)
-    x = x.contiguous()
-    if len(set(sizes)) == 1:
+    if same:
         out = torch.empty((world * bmax,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
         dist.all_gather_into_tensor(out, x, group=group)
         return out
