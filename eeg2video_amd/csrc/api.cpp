@@ -6,6 +6,7 @@
 #include <mutex>
 
 #include "../../include/eeg2video_hip_ops.h"
+#include "h16.h"
 #include "model.h"
 #include "prof.h"
 
@@ -246,7 +247,8 @@ e2v_status e2v_semantic_predict(e2v_ctx* c, const float* eeg, int B, float* out,
                 const bool last = i + 1 == c->sem.size();
                 Act y;
                 if (!last) y = Act(c->pool, B, w.out);
-                gemv_rows(x.p, x.C, b16 ? w.w16 : (const void*)w.w, b16 ? w.in16 : w.in, b16 ? 1 : 0, w.b, last ? out : y.p, w.out, B, w.out,
+                const void* w16 = c->h16_mode == H16_FP16 ? c->lin_f16(w, s) : w.w16;
+                gemv_rows(x.p, x.C, b16 ? w16 : (const void*)w.w, b16 ? w.in16 : w.in, b16 ? c->h16_mode : 0, w.b, last ? out : y.p, w.out, B, w.out,
                           b16 ? w.in16 : w.in, last ? 0 : 1, s);
                 if (!last) x = std::move(y);
             }
@@ -254,7 +256,7 @@ e2v_status e2v_semantic_predict(e2v_ctx* c, const float* eeg, int B, float* out,
             return;
         }
         Act x(c->pool, B, c->sem_in_pad, b16);
-        pad_cols(eeg, c->cfg.sem_in_features, x.p, c->sem_in_pad, B, s, b16 ? 1 : 0);
+        pad_cols(eeg, c->cfg.sem_in_features, x.p, c->sem_in_pad, B, s, b16 ? c->h16_mode : 0);
         for (size_t i = 0; i < c->sem.size(); ++i) {              // Linear -> ReLU ... -> Linear (train_semantic_predictor.py:14-28)
             const LinW& w = c->sem[i];
             const bool last = i + 1 == c->sem.size();
@@ -263,8 +265,7 @@ e2v_status e2v_semantic_predict(e2v_ctx* c, const float* eeg, int B, float* out,
             IgemmArgs g;
             g.a0 = x.p; g.c0 = b16 ? w.in16 : w.in; g.lda0 = g.c0; g.w = w.w; g.ldw = w.in; g.bias = w.b;
             g.out = last ? out : y.p; g.ldc = w.out; g.M = B; g.N = w.out; g.taps = 1; g.relu = last ? 0 : 1; g.ldw16 = w.in16;
-            g.w16 = w.w16;
-            if (b16) { g.a_bf16 = 1; g.out_f32 = last ? 1 : 0; }
+            if (b16) { g.w16 = c->h16_mode == H16_FP16 ? c->lin_f16(w, s) : w.w16; g.a_bf16 = c->h16_mode; g.out_f32 = last ? 1 : 0; }
             igemm(g, s);
             if (!last) x = std::move(y);
         }
@@ -328,12 +329,12 @@ int64_t e2v_profile_end(e2v_ctx* c, char* json, int64_t cap) {
 }
 
 e2v_status e2v_set_compute_dtype(e2v_ctx* c, int dtype) {
-    if (!c || (dtype != E2V_F32 && dtype != E2V_BF16 && dtype != E2V_F32X3)) return E2V_EINVAL;
+    if (!c || (dtype != E2V_F32 && dtype != E2V_BF16 && dtype != E2V_F16 && dtype != E2V_F32X3)) return E2V_EINVAL;
     if (dtype == E2V_F32X3 && (c->unet_ready || c->vae_ready || c->sem_ready)) {
         c->err = "E2V_F32X3 needs the split weights: select it before e2v_finalize_weights";
         return E2V_ESTATE;
     }
-    c->bf16_compute = dtype == E2V_BF16;
+    c->set_h16_mode(dtype == E2V_BF16 ? H16_BF16 : dtype == E2V_F16 ? H16_FP16 : H16_NONE);
     c->x3_compute = dtype == E2V_F32X3;
     return E2V_OK;
 }
@@ -560,7 +561,7 @@ e2v_status e2v_generate(e2v_ctx* c, const float* latents, const float* cond, con
 // made, and every launch leaves one record "class shape -> kernel tile".  Output: one line per distinct record in first-occurrence
 // order, "<count>x <record>\n".  A rule change shows up as a diff of this text (tests/golden/dispatch_sd_v1_4.json).
 e2v_status e2v_op_describe_dispatch(e2v_ctx* c, int dtype, int B, int F, int h, int w, int T, char* buf, int64_t cap, int64_t* needed) {
-    if (!c || !needed || (dtype != E2V_F32 && dtype != E2V_BF16) || B <= 0 || F <= 0 || h <= 0 || w <= 0 || T <= 0 || (cap > 0 && !buf)) return E2V_EINVAL;
+    if (!c || !needed || (dtype != E2V_F32 && dtype != E2V_BF16 && dtype != E2V_F16) || B <= 0 || F <= 0 || h <= 0 || w <= 0 || T <= 0 || (cap > 0 && !buf)) return E2V_EINVAL;
     if (c->device >= 0) { c->err = "e2v_op_describe_dispatch runs on a host-only context (e2v_create(..., device = -1, ...))"; return E2V_ESTATE; }
     struct Dry {
         Dry() { dry_run() = true; dry_log().clear(); }
@@ -570,13 +571,12 @@ e2v_status e2v_op_describe_dispatch(e2v_ctx* c, int dtype, int B, int F, int h, 
         if (!c->unet_ready || !c->vae_ready) c->finalize(3);
     });
     if (st != E2V_OK) return st;
-    const bool was_bf16 = c->bf16_compute;
-    c->bf16_compute = dtype == E2V_BF16;
+    const int was_mode = c->h16_mode;
+    c->set_h16_mode(dtype == E2V_BF16 ? H16_BF16 : dtype == E2V_F16 ? H16_FP16 : H16_NONE);
     dry_log().clear();
     const float* fake = dry_fake_ptr(1 << 20);
     st = e2v_generate(c, fake, fake, fake, 1, B, F, h, w, T, 1, 12.5f, 0.0f, dry_fake_ptr(1 << 20), nullptr, nullptr);
-    c->bf16_compute = was_bf16;
-    (void)hipGetLastError();          // nothing the dry run touched may linger as the thread's "last error" of a later real call
+    c->set_h16_mode(was_mode);
     if (st != E2V_OK) return st;
     std::vector<std::pair<std::string, long>> agg;
     std::unordered_map<std::string, size_t> at;
@@ -685,12 +685,12 @@ e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, 
             const int c0p = c1 > 0 ? c0 : (c0 + 7) / 8 * 8, c1p = (c1 + 7) / 8 * 8;
             const int64_t rows_in = (int64_t)n_img * Hs * Ws;
             Act a0(c->pool, rows_in, c0p, true), a1;
-            cvt_rows(x0, c0, 0, a0.p, c0p, 1, rows_in, c0, c0p, s);
-            if (c1 > 0) { a1 = Act(c->pool, rows_in, c1p, true); cvt_rows(x1, c1, 0, a1.p, c1p, 1, rows_in, c1, c1p, s); }
+            cvt_rows(x0, c0, 0, a0.p, c0p, c->h16_mode, rows_in, c0, c0p, s);
+            if (c1 > 0) { a1 = Act(c->pool, rows_in, c1p, true); cvt_rows(x1, c1, 0, a1.p, c1p, c->h16_mode, rows_in, c1, c1p, s); }
             const int ld64 = conv3x3_packed_ld(cin, 64);
             Act w64(c->pool, cout, ld64), w16(c->pool, cout, (ld64 + 1) / 2);
             pack_conv3x3(w_oihw, w64.p, cout, cin, 64, s);
-            to_bf16(w64.p, w16.p, (size_t)cout * ld64, s);
+            to_h16(w64.p, w16.p, (size_t)cout * ld64, c->h16_mode, s);
             IgemmArgs g;
             g.a0 = a0.p; g.c0 = c0p; g.lda0 = c0p; g.a1 = c1 > 0 ? a1.p : nullptr; g.c1 = c1 > 0 ? c1p : 0; g.lda1 = c1p;
             g.w16 = w16.p; g.ldw16 = ld64; g.ldw = ld64; g.out = out; g.ldc = cout; g.bias = bias;
@@ -698,12 +698,12 @@ e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, 
             g.resid = resid; g.ldr = cout; g.M = n_img * Ho * Wo; g.N = cout; g.taps = 9;
             g.Ho = Ho; g.Wo = Wo; g.Hi = Hi; g.Wi = Wi; g.Hs = Hs; g.Ws = Ws; g.stride = stride; g.pad = pad_lo;
             if (Hi != Hs || Wi != Ws) { g.upsample = 1; g.ups_h = (float)Hs / (float)Hi; g.ups_w = (float)Ws / (float)Wi; }
-            g.a_bf16 = 1; g.out_f32 = 1;
+            g.a_bf16 = c->h16_mode; g.out_f32 = 1;
             if (c1 == 0 && c0p == c0 && bgemm_up2x_applies(g)) {   // exact 2x resize: the sub-pixel form the graph runner takes
                 const size_t n = 4 * (size_t)cout * conv_up2x_packed_ld(cin);
                 Act u32(c->pool, (int64_t)((n + 1023) / 1024), 1024), u16(c->pool, (int64_t)((n + 2047) / 2048), 1024);
                 pack_conv_up2x(w_oihw, u32.p, cout, cin, s);
-                to_bf16(u32.p, u16.p, n, s);
+                to_h16(u32.p, u16.p, n, c->h16_mode, s);
                 bgemm_up2x_launch(g, u16.p, s);
                 E2V_HIP(hipGetLastError());
                 return;
@@ -790,11 +790,11 @@ e2v_status e2v_op_linear(e2v_ctx* c, const float* x, int ldx, int64_t M, int K, 
         if (c->bf16_compute) {       // bf16-activation mode: A and W rounded to bf16 once (K zero-padded to 8), fp32 result
             const int K8 = (K + 7) / 8 * 8;
             a16 = Act(c->pool, M, K8, true);
-            cvt_rows(x, ldx, 0, a16.p, K8, 1, M, K, K8, s);
+            cvt_rows(x, ldx, 0, a16.p, K8, c->h16_mode, M, K, K8, s);
             w16 = Act(c->pool, g.N, K8, true);
-            cvt_rows(g.w, K, 0, w16.p, K8, 1, g.N, K, K8, s);
+            cvt_rows(g.w, K, 0, w16.p, K8, c->h16_mode, g.N, K, K8, s);
             g.a0 = a16.p; g.c0 = K8; g.lda0 = K8;
-            g.a_bf16 = 1; g.out_f32 = 1; g.w16 = w16.p; g.ldw16 = K8;
+            g.a_bf16 = c->h16_mode; g.out_f32 = 1; g.w16 = w16.p; g.ldw16 = K8;
         }
         Act w3;
         if (c->x3_compute) {
@@ -824,11 +824,11 @@ e2v_status e2v_op_groupnorm(e2v_ctx* c, const float* x0, int c0, const float* x1
         if (c->bf16_compute) {       // bf16-activation mode: bf16 rows in and out (fp32 statistics), converted at this boundary
             const int64_t rows = (int64_t)samples * P;
             Act b0(c->pool, rows, c0, true), b1, bo(c->pool, rows, C, true);
-            cvt_rows(x0, c0, 0, b0.p, c0, 1, rows, c0, c0, s);
-            if (c1 > 0) { b1 = Act(c->pool, rows, c1, true); cvt_rows(x1, c1, 0, b1.p, c1, 1, rows, c1, c1, s); }
-            a.bf16 = 1; a.x0 = b0.p; a.x1 = c1 > 0 ? b1.p : nullptr; a.out = bo.p;
+            cvt_rows(x0, c0, 0, b0.p, c0, c->h16_mode, rows, c0, c0, s);
+            if (c1 > 0) { b1 = Act(c->pool, rows, c1, true); cvt_rows(x1, c1, 0, b1.p, c1, c->h16_mode, rows, c1, c1, s); }
+            a.bf16 = c->h16_mode; a.x0 = b0.p; a.x1 = c1 > 0 ? b1.p : nullptr; a.out = bo.p;
             groupnorm(a, s);
-            cvt_rows(bo.p, C, 1, out, C, 0, rows, C, C, s);
+            cvt_rows(bo.p, C, c->h16_mode, out, C, 0, rows, C, C, s);
         } else {
             groupnorm(a, s);
         }
@@ -844,9 +844,9 @@ e2v_status e2v_op_layernorm(e2v_ctx* c, const float* x, int64_t rows, int C, con
         hipStream_t s = S(c, stream);
         if (c->bf16_compute) {
             Act bi(c->pool, rows, C, true), bo(c->pool, rows, C, true);
-            cvt_rows(x, C, 0, bi.p, C, 1, rows, C, C, s);
-            layernorm(bi.p, C, gamma, beta, bo.p, C, (int)rows, C, eps, s, 1);
-            cvt_rows(bo.p, C, 1, out, C, 0, rows, C, C, s);
+            cvt_rows(x, C, 0, bi.p, C, c->h16_mode, rows, C, C, s);
+            layernorm(bi.p, C, gamma, beta, bo.p, C, (int)rows, C, eps, s, c->h16_mode);
+            cvt_rows(bo.p, C, c->h16_mode, out, C, 0, rows, C, C, s);
         } else {
             layernorm(x, C, gamma, beta, out, C, (int)rows, C, eps, s);
         }
@@ -862,7 +862,7 @@ e2v_status e2v_op_rowblock_sums(e2v_ctx* c, const float* x, int64_t rows, int C,
         E2V_REQUIRE(x && out && rows > 0 && rows % 64 == 0 && C > 0 && C % 8 == 0, E2V_EINVAL, "rowblock_sums: rows must be a multiple of 64, C of 8");
         hipStream_t s = S(c, stream);
         Act b(c->pool, rows, C, true);
-        cvt_rows(x, C, 0, b.p, C, 1, rows, C, C, s);
+        cvt_rows(x, C, 0, b.p, C, H16_BF16, rows, C, C, s);
         rowblock_sums(b.p, C, C, rows, rbsum_rows_per_pass(C), out, s);
         E2V_HIP(hipGetLastError());
     });
@@ -885,12 +885,12 @@ e2v_status e2v_op_attention(e2v_ctx* c, const float* q, int ldq, const float* k,
             const int C = heads * D;
             const int64_t qrows = (int64_t)n * F * Nq, krows = mode == 0 ? (int64_t)n * F * Nk : (int64_t)n * Nk;
             Act bq(c->pool, qrows, C, true), bk(c->pool, krows, C, true), bv(c->pool, krows, C, true), bo(c->pool, qrows, C, true);
-            cvt_rows(q, ldq, 0, bq.p, C, 1, qrows, C, C, s);
-            cvt_rows(k, ldkv, 0, bk.p, C, 1, krows, C, C, s);
-            cvt_rows(v, ldkv, 0, bv.p, C, 1, krows, C, C, s);
-            a.q = bq.p; a.ldq = C; a.k = bk.p; a.v = bv.p; a.ldkv = C; a.o = bo.p; a.ldo = C; a.io_bf16 = 1;
+            cvt_rows(q, ldq, 0, bq.p, C, c->h16_mode, qrows, C, C, s);
+            cvt_rows(k, ldkv, 0, bk.p, C, c->h16_mode, krows, C, C, s);
+            cvt_rows(v, ldkv, 0, bv.p, C, c->h16_mode, krows, C, C, s);
+            a.q = bq.p; a.ldq = C; a.k = bk.p; a.v = bv.p; a.ldkv = C; a.o = bo.p; a.ldo = C; a.io_bf16 = c->h16_mode;
             flash_attention(a, s);
-            cvt_rows(bo.p, C, 1, o, ldo, 0, qrows, C, C, s);
+            cvt_rows(bo.p, C, c->h16_mode, o, ldo, 0, qrows, C, C, s);
         } else {
             flash_attention(a, s);
         }
@@ -908,9 +908,9 @@ e2v_status e2v_op_temporal_attention(e2v_ctx* c, const float* qkv, float* out, i
         if (c->bf16_compute) {
             const int64_t rows = (int64_t)n * F * HW;
             Act bi(c->pool, rows, 3 * C, true), bo(c->pool, rows, C, true);
-            cvt_rows(qkv, 3 * C, 0, bi.p, 3 * C, 1, rows, 3 * C, 3 * C, s);
-            temporal_attention(bi.p, 3 * C, bo.p, C, n, F, HW, heads, D, scale, s, 1);
-            cvt_rows(bo.p, C, 1, out, C, 0, rows, C, C, s);
+            cvt_rows(qkv, 3 * C, 0, bi.p, 3 * C, c->h16_mode, rows, 3 * C, 3 * C, s);
+            temporal_attention(bi.p, 3 * C, bo.p, C, n, F, HW, heads, D, scale, s, c->h16_mode);
+            cvt_rows(bo.p, C, c->h16_mode, out, C, 0, rows, C, C, s);
         } else {
             temporal_attention(qkv, 3 * C, out, C, n, F, HW, heads, D, scale, s);
         }

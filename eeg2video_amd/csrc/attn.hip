@@ -12,6 +12,7 @@
 // two lane halves, so the row max / row sum of the online softmax are per-lane scalars (one
 // cross-half exchange), and P^T is already in the B-operand layout of O^T = V^T P^T: no LDS round
 // trip, no transposes.  K and V tiles (32 keys) are staged through LDS, double-buffered.
+#include "h16.h"
 #include "kernels.h"
 #include "prof.h"
 #include "runtime.h"
@@ -317,7 +318,7 @@ typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
 // that is bound by its vector instructions (16 v_exp_f32 + 8 conversions + the maximum are what is left).
 // KT: keys per LDS stage (32 or 64: one barrier per 64 keys -- the four waves of a workgroup sit on four SIMDs, each shared with
 // three other workgroups, and every barrier couples them).
-template <int D, bool FOLD, int KT>
+template <typename H, int D, bool FOLD, int KT>      // H: bf16 / fp16 (h16.h)
 __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p) {
     constexpr int DP = (D + 15) / 16 * 16;      // head dim padded to the 16-deep MFMA step
     constexpr int KS = DP / 16;
@@ -349,9 +350,9 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
     const int head = blk.head;
     const int q0 = (blk.qb * 4 + wave) * 32;
     const bool active = q0 < p.Nq;
-    const __bf16* __restrict__ Q = reinterpret_cast<const __bf16*>(p.q);
-    const __bf16* __restrict__ K = reinterpret_cast<const __bf16*>(p.k);
-    const __bf16* __restrict__ V = reinterpret_cast<const __bf16*>(p.v);
+    const H* __restrict__ Q = reinterpret_cast<const H*>(p.q);
+    const H* __restrict__ K = reinterpret_cast<const H*>(p.k);
+    const H* __restrict__ V = reinterpret_cast<const H*>(p.v);
 
     int nseg = 1;
     size_t kvbase[2];
@@ -370,24 +371,24 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
     if constexpr (SUMV) {
         __syncthreads();
         if (tid < 2 * KT)                                                   // value column D of every key row, both stages: 1.0
-            *reinterpret_cast<__bf16*>(smem_h + (tid / KT) * STAGE + KBYTES + (tid % KT) * VROW + D * 2) = (__bf16)1.0f;
+            *reinterpret_cast<H*>(smem_h + (tid / KT) * STAGE + KBYTES + (tid % KT) * VROW + D * 2) = (H)1.0f;
     }
 
-    abf16x8 qf[KS];
+    hx8<H> qf[KS];
     {
         const int qrow = min(q0 + j, p.Nq - 1);
-        const __bf16* qp = Q + ((size_t)sf * p.Nq + qrow) * p.ldq + head * D;
+        const H* qp = Q + ((size_t)sf * p.Nq + qrow) * p.ldq + head * D;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int k0 = 16 * s + 8 * h;
-            abf16x8 a;
+            hx8<H> a;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] = (__bf16)0.f;
-            if (k0 < D) a = *reinterpret_cast<const abf16x8*>(qp + k0);
+            for (int e = 0; e < 8; ++e) a[e] = (H)0.f;
+            if (k0 < D) a = *reinterpret_cast<const hx8<H>*>(qp + k0);
             if constexpr (FOLD) {
                 const float qs = p.scale * 1.44269504088896340736f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = (__bf16)((float)a[e] * qs);
+                for (int e = 0; e < 8; ++e) a[e] = (H)((float)a[e] * qs);
             }
             qf[s] = a;
         }
@@ -455,7 +456,6 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
     // and keys 4 (g >> 1) .. + 3 of each 8-key half of the k-step; lane 4 q + p of the group supplies row q, columns 4 p ..
     const int ti = lane & 15;
     const int tr_off = (4 * h + (ti >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (ti & 3)) * 2;
-    typedef __attribute__((address_space(3))) abf16x4* lds_b4;
 
     int key0 = 0;
     for (int tt = 0; tt < ntiles; ++tt) {
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
             const char* kp = Kl + j * KROW + h * 16;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const abf16x8 kf = *reinterpret_cast<const abf16x8*>(kp + s * 32);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? (FOLD ? negm : zero16) : st, 0, 0, 0);
+                const hx8<H> kf = *reinterpret_cast<const hx8<H>*>(kp + s * 32);
+                st = mfma_32x32x16(kf, qf[s], s == 0 ? (FOLD ? negm : zero16) : st);
             }
             if (keyb + 32 > p.Nk) {
                 asm volatile("" ::: "memory");                  // (rare path: keep it a branch -- if-converted, its 48 selects run on every tile)
@@ -543,11 +543,11 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
                 for (int r = 0; r < 16; ++r) ps += st[r];
                 l_i = l_i * alpha + ps;
             }
-            abf16x8 pf[2];                       // P^T fragments: registers 8s..8s+7 are k-step s as they stand
+            hx8<H> pf[2];                       // P^T fragments: registers 8s..8s+7 are k-step s as they stand
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[s][e] = (__bf16)st[8 * s + e];
+                for (int e = 0; e < 8; ++e) pf[s][e] = (H)st[8 * s + e];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 if (moved) {
@@ -558,10 +558,10 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
                 const char* vb = Vl + tr_off + t * 64;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const abf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s) * VROW));       // keys 16s + 4h + 0..3
-                    const abf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s + 8) * VROW));   // keys 16s + 8 + 4h + 0..3
-                    const abf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], acc[t], 0, 0, 0);
+                    const hx4<H> lo = lds_read_tr16<H>((vb + (16 * s) * VROW));       // keys 16s + 4h + 0..3
+                    const hx4<H> hi = lds_read_tr16<H>((vb + (16 * s + 8) * VROW));   // keys 16s + 8 + 4h + 0..3
+                    const hx8<H> vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[t] = mfma_32x32x16(vf, pf[s], acc[t]);
                 }
             }
         }
@@ -576,17 +576,17 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
     else l_tot = l_i + __shfl_xor(l_i, 32);
     if (active && q0 + j < p.Nq) {
         const float inv = 1.0f / l_tot;
-        __bf16* op = reinterpret_cast<__bf16*>(p.o) + ((size_t)sf * p.Nq + q0 + j) * p.ldo + head * D;
+        H* op = reinterpret_cast<H*>(p.o) + ((size_t)sf * p.Nq + q0 + j) * p.ldo + head * D;
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int dv = t * 32 + 8 * rg + 4 * h;
                 if (dv < D) {
-                    abf16x4 o;
+                    hx4<H> o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[t][rg * 4 + e] * inv);
-                    *reinterpret_cast<abf16x4*>(op + dv) = o;
+                    for (int e = 0; e < 4; ++e) o[e] = (H)(acc[t][rg * 4 + e] * inv);
+                    *reinterpret_cast<hx4<H>*>(op + dv) = o;
                 }
             }
     }
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void flash_attn_b16io_kernel(const AttnArgs p)
 // before this tile is computed, and the denominator is again row D of O^T.  The maximum is subtracted only when a row needs it
 // (|max| > 8, wave-uniform branch): with scores pre-scaled into the exp2 domain by the bf16 Q, probabilities stay within
 // [2^-8, 2^8] otherwise and the normalised result is the same.
-template <int D>
+template <typename H, int D>
 __global__ __launch_bounds__(256) void cross_attn_resident_kernel(const AttnArgs p, const int tpw, const int chunks) {
     constexpr int DP = (D + 15) / 16 * 16;
     constexpr int KS = DP / 16;
@@ -626,10 +626,10 @@ __global__ __launch_bounds__(256) void cross_attn_resident_kernel(const AttnArgs
     if (smp >= p.n) return;
     const int head = w / chunks, chunk = w - head * chunks;
     const int rows = p.F * p.Nq;                                        // query rows of the sample
-    const __bf16* __restrict__ Q = reinterpret_cast<const __bf16*>(p.q) + (size_t)smp * rows * p.ldq + head * D;
-    const __bf16* __restrict__ K = reinterpret_cast<const __bf16*>(p.k) + (size_t)smp * p.Nk * p.ldkv + head * D;
-    const __bf16* __restrict__ V = reinterpret_cast<const __bf16*>(p.v) + (size_t)smp * p.Nk * p.ldkv + head * D;
-    __bf16* __restrict__ O = reinterpret_cast<__bf16*>(p.o) + (size_t)smp * rows * p.ldo + head * D;
+    const H* __restrict__ Q = reinterpret_cast<const H*>(p.q) + (size_t)smp * rows * p.ldq + head * D;
+    const H* __restrict__ K = reinterpret_cast<const H*>(p.k) + (size_t)smp * p.Nk * p.ldkv + head * D;
+    const H* __restrict__ V = reinterpret_cast<const H*>(p.v) + (size_t)smp * p.Nk * p.ldkv + head * D;
+    H* __restrict__ O = reinterpret_cast<H*>(p.o) + (size_t)smp * rows * p.ldo + head * D;
 
     for (int i = tid * 16; i < KBYTES + NKEY * VROW; i += 256 * 16)      // pad rows / columns: zeros
         *reinterpret_cast<f32x4*>(smem_c + i) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -640,42 +640,41 @@ __global__ __launch_bounds__(256) void cross_attn_resident_kernel(const AttnArgs
         *reinterpret_cast<f32x4*>(smem_c + KBYTES + row * VROW + c8 * 16) = *reinterpret_cast<const f32x4*>(V + (size_t)row * p.ldkv + c8 * 8);
     }
     if constexpr (SUMV) {
-        if (tid < NKEY) *reinterpret_cast<__bf16*>(smem_c + KBYTES + tid * VROW + D * 2) = (__bf16)(tid < p.Nk ? 1.0f : 0.0f);
+        if (tid < NKEY) *reinterpret_cast<H*>(smem_c + KBYTES + tid * VROW + D * 2) = (H)(tid < p.Nk ? 1.0f : 0.0f);
     }
     __syncthreads();
 
     const float qs = p.scale * 1.44269504088896340736f;
-    auto load_q = [&](const int row0, abf16x8 (&qf)[KS]) {
+    auto load_q = [&](const int row0, hx8<H> (&qf)[KS]) {
         const int qrow = min(row0 + j, rows - 1);
-        const __bf16* qp = Q + (size_t)qrow * p.ldq;
+        const H* qp = Q + (size_t)qrow * p.ldq;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int k0 = 16 * s + 8 * h;
-            abf16x8 a;
+            hx8<H> a;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] = (__bf16)0.f;
-            if (k0 < D) a = *reinterpret_cast<const abf16x8*>(qp + k0);
+            for (int e = 0; e < 8; ++e) a[e] = (H)0.f;
+            if (k0 < D) a = *reinterpret_cast<const hx8<H>*>(qp + k0);
             qf[s] = a;
         }
     };
     const int ti = lane & 15;
     const int tr_off = (4 * h + (ti >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (ti & 3)) * 2;
-    typedef __attribute__((address_space(3))) abf16x4* lds_b4;
     const char* const Kl = smem_c;
     const char* const Vl = smem_c + KBYTES;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     const int tile0 = chunk * 4 * tpw + wave;                            // this wave's tiles: tile0, tile0 + 4, ...
-    abf16x8 qn[KS];
+    hx8<H> qn[KS];
     if (tile0 * 32 < rows) load_q(tile0 * 32, qn);
     for (int it = 0; it < tpw; ++it) {
         const int row0 = (tile0 + 4 * it) * 32;
         if (row0 >= rows) break;
-        abf16x8 qf[KS];
+        hx8<H> qf[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)((float)qn[s][e] * qs);
+            for (int e = 0; e < 8; ++e) qf[s][e] = (H)((float)qn[s][e] * qs);
         }
         if (it + 1 < tpw && row0 + 128 < rows) load_q(row0 + 128, qn);      // the next tile's rows: in flight under this tile
 
@@ -685,8 +684,8 @@ __global__ __launch_bounds__(256) void cross_attn_resident_kernel(const AttnArgs
             const char* kp = Kl + (kt * 32 + j) * KROW + h * 16;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const abf16x8 kf = *reinterpret_cast<const abf16x8*>(kp + s * 32);
-                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? zero16 : st[kt], 0, 0, 0);
+                const hx8<H> kf = *reinterpret_cast<const hx8<H>*>(kp + s * 32);
+                st[kt] = mfma_32x32x16(kf, qf[s], s == 0 ? zero16 : st[kt]);
             }
         }
 #pragma unroll
@@ -726,18 +725,18 @@ __global__ __launch_bounds__(256) void cross_attn_resident_kernel(const AttnArgs
         for (int t = 0; t < T; ++t) {
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-                abf16x8 pf[2];
+                hx8<H> pf[2];
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) pf[s][e] = (__bf16)st[kt][8 * s + e];
+                    for (int e = 0; e < 8; ++e) pf[s][e] = (H)st[kt][8 * s + e];
                 const char* vb = Vl + kt * 32 * VROW + tr_off + t * 64;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const abf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s) * VROW));
-                    const abf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s + 8) * VROW));
-                    const abf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], (kt == 0 && s == 0) ? zero16 : acc[t], 0, 0, 0);
+                    const hx4<H> lo = lds_read_tr16<H>((vb + (16 * s) * VROW));
+                    const hx4<H> hi = lds_read_tr16<H>((vb + (16 * s + 8) * VROW));
+                    const hx8<H> vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[t] = mfma_32x32x16(vf, pf[s], (kt == 0 && s == 0) ? zero16 : acc[t]);
                 }
             }
         }
@@ -750,7 +749,7 @@ __global__ __launch_bounds__(256) void cross_attn_resident_kernel(const AttnArgs
             // columns 16 k + 8 h .. + 7 -- per row and instruction 32 contiguous bytes, half as many store instructions as 8-byte pieces
             const float inv = 1.0f / l_tot;
             const bool row_ok = row0 + j < rows;
-            __bf16* op = O + (size_t)min(row0 + j, rows - 1) * p.ldo;
+            H* op = O + (size_t)min(row0 + j, rows - 1) * p.ldo;
             typedef unsigned cu32x2 __attribute__((ext_vector_type(2)));
             typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -758,11 +757,11 @@ __global__ __launch_bounds__(256) void cross_attn_resident_kernel(const AttnArgs
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     if (32 * t + 16 * k >= D) continue;               // (compile-time: the pair lies beyond the head)
-                    abf16x4 oa, ob;
+                    hx4<H> oa, ob;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        oa[e] = (__bf16)(acc[t][(2 * k) * 4 + e] * inv);
-                        ob[e] = (__bf16)(acc[t][(2 * k + 1) * 4 + e] * inv);
+                        oa[e] = (H)(acc[t][(2 * k) * 4 + e] * inv);
+                        ob[e] = (H)(acc[t][(2 * k + 1) * 4 + e] * inv);
                     }
                     const cu32x2 a = __builtin_bit_cast(cu32x2, oa), bq = __builtin_bit_cast(cu32x2, ob);
                     unsigned a0 = a[0], a1 = a[1], b0 = bq[0], b1 = bq[1];
@@ -789,16 +788,15 @@ static bool launch_cross_resident(const AttnArgs& a, hipStream_t s) {
     const int chunks = (tiles + 4 * tpw - 1) / (4 * tpw);
     const unsigned grid = 8u * ((a.n + 7) / 8) * (unsigned)(a.heads * chunks);
     const double probs = (double)a.n * a.F * a.heads;
-    std::string pname = "flash_attn_bf16_cross";
+    std::string pname = a.io_bf16 == H16_FP16 ? "flash_attn_fp16_cross" : "flash_attn_bf16_cross";
     if (prof_detail()) pname += attn_shape_tag(a);
     ProfScope ps(pname.c_str(), 4.0 * probs * a.Nq * a.Nk * D, 2.0 * probs * D * (2.0 * a.Nq + 2.0 * (double)a.Nk / a.F), s);
     dry_tag(" -> cross_attn_resident_kernel tpw" + std::to_string(tpw));
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_resident_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        configured = true;
-    }
-    E2V_KLAUNCH(cross_attn_resident_kernel<D>, dim3(grid), dim3(256), smem, s, a, tpw, chunks);
+    h16_dispatch(a.io_bf16, [&](auto h16_tag) {
+        using H = decltype(h16_tag);
+        E2V_KATTR((cross_attn_resident_kernel<H, D>), smem);
+        E2V_KLAUNCH((cross_attn_resident_kernel<H, D>), dim3(grid), dim3(256), smem, s, a, tpw, chunks);
+    });
     return true;
 }
 
@@ -814,27 +812,26 @@ static void launch_flash_b16io(const AttnArgs& a, hipStream_t s) {
     dim3 grid(attn_grid(a), 1, 1);
     const double nk = a.mode == 0 ? 2.0 * a.Nk : (double)a.Nk;
     const double probs = (double)a.n * a.F * a.heads;
-    std::string pname = a.mode == 0 ? "flash_attn_bf16_sparse_causal" : "flash_attn_bf16_cross";
+    std::string pname = std::string(a.io_bf16 == H16_FP16 ? "flash_attn_fp16" : "flash_attn_bf16") + (a.mode == 0 ? "_sparse_causal" : "_cross");
     if (prof_detail()) pname += attn_shape_tag(a);
     ProfScope ps(pname.c_str(), 4.0 * probs * a.Nq * nk * D,
                  2.0 * probs * D * (2.0 * a.Nq + 2.0 * (a.mode == 0 ? a.Nk : (double)a.Nk / a.F)), s);
     auto go = [&](auto kern, const int kt) {
         dry_tag(std::string(" -> flash_attn_b16io_kernel") + (*fold ? " fold" : "") + " kt" + std::to_string(kt));
-        static bool configured = false;
         const size_t smem = 2 * stage_bytes(kt);
-        if (!configured) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * stage_bytes(64)));
-            configured = true;
-        }
+        E2V_KATTR(kern, (2 * stage_bytes(64)));
         E2V_KLAUNCH(kern, grid, dim3(256), smem, s, a);
     };
     // 64-key stages halve the barriers per key, but at D = 160 two such stages are 84 KB and only one block fits a CU (measured: 224 vs
     // 344 TFLOP/s at the 12x12 level) -- keep them to the head sizes where three blocks still fit
     const bool wide = *kt64 && a.Nk > 32 && 2 * stage_bytes(64) <= 52 * 1024;
-    if (*fold) { if (wide) go(flash_attn_b16io_kernel<D, true, 64>, 64); else go(flash_attn_b16io_kernel<D, true, 32>, 32); }
+    h16_dispatch(a.io_bf16, [&](auto h16_tag) {
+        using H = decltype(h16_tag);
+        if (*fold) { if (wide) go(flash_attn_b16io_kernel<H, D, true, 64>, 64); else go(flash_attn_b16io_kernel<H, D, true, 32>, 32); }
 #ifdef E2V_AB              // the plain form (scale and maximum by vector FMAs): the other arm of the A/B that adopted the fold
-    else       { if (wide) go(flash_attn_b16io_kernel<D, false, 64>, 64); else go(flash_attn_b16io_kernel<D, false, 32>, 32); }
+        else       { if (wide) go(flash_attn_b16io_kernel<H, D, false, 64>, 64); else go(flash_attn_b16io_kernel<H, D, false, 32>, 32); }
 #endif
+    });
 }
 
 // =====================================================================================================
@@ -1103,15 +1100,10 @@ __global__ __launch_bounds__(256) void flash_attn_x3_kernel(const AttnArgs p) {
 }
 template <int D>
 static void launch_flash_x3(const AttnArgs& a, hipStream_t s) {
-    static bool configured = false;
     constexpr int DP = (D + 15) / 16 * 16;
     constexpr size_t stage = ((size_t)3 * (32 * (DP * 2 + 16) + ((D + 31) / 32) * 32 * 72) + 15) / 16 * 16;
     constexpr size_t smem = 2 * stage;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_x3_kernel<D>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        configured = true;
-    }
+    E2V_KATTR(&flash_attn_x3_kernel<D>, smem);
     dim3 grid(attn_grid(a), 1, 1);
     const double nk = a.mode == 0 ? 2.0 * a.Nk : (double)a.Nk;
     const double probs = (double)a.n * a.F * a.heads;
@@ -1122,13 +1114,8 @@ static void launch_flash_x3(const AttnArgs& a, hipStream_t s) {
 
 template <int D>
 static void launch_flash(const AttnArgs& a, hipStream_t s) {
-    static bool configured = false;
     constexpr size_t smem = (size_t)2 * 2 * 32 * (D + 4) * sizeof(float);
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_kernel<D>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        configured = true;
-    }
+    E2V_KATTR(&flash_attn_kernel<D>, smem);
     dim3 grid(attn_grid(a), 1, 1);
     const double nk = a.mode == 0 ? 2.0 * a.Nk : (double)a.Nk;       // the reference attends to 2N concatenated keys
     const double probs = (double)a.n * a.F * a.heads;
@@ -1256,7 +1243,7 @@ __global__ __launch_bounds__(128) void temporal_attn_lds_kernel(const T* __restr
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [F][PB][q | k | v][CS]
     const int smp = blockIdx.x / npg, p0 = (blockIdx.x - smp * npg) * PB;
     const int c_base = blockIdx.y * CS;
-    if constexpr (std::is_same<T, __bf16>::value) {       // bf16 rows: 16-byte (8-channel) pieces, widened on their way into LDS
+    if constexpr (!std::is_same<T, float>::value) {       // bf16 rows: 16-byte (8-channel) pieces, widened on their way into LDS
         const int CO = CS / 8;
         const int total = F * PB * 3 * CO;
         for (int idx = threadIdx.x; idx < total; idx += 128) {
@@ -1268,7 +1255,7 @@ __global__ __launch_bounds__(128) void temporal_attn_lds_kernel(const T* __restr
             const int pix = p0 + pp;
             f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
             if (pix < HW) {
-                const abf16x8 v = *reinterpret_cast<const abf16x8*>(qkv + ((size_t)(smp * F + f) * HW + pix) * ld + part * C + c_base + c8 * 8);
+                const hx8<T> v = *reinterpret_cast<const hx8<T>*>(qkv + ((size_t)(smp * F + f) * HW + pix) * ld + part * C + c_base + c8 * 8);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { lo[e] = (float)v[e]; hi[e] = (float)v[4 + e]; }
             }
@@ -1331,7 +1318,7 @@ __global__ __launch_bounds__(128) void temporal_attn_lds_kernel(const T* __restr
             }
         const float inv = 1.0f / l;
         T* op = out + ((size_t)(smp * F + i) * HW + pix) * ldo + c_base + hh * D;
-        if constexpr (std::is_same<T, __bf16>::value) {
+        if constexpr (!std::is_same<T, float>::value) {
             for (int c = 0; c < D; c += 8) {                    // D % 8 == 0: one 16-byte store per 8 channels
                 f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
@@ -1341,10 +1328,10 @@ __global__ __launch_bounds__(128) void temporal_attn_lds_kernel(const T* __restr
                         o0 += *reinterpret_cast<const f32x4*>(v + jf * fs + c) * pw;
                         o1 += *reinterpret_cast<const f32x4*>(v + jf * fs + c + 4) * pw;
                     }
-                abf16x8 ob;
+                hx8<T> ob;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { ob[e] = (__bf16)o0[e]; ob[4 + e] = (__bf16)o1[e]; }
-                *reinterpret_cast<abf16x8*>(op + c) = ob;
+                for (int e = 0; e < 4; ++e) { ob[e] = (T)o0[e]; ob[4 + e] = (T)o1[e]; }
+                *reinterpret_cast<hx8<T>*>(op + c) = ob;
             }
         } else {
             for (int c = 0; c < D; c += 4) {
@@ -1386,7 +1373,7 @@ __global__ __launch_bounds__(256) void temporal_attn_wave_kernel(const T* __rest
                                                                  long npix, int heads, float scale) {
     constexpr int CH = D / 8;
     constexpr int LH = CH <= 4 ? 4 : CH <= 8 ? 8 : CH <= 16 ? 16 : 32;
-    constexpr bool B16 = std::is_same<T, __bf16>::value;
+    constexpr bool B16 = !std::is_same<T, float>::value;
     const int lpp = heads * LH;                                  // lanes per pixel (divides 256: launcher)
     const int t = threadIdx.x;
     const int lp = t % lpp;
@@ -1419,8 +1406,8 @@ __global__ __launch_bounds__(256) void temporal_attn_wave_kernel(const T* __rest
         // (bf16 -> fp32 is a shift: the element is the high half of the float.  v_dot2c_f32_bf16 would take the packed pairs as they
         // are, but its result feeding a DPP add came out wrong on gfx950 / ROCm 7.2 -- tools/micro/dot2_check.hip shows the
         // instruction itself is right -- and the kernel is bound by its loads either way)
-        auto lo = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
-        auto hi = [](unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); };
+        auto lo = [](unsigned u) { return h16_unpack_lo<T>(u); };
+        auto hi = [](unsigned u) { return h16_unpack_hi<T>(u); };
 #pragma unroll
         for (int i = 0; i < F; ++i)
 #pragma unroll
@@ -1482,8 +1469,8 @@ __global__ __launch_bounds__(256) void temporal_attn_wave_kernel(const T* __rest
             if constexpr (B16) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {                    // bf16 -> fp32: the element IS the high half of the float
-                    o[2 * e] = __builtin_fmaf(s[i][j], __builtin_bit_cast(float, v16[j][e] << 16), o[2 * e]);
-                    o[2 * e + 1] = __builtin_fmaf(s[i][j], __builtin_bit_cast(float, v16[j][e] & 0xFFFF0000u), o[2 * e + 1]);
+                    o[2 * e] = __builtin_fmaf(s[i][j], h16_unpack_lo<T>(v16[j][e]), o[2 * e]);
+                    o[2 * e + 1] = __builtin_fmaf(s[i][j], h16_unpack_hi<T>(v16[j][e]), o[2 * e + 1]);
                 }
             } else {
 #pragma unroll
@@ -1492,10 +1479,10 @@ __global__ __launch_bounds__(256) void temporal_attn_wave_kernel(const T* __rest
         }
         if (on) {
             if constexpr (B16) {
-                abf16x8 ob8;
+                hx8<T> ob8;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ob8[e] = (__bf16)o[e];
-                *reinterpret_cast<abf16x8*>(ob + i * ofs) = ob8;
+                for (int e = 0; e < 8; ++e) ob8[e] = (T)o[e];
+                *reinterpret_cast<hx8<T>*>(ob + i * ofs) = ob8;
             } else {
                 *reinterpret_cast<f32x4*>(ob + i * ofs) = f32x4{o[0], o[1], o[2], o[3]};
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ob + i * ofs) + 4) = f32x4{o[4], o[5], o[6], o[7]};
@@ -1528,7 +1515,10 @@ void temporal_attention(const float* qkv, int ld, float* out, int ldo, int n, in
     if (prof_detail()) pname += " n" + std::to_string(n) + " F" + std::to_string(F) + " HW" + std::to_string(HW) + " h" + std::to_string(heads) + " D" + std::to_string(D);
     ProfScope ps(pname.c_str(), 4.0 * total * F * D, 4.0 * (bf16 ? 2.0 : 4.0) * (double)n * F * HW * heads * D, s);
     if (bf16)
-        temporal_attention_launch(reinterpret_cast<const __bf16*>(qkv), ld, reinterpret_cast<__bf16*>(out), ldo, n, F, HW, heads, D, scale, s);
+        h16_dispatch(bf16, [&](auto h16_tag) {
+            using H = decltype(h16_tag);
+            temporal_attention_launch(reinterpret_cast<const H*>(qkv), ld, reinterpret_cast<H*>(out), ldo, n, F, HW, heads, D, scale, s);
+        });
     else
         temporal_attention_launch(qkv, ld, out, ldo, n, F, HW, heads, D, scale, s);
 }
@@ -1575,7 +1565,8 @@ static void temporal_attention_launch(const T* qkv, int ld, T* out, int ldo, int
 }
 
 // ---- row softmax in place (single-head VAE attention, 2304 keys, fp32 as the dep computes it) ----------
-__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int ld, int rows, int cols, __bf16* __restrict__ out16) {
+template <typename H>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int ld, int rows, int cols, H* __restrict__ out16) {
     __shared__ float red[4];
     const int row = blockIdx.x;
     float* xr = x + (size_t)row * ld;
@@ -1601,17 +1592,20 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
     l = (red[0] + red[1]) + (red[2] + red[3]);
     const float inv = 1.0f / l;
     if (out16) {                      // bf16-activation mode: the probabilities feed a bf16 GEMM
-        __bf16* orow = out16 + (size_t)row * ld;
-        for (int c = threadIdx.x; c < cols; c += 256) orow[c] = (__bf16)(xr[c] * inv);
+        H* orow = out16 + (size_t)row * ld;
+        for (int c = threadIdx.x; c < cols; c += 256) orow[c] = (H)(xr[c] * inv);
     } else {
         for (int c = threadIdx.x; c < cols; c += 256) xr[c] *= inv;
     }
 }
 
-void softmax_rows(float* x, int ld, int rows, int cols, hipStream_t s, void* out_bf16) {
+void softmax_rows(float* x, int ld, int rows, int cols, hipStream_t s, void* out_bf16, int out_mode) {
     if (rows <= 0) return;
     ProfScope ps("softmax_rows", 8.0 * rows * cols, (out_bf16 ? 10.0 : 12.0) * rows * (double)cols, s);
-    E2V_KLAUNCH(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, x, ld, rows, cols, static_cast<__bf16*>(out_bf16));
+    h16_dispatch(out_mode, [&](auto h16_tag) {
+        using H = decltype(h16_tag);
+        E2V_KLAUNCH(softmax_rows_kernel<H>, dim3(rows), dim3(256), 0, s, x, ld, rows, cols, static_cast<H*>(out_bf16));
+    });
 }
 
 }  // namespace e2v

@@ -16,6 +16,7 @@
 // floats order like their bit patterns, so v_max3_i32 on the raw MFMA output finds it without the canonicalising v_max the
 // compiler puts in front of every fmaxf of an MFMA result) + 1 compare + 16 v_exp_f32 + 8 v_cvt_pk_bf16_f32; the cross-half
 // exchange of the maximum happens only inside the (rare) branch that moves a maximum.
+#include "h16.h"
 #include "kernels.h"
 #include "prof.h"
 #include "runtime.h"
@@ -28,8 +29,6 @@ namespace e2v {
 
 typedef float qf32x16 __attribute__((ext_vector_type(16)));
 typedef float qf32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 qbf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 qbf16x8 __attribute__((ext_vector_type(8)));
 
 // Workgroup -> (query block, head, sample-frame), XCD-aware exactly as attn_block of attn.hip (XCD b & 7 takes whole samples and walks
 // them frame by frame, head by head: the K / V rows of a frame are fetched into ONE L2), for query blocks of QB rows.
@@ -73,7 +72,7 @@ struct Q64Layout {
 };
 
 #ifdef E2V_AB          // the phase-by-phase form (E2V_ATTN_Q64P = 0; d = 80 with E2V_ATTN_Q64 = 2): the other arm of the A/B
-template <int D, int NW>
+template <typename H, int D, int NW>
 __global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnArgs p) {
     static_assert(D % 32 != 0 && D % 8 == 0, "the denominator rides in a spare row of the last O^T tile");
     static_assert(NW >= 2 && NW <= 4, "");
@@ -96,9 +95,9 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnAr
     const int head = blk.head;
     const int q0 = blk.qb * QB + wave * 64;
     const bool active = q0 < p.Nq;
-    const __bf16* __restrict__ Q = reinterpret_cast<const __bf16*>(p.q);
-    const __bf16* __restrict__ K = reinterpret_cast<const __bf16*>(p.k);
-    const __bf16* __restrict__ V = reinterpret_cast<const __bf16*>(p.v);
+    const H* __restrict__ Q = reinterpret_cast<const H*>(p.q);
+    const H* __restrict__ K = reinterpret_cast<const H*>(p.k);
+    const H* __restrict__ V = reinterpret_cast<const H*>(p.v);
 
     int nseg = 1;
     size_t kvbase[2];
@@ -112,24 +111,24 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnAr
         *reinterpret_cast<qf32x4*>(smem_q + i) = qf32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     if (tid < 2 * KT)                                                     // value column D of every key row, both stages: 1.0
-        *reinterpret_cast<__bf16*>(smem_q + (tid / KT) * STAGE + KBYTES + (tid % KT) * VROW + D * 2) = (__bf16)1.0f;
+        *reinterpret_cast<H*>(smem_q + (tid / KT) * STAGE + KBYTES + (tid % KT) * VROW + D * 2) = (H)1.0f;
 
-    qbf16x8 qf[2][KS];
+    hx8<H> qf[2][KS];
     {
         const float qs = p.scale * 1.44269504088896340736f;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int qrow = min(q0 + 32 * b + j, p.Nq - 1);
-            const __bf16* qp = Q + ((size_t)sf * p.Nq + qrow) * p.ldq + head * D;
+            const H* qp = Q + ((size_t)sf * p.Nq + qrow) * p.ldq + head * D;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int k0 = 16 * s + 8 * h;
-                qbf16x8 a;
+                hx8<H> a;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = (__bf16)0.f;
-                if (k0 < D) a = *reinterpret_cast<const qbf16x8*>(qp + k0);
+                for (int e = 0; e < 8; ++e) a[e] = (H)0.f;
+                if (k0 < D) a = *reinterpret_cast<const hx8<H>*>(qp + k0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = (__bf16)((float)a[e] * qs);
+                for (int e = 0; e < 8; ++e) a[e] = (H)((float)a[e] * qs);
                 qf[b][s] = a;
             }
         }
@@ -198,7 +197,6 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnAr
     // tile and keys 4 (g >> 1) .. + 3 of each 8-key half of the k-step; lane 4 q + p of the group supplies row q, columns 4 p ..
     const int ti = lane & 15;
     const int tr_off = (4 * h + (ti >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (ti & 3)) * 2;
-    typedef __attribute__((address_space(3))) qbf16x4* lds_b4;
     constexpr int THRESH_BITS = 0x41000000;        // 8.0f: positive floats compare like their bit patterns
 
     int key0 = 0;
@@ -216,15 +214,15 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnAr
                 const char* Vl = smem_q + buf * STAGE + KBYTES + sub * 32 * VROW;
                 const bool first = tt == 0 && sub == 0;
                 const char* kp = Kl + j * KROW + h * 16;
-                qbf16x8 kf[KS];
+                hx8<H> kf[KS];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const qbf16x8*>(kp + s * 32);
+                for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const hx8<H>*>(kp + s * 32);
                 qf32x16 st[2];
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int s = 0; s < KS; ++s)
-                        st[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[b][s], s == 0 ? negm[b] : st[b], 0, 0, 0);
+                        st[b] = mfma_32x32x16(kf[s], qf[b][s], s == 0 ? negm[b] : st[b]);
                 if (keyb + 32 > p.Nk) {
                     asm volatile("" ::: "memory");              // (ragged last tile of a segment: a branch, not 32 selects on every tile)
 #pragma unroll
@@ -233,14 +231,14 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnAr
                         if (key >= p.Nk) { st[0][r] = -INFINITY; st[1][r] = -INFINITY; }
                     }
                 }
-                qbf16x8 vf[T][2];
+                hx8<H> vf[T][2];
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     const char* vb = Vl + tr_off + t * 64;
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const qbf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s) * VROW));       // keys 16s + 4h + 0..3
-                        const qbf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s + 8) * VROW));   // keys 16s + 8 + 4h + 0..3
+                        const hx4<H> lo = lds_read_tr16<H>((vb + (16 * s) * VROW));       // keys 16s + 4h + 0..3
+                        const hx4<H> hi = lds_read_tr16<H>((vb + (16 * s + 8) * VROW));   // keys 16s + 8 + 4h + 0..3
                         vf[t][s] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
                 }
@@ -275,15 +273,15 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnAr
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[b][t][r] *= alpha;
                     }
-                    qbf16x8 pf[2];                       // P^T fragments: registers 8s..8s+7 are k-step s as they stand
+                    hx8<H> pf[2];                       // P^T fragments: registers 8s..8s+7 are k-step s as they stand
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) pf[s][e] = (__bf16)__builtin_amdgcn_exp2f(st[b][8 * s + e]);
+                        for (int e = 0; e < 8; ++e) pf[s][e] = (H)__builtin_amdgcn_exp2f(st[b][8 * s + e]);
 #pragma unroll
                     for (int t = 0; t < T; ++t)
 #pragma unroll
-                        for (int s = 0; s < 2; ++s) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][s], pf[s], acc[b][t], 0, 0, 0);
+                        for (int s = 0; s < 2; ++s) acc[b][t] = mfma_32x32x16(vf[t][s], pf[s], acc[b][t]);
                 }
             }
         }
@@ -299,17 +297,17 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnAr
             const int qrow = q0 + 32 * b + j;
             if (qrow < p.Nq) {
                 const float inv = 1.0f / l_tot;
-                __bf16* op = reinterpret_cast<__bf16*>(p.o) + ((size_t)sf * p.Nq + qrow) * p.ldo + head * D;
+                H* op = reinterpret_cast<H*>(p.o) + ((size_t)sf * p.Nq + qrow) * p.ldo + head * D;
 #pragma unroll
                 for (int t = 0; t < T; ++t)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
                         const int dv = t * 32 + 8 * rg + 4 * h;
                         if (dv < D) {
-                            qbf16x4 o;
+                            hx4<H> o;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[b][t][rg * 4 + e] * inv);
-                            *reinterpret_cast<qbf16x4*>(op + dv) = o;
+                            for (int e = 0; e < 4; ++e) o[e] = (H)(acc[b][t][rg * 4 + e] * inv);
+                            *reinterpret_cast<hx4<H>*>(op + dv) = o;
                         }
                     }
             }
@@ -336,7 +334,7 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_b16q64_kernel(const AttnAr
 //   * P is bounded as before: a reference moves when a score tops it by more than 2^8.
 // (Pinning the interleave of an iteration with sched_group_barrier -- one MFMA, 3 v_exp_f32 + 1-2 conversions, ... -- made the
 // scheduler give up and bunch eight MFMAs back to back; the compiler's own interleave of the single basic block is the one kept.)
-template <int NW>
+template <typename H, int NW>      // H: bf16 / fp16 (h16.h)
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn_b16q64p_kernel(const AttnArgs p) {
     constexpr int D = 40;
     typedef Q64Layout<D> L;
@@ -359,9 +357,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int head = blk.head;
     const int q0 = blk.qb * QB + wave * 64;
     const bool active = q0 < p.Nq;
-    const __bf16* __restrict__ Q = reinterpret_cast<const __bf16*>(p.q);
-    const __bf16* __restrict__ K = reinterpret_cast<const __bf16*>(p.k);
-    const __bf16* __restrict__ V = reinterpret_cast<const __bf16*>(p.v);
+    const H* __restrict__ Q = reinterpret_cast<const H*>(p.q);
+    const H* __restrict__ K = reinterpret_cast<const H*>(p.k);
+    const H* __restrict__ V = reinterpret_cast<const H*>(p.v);
 
     size_t kvbase[2];
     kvbase[0] = (size_t)(smp * p.F) * p.Nk;
@@ -375,28 +373,28 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     __syncthreads();
     for (int i = tid; i < NBUF * KT; i += NT) {
         char* st = smem_q + (i / KT) * STAGE;
-        *reinterpret_cast<__bf16*>(st + KBYTES + (i % KT) * VROW + D * 2) = (__bf16)1.0f;      // V column D: row D of O^T = the denominator
+        *reinterpret_cast<H*>(st + KBYTES + (i % KT) * VROW + D * 2) = (H)1.0f;      // V column D: row D of O^T = the denominator
     }
 
-    qbf16x8 qf[2][KS];
+    hx8<H> qf[2][KS];
     {
         const float qs = p.scale * 1.44269504088896340736f;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int qrow = min(q0 + 32 * b + j, p.Nq - 1);
-            const __bf16* qp = Q + ((size_t)sf * p.Nq + qrow) * p.ldq + head * D;
+            const H* qp = Q + ((size_t)sf * p.Nq + qrow) * p.ldq + head * D;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int k0 = 16 * s + 8 * h;
-                qbf16x8 a;
+                hx8<H> a;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = (__bf16)0.f;
-                if (k0 < D) a = *reinterpret_cast<const qbf16x8*>(qp + k0);
+                for (int e = 0; e < 8; ++e) a[e] = (H)0.f;
+                if (k0 < D) a = *reinterpret_cast<const hx8<H>*>(qp + k0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = (__bf16)((float)a[e] * qs);
+                for (int e = 0; e < 8; ++e) a[e] = (H)((float)a[e] * qs);
                 qf[b][s] = a;
             }
-            if (h) qf[b][KS - 1][2] = (__bf16)-32768.0f;            // slot D + 2: times the marker column of a key past its segment's end
+            if (h) qf[b][KS - 1][2] = (H)(-H16Traits<H>::mask_marker);      // slot D + 2: times the marker column of a key past its segment's end
         }
     }
 
@@ -433,8 +431,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     };
     // Keys past the end of a segment (its ragged last stage) are masked by the MATRIX pipe as well: column D + 2 of their K rows holds
-    // 1.0 (0 in every real key's row) and slot D + 2 of every query's Q fragment holds -2^15, so their scores come out of the MFMA
-    // near -32768 and exponentiate to zero -- no select in the loop, no second instance of its body.  The thread that stores the
+    // a marker (0 in every real key's row) and slot D + 2 of every query's Q fragment holds minus that marker, so their scores come out
+    // of the MFMA at -marker^2 -- -2^120 in bf16, -2^30 in fp16 (H16Traits: whatever the row's reference maximum is, nothing a real score
+    // reaches) -- and exponentiate to zero: no select in the loop, no second instance of its body.  The thread that stores the
     // first piece of a K row rewrites the row's two marker columns with every stage (the ring reuses the buffer).
     auto store_stage = [&](const int buf, const int left) {     // left: valid keys from the stage's first on
         char* Kl = smem_q + buf * STAGE;
@@ -446,8 +445,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 *reinterpret_cast<qf32x4*>(Vl + ld_row[e] * VROW + ld_c8[e] * 16) = vreg[e];
                 if (ld_c8[e] == 0) {                            // columns D, D + 1: 1.0 (the two maximum slots); D + 2: the marker; D + 3: 0
                     unsigned* mk = reinterpret_cast<unsigned*>(Kl + ld_row[e] * KROW + D * 2);
-                    mk[0] = 0x3F803F80u;
-                    mk[1] = ld_row[e] < left ? 0u : 0x00003F80u;
+                    mk[0] = (unsigned)H16Traits<H>::max_marker_bits * 0x00010001u;
+                    mk[1] = ld_row[e] < left ? 0u : (unsigned)H16Traits<H>::mask_marker_bits;
                 }
             }
         }
@@ -471,21 +470,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int ti = lane & 15;
     const int k_off = j * KROW + h * 16;                                              // K fragment: key row j, columns 16 s + 8 h ..
     const int v_off = KBYTES + (4 * h + (ti >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (ti & 3)) * 2;      // V^T fragment (tr read), as above
-    typedef __attribute__((address_space(3))) qbf16x4* lds_b4;
     constexpr int THRESH_BITS = 0x41000000;        // 8.0f
     const qf32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    qbf16x8 kf[KS];
+    hx8<H> kf[KS];
     auto read_k = [&](const int buf, const int sub) {
         const char* kp = smem_q + buf * STAGE + sub * 32 * KROW + k_off;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const qbf16x8*>(kp + s * 32);
+        for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const hx8<H>*>(kp + s * 32);
     };
     auto scores = [&](qf32x16 (&S)[2]) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) S[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[b][s], s == 0 ? zero16 : S[b], 0, 0, 0);
+            for (int s = 0; s < KS; ++s) S[b] = mfma_32x32x16(kf[s], qf[b][s], s == 0 ? zero16 : S[b]);
     };
     // Move the reference maxima of the rows whose new scores S (computed against the old references) top them by more than 2^8
     // (FIRST: take the tile's maximum whatever it is): new reference = a bf16 number, S and the accumulators follow, -m goes into Q.
@@ -504,10 +502,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const float d = first ? mt : (mt > DEFER ? mt : 0.f);
             // the new reference as TWO bf16 numbers (16 mantissa bits: within 2^-16 of the wanted value at any magnitude, so that a row
             // of huge scores neither overflows its probabilities nor underflows them all)
-            const float want = mref[b] + d;
-            const __bf16 m_hi = (__bf16)want;
-            const __bf16 m_lo = (__bf16)(want - (float)m_hi);
-            const float mnew = (float)m_hi + (float)m_lo;
+            // (the marker columns of K hold MM: 1.0 for bf16; 2.0 for fp16, whose range a reference of 6e4 x log2 e would leave)
+            constexpr float MM = H16Traits<H>::max_marker;
+            const float want = (mref[b] + d) * (1.0f / MM);
+            const H m_hi = (H)want;
+            const H m_lo = (H)(want - (float)m_hi);
+            const float mnew = MM * ((float)m_hi + (float)m_lo);
             const float delta = mnew - mref[b];
             mref[b] = mnew;
             const float alpha = __builtin_amdgcn_exp2f(-delta);
@@ -519,35 +519,35 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[b][t][r] *= alpha;
             }
-            qf[b][KS - 1][0] = h ? (__bf16)(-(float)m_hi) : qf[b][KS - 1][0];      // k = D, D + 1 live in the upper half-wave's fragment of the last k-step
-            qf[b][KS - 1][1] = h ? (__bf16)(-(float)m_lo) : qf[b][KS - 1][1];
+            qf[b][KS - 1][0] = h ? (H)(-(float)m_hi) : qf[b][KS - 1][0];      // k = D, D + 1 live in the upper half-wave's fragment of the last k-step
+            qf[b][KS - 1][1] = h ? (H)(-(float)m_lo) : qf[b][KS - 1][1];
         }
     };
     // One iteration: scores of the NEXT tile into Sn (from the K fragment registers), softmax numerators and PV of THIS tile (scores
     // Sc, V rows at vl), then the K fragments of the tile after next.
     auto iteration = [&](qf32x16 (&Sc)[2], qf32x16 (&Sn)[2], const char* vl, const int kbuf, const int ksub, const bool has_next) {
-        qbf16x8 vf[T][2];
+        hx8<H> vf[T][2];
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const char* vb = vl + t * 64;
-                const qbf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s) * VROW));       // keys 16s + 4h + 0..3
-                const qbf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(vb + (16 * s + 8) * VROW));   // keys 16s + 8 + 4h + 0..3
+                const hx4<H> lo = lds_read_tr16<H>((vb + (16 * s) * VROW));       // keys 16s + 4h + 0..3
+                const hx4<H> hi = lds_read_tr16<H>((vb + (16 * s + 8) * VROW));   // keys 16s + 8 + 4h + 0..3
                 vf[t][s] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         scores(Sn);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            qbf16x8 pf[2];                       // P^T fragments: registers 8s..8s+7 are k-step s as they stand
+            hx8<H> pf[2];                       // P^T fragments: registers 8s..8s+7 are k-step s as they stand
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[s][e] = (__bf16)__builtin_amdgcn_exp2f(Sc[b][8 * s + e]);
+                for (int e = 0; e < 8; ++e) pf[s][e] = (H)__builtin_amdgcn_exp2f(Sc[b][8 * s + e]);
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][s], pf[s], acc[b][t], 0, 0, 0);
+                for (int s = 0; s < 2; ++s) acc[b][t] = mfma_32x32x16(vf[t][s], pf[s], acc[b][t]);
         }
         read_k(kbuf, ksub);
         int mi = imax3(__float_as_int(Sn[0][0]), __float_as_int(Sn[0][1]), __float_as_int(Sn[0][2]));
@@ -598,17 +598,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const int qrow = q0 + 32 * b + j;
             if (qrow < p.Nq) {
                 const float inv = 1.0f / l_tot;
-                __bf16* op = reinterpret_cast<__bf16*>(p.o) + ((size_t)sf * p.Nq + qrow) * p.ldo + head * D;
+                H* op = reinterpret_cast<H*>(p.o) + ((size_t)sf * p.Nq + qrow) * p.ldo + head * D;
 #pragma unroll
                 for (int t = 0; t < T; ++t)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
                         const int dv = t * 32 + 8 * rg + 4 * h;
                         if (dv < D) {
-                            qbf16x4 o;
+                            hx4<H> o;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[b][t][rg * 4 + e] * inv);
-                            *reinterpret_cast<qbf16x4*>(op + dv) = o;
+                            for (int e = 0; e < 4; ++e) o[e] = (H)(acc[b][t][rg * 4 + e] * inv);
+                            *reinterpret_cast<hx4<H>*>(op + dv) = o;
                         }
                     }
             }
@@ -619,26 +619,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 template <int NW>
 static void launch_q64p(const AttnArgs& a, hipStream_t s) {
     typedef Q64Layout<40> L;
-    static bool configured = false;
     constexpr size_t smem = 3 * (size_t)L::STAGE;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_b16q64p_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        configured = true;
-    }
-    E2V_KLAUNCH((flash_attn_b16q64p_kernel<NW>), dim3(q64_grid(a, 64 * NW)), dim3(64 * NW), smem, s, a);
+    h16_dispatch(a.io_bf16, [&](auto h16_tag) {
+        using H = decltype(h16_tag);
+        E2V_KATTR((flash_attn_b16q64p_kernel<H, NW>), smem);
+        E2V_KLAUNCH((flash_attn_b16q64p_kernel<H, NW>), dim3(q64_grid(a, 64 * NW)), dim3(64 * NW), smem, s, a);
+    });
 }
 
 #ifdef E2V_AB
 template <int D, int NW>
 static void launch_q64(const AttnArgs& a, hipStream_t s) {
     typedef Q64Layout<D> L;
-    static bool configured = false;
     constexpr size_t smem = 2 * (size_t)L::STAGE;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_b16q64_kernel<D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        configured = true;
-    }
-    E2V_KLAUNCH((flash_attn_b16q64_kernel<D, NW>), dim3(q64_grid(a, 64 * NW)), dim3(64 * NW), smem, s, a);
+    h16_dispatch(a.io_bf16, [&](auto h16_tag) {
+        using H = decltype(h16_tag);
+        E2V_KATTR((flash_attn_b16q64_kernel<H, D, NW>), smem);
+        E2V_KLAUNCH((flash_attn_b16q64_kernel<H, D, NW>), dim3(q64_grid(a, 64 * NW)), dim3(64 * NW), smem, s, a);
+    });
 }
 #endif
 
@@ -669,7 +667,7 @@ bool flash_attention_q64(const AttnArgs& a, hipStream_t s) {
     const int nw = flash_attention_q64_waves(a);
     if (!nw) return false;
     const double probs = (double)a.n * a.F * a.heads;
-    std::string pname = "flash_attn_bf16_sparse_causal";
+    std::string pname = a.io_bf16 == H16_FP16 ? "flash_attn_fp16_sparse_causal" : "flash_attn_bf16_sparse_causal";
     if (prof_detail()) pname += attn_shape_tag(a);
     ProfScope ps(pname.c_str(), 4.0 * probs * a.Nq * 2.0 * a.Nk * a.D, 2.0 * probs * a.D * (2.0 * a.Nq + 2.0 * a.Nk), s);
     static const int* const pipelined = E2V_AB_KNOB("E2V_ATTN_Q64P", 1);      // 0: the phase-by-phase form of the 64-query kernel

@@ -73,7 +73,7 @@ __device__ __forceinline__ void static_for_taps(F&& f, std::integer_sequence<int
 
 // NST: LDS stages.  2: the next stage's DMA is in flight while this one is multiplied.  3 (one 512-thread workgroup per CU: nothing
 // else on the CU covers a wait): TWO stages in flight, the consumer waits with a counted vmcnt that leaves the younger one outstanding.
-template <int BM, int BN, int WGM, int WGN, int STAGE = 128 * 128 * 2, bool LIN = false, int NST = 2>      // STAGE: stage stride, sized for the largest tile of the launch
+template <typename H, int BM, int BN, int WGM, int WGN, int STAGE = 128 * 128 * 2, bool LIN = false, int NST = 2>      // H: bf16 / fp16 (h16.h); STAGE: stage stride, sized for the largest tile of the launch
 __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, const int n0, char* smem) {
     constexpr int BKE = 64;                         // bf16 elements per stage
     constexpr int ROWB = 128;                       // bytes per LDS tile row
@@ -91,8 +91,8 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
 
-    const __bf16* __restrict__ a0 = reinterpret_cast<const __bf16*>(p.a0) + (size_t)z * p.sa0;
-    const __bf16* __restrict__ a1 = reinterpret_cast<const __bf16*>(p.a1);
+    const H* __restrict__ a0 = reinterpret_cast<const H*>(p.a0) + (size_t)z * p.sa0;
+    const H* __restrict__ a1 = reinterpret_cast<const H*>(p.a1);
     const char* __restrict__ w = reinterpret_cast<const char*>(p.w16) + ((size_t)z * p.sw + (size_t)n0 * p.ldw) * 2;
 
     const int steps0 = (p.c0 + BKE - 1) / BKE, steps1 = (p.c1 + BKE - 1) / BKE;
@@ -129,8 +129,8 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
         tab[e] = pix;
     }
     constexpr unsigned OOB = 0x80000000u;                   // beyond the descriptor window: the buffer unit returns zeros
-    const __bf16* const a0b = a0 + row_base * p.lda0;
-    const __bf16* const a1b = p.c1 > 0 ? a1 + row_base * p.lda1 : a0b;
+    const H* const a0b = a0 + row_base * p.lda0;
+    const H* const a1b = p.c1 > 0 ? a1 + row_base * p.lda1 : a0b;
     const int a_records = (p.ablate & 2) ? 0 : 0x7FFFFFF0;      // timing experiment: a zero-record descriptor drops every A load
     auto rsrc_of = [](const void* ptr, const int records = 0x7FFFFFF0) {
         const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
@@ -252,21 +252,21 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
     for (int g = 0; g < 4; ++g) foff[g] = (unsigned)(((2 * g + fh) ^ fs) * 16);
     const char* Afr = smem + (wm * WM + fr) * ROWB;
     const char* Bfr = smem + A_BYTES + (wn * WN + fr) * ROWB;
-    bf16x8 af[2][TM], bfr[2][TN];
+    hx8<H> af[2][TM], bfr[2][TN];
     auto read_frags = [&](int set, int buf, int g) {
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
-            af[set][mi] = *reinterpret_cast<const bf16x8*>(Afr + buf * STAGE + mi * 32 * ROWB + foff[g]);
+            af[set][mi] = *reinterpret_cast<const hx8<H>*>(Afr + buf * STAGE + mi * 32 * ROWB + foff[g]);
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
-            bfr[set][ni] = *reinterpret_cast<const bf16x8*>(Bfr + buf * STAGE + ni * 32 * ROWB + foff[g]);
+            bfr[set][ni] = *reinterpret_cast<const hx8<H>*>(Bfr + buf * STAGE + ni * 32 * ROWB + foff[g]);
     };
     auto mma = [&](int set) {
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[set][ni], af[set][mi], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = mfma_32x32x16(bfr[set][ni], af[set][mi], acc[mi][ni]);
     };
 
     if constexpr (NST == 3 && LIN) {
@@ -432,7 +432,7 @@ __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, co
         float* __restrict__ out = p.out + (size_t)z * p.sout;
         igemm_epilogue<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane, reinterpret_cast<float*>(smem));
     } else {
-        __bf16* __restrict__ out = reinterpret_cast<__bf16*>(p.out) + (size_t)z * p.sout;
+        H* __restrict__ out = reinterpret_cast<H*>(p.out) + (size_t)z * p.sout;
         bgemm_epilogue_bf16<BM, TM, TN, WM, WN>(p, acc, out, bm, n0, wm, wn, lane, reinterpret_cast<float*>(smem));
     }
 }
@@ -474,7 +474,7 @@ __device__ __forceinline__ BgTile bgemm_decode(const IgemmArgs& p, const int x, 
     return t;
 }
 
-template <int BM, int WGM, bool LIN>
+template <typename H, int BM, int WGM, bool LIN>
 __device__ __forceinline__ void bgemm_pers_body(const IgemmArgs& p, char* smem, const int x, const int slot, const int nslots) {
     constexpr int BKE = 64, ROWB = 128, WGN = 2;
     constexpr bool PREFETCH = BM == 128;                      // next tile's first stage in flight under the epilogue
@@ -512,8 +512,8 @@ __device__ __forceinline__ void bgemm_pers_body(const IgemmArgs& p, char* smem, 
     const unsigned kc0 = (unsigned)(pp ^ (r8 >> 1));
     auto a_row = [&](const int i) { return 8 * (wave * APW + i) + r8; };
     auto a_kc = [&](const int i) { return kc0 ^ (unsigned)((((wave * APW + i) & 1)) << 2); };
-    const __bf16* i_a0b = nullptr;
-    const __bf16* i_a1b = nullptr;
+    const H* i_a0b = nullptr;
+    const H* i_a1b = nullptr;
     const char* i_w = nullptr;
     const unsigned* i_tab = tabs;
     int i_bpw = BPWM;
@@ -564,8 +564,8 @@ __device__ __forceinline__ void bgemm_pers_body(const IgemmArgs& p, char* smem, 
     auto aim = [&](const BgTile t, const int which) {
         const int z = p.batch > 1 ? t.rbg / p.nbm_per : 0;
         const int bm = t.rbg - z * p.nbm_per;
-        const __bf16* a0 = reinterpret_cast<const __bf16*>(p.a0) + (size_t)z * p.sa0;
-        const __bf16* a1 = reinterpret_cast<const __bf16*>(p.a1);
+        const H* a0 = reinterpret_cast<const H*>(p.a0) + (size_t)z * p.sa0;
+        const H* a1 = reinterpret_cast<const H*>(p.a1);
         i_w = reinterpret_cast<const char*>(p.w16) + ((size_t)z * p.sw + (size_t)t.n0 * p.ldw) * 2;
         const int img0 = p.taps == 1 ? 0 : (bm * BM) / hw_out;
         const size_t row_base = p.taps == 1 ? (size_t)bm * BM : (size_t)img0 * hw_in;
@@ -715,19 +715,19 @@ __device__ __forceinline__ void bgemm_pers_body(const IgemmArgs& p, char* smem, 
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-            bf16x8 af[2][TM], bfr[2][TN];
+            hx8<H> af[2][TM], bfr[2][TN];
             auto read_frags = [&](const int set, const int off, const int g) {
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi) af[set][mi] = *reinterpret_cast<const bf16x8*>(Afr + off + mi * 32 * ROWB + foff[g]);
+                for (int mi = 0; mi < TM; ++mi) af[set][mi] = *reinterpret_cast<const hx8<H>*>(Afr + off + mi * 32 * ROWB + foff[g]);
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni) bfr[set][ni] = *reinterpret_cast<const bf16x8*>(Bfr + off + ni * 32 * ROWB + foff[g]);
+                for (int ni = 0; ni < TN; ++ni) bfr[set][ni] = *reinterpret_cast<const hx8<H>*>(Bfr + off + ni * 32 * ROWB + foff[g]);
             };
             auto mma = [&](const int set) {
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[set][ni], af[set][mi], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = mfma_32x32x16(bfr[set][ni], af[set][mi], acc[mi][ni]);
             };
             const int z = c_z, bm = c_bm;
             read_frags(0, bo, 0);
@@ -761,7 +761,7 @@ __device__ __forceinline__ void bgemm_pers_body(const IgemmArgs& p, char* smem, 
             __builtin_amdgcn_s_barrier();                   // every wave is done reading the stage: it becomes the staging area
             __builtin_amdgcn_sched_barrier(0);
             mma(1);
-            BgEpilogue<BM, TM, TN, WM, WN, !LIN> epi;
+            BgEpilogue<H, BM, TM, TN, WM, WN, !LIN> epi;
             epi.prefetch(p, bm, cur.n0, wm, wn, lane);      // bias / residual loads: older than the DMA below in the vmcnt queue
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (PREFETCH) {
@@ -772,7 +772,7 @@ __device__ __forceinline__ void bgemm_pers_body(const IgemmArgs& p, char* smem, 
                 }
                 issue(bn);
                 __builtin_amdgcn_sched_barrier(0);
-                __bf16* __restrict__ out = reinterpret_cast<__bf16*>(p.out) + (size_t)z * p.sout;
+                H* __restrict__ out = reinterpret_cast<H*>(p.out) + (size_t)z * p.sout;
                 epi.finish(p, acc, out, bm, cur.n0, wm, wn, lane, reinterpret_cast<float*>(smem + bo) + wave * 32 * WN, brow, s_lo);
                 // finish() ends on a counted vmcnt: this wave's part of the next tile's stage 0 has landed, its stores have not
                 // been waited for
@@ -783,7 +783,7 @@ __device__ __forceinline__ void bgemm_pers_body(const IgemmArgs& p, char* smem, 
                 // 256-row tiles: eight waves stage 64 KB, more than one 48 KB stage buffer -- the staging area is both buffers and
                 // the next tile's first stage is fetched behind the epilogue (one exposed round trip per ~100 us tile); the
                 // workgroup still keeps its place, its next table is built and its stores are not waited for
-                __bf16* __restrict__ out = reinterpret_cast<__bf16*>(p.out) + (size_t)z * p.sout;
+                H* __restrict__ out = reinterpret_cast<H*>(p.out) + (size_t)z * p.sout;
                 epi.finish(p, acc, out, bm, cur.n0, wm, wn, lane, reinterpret_cast<float*>(smem) + wave * 32 * WN, brow, s_lo);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();               // staging reads done
@@ -813,17 +813,17 @@ __device__ __forceinline__ void bgemm_pers_body(const IgemmArgs& p, char* smem, 
 // 8-10 TB/s of L2 -> LDS traffic remain, because a 64-column wave panel re-reads A as often as 128 x 128 tiles re-read A and B.
 // DESIGN.md 3.5.)
 
-template <bool LIN>
+template <typename H, bool LIN>
 __global__ __launch_bounds__(256, 2) void bgemm_pers_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_bp[];
-    bgemm_pers_body<128, 2, LIN>(p, smem_bp, blockIdx.x & 7, blockIdx.x >> 3, gridDim.x >> 3);
+    bgemm_pers_body<H, 128, 2, LIN>(p, smem_bp, blockIdx.x & 7, blockIdx.x >> 3, gridDim.x >> 3);
 }
 
-// (bgemm_pers_body<256, 4, LIN> -- persistent 256-row tiles, 512 threads -- was built and measured bit-identical and +-0 % against
+// (bgemm_pers_body<H, 256, 4, LIN> -- persistent 256-row tiles, 512 threads -- was built and measured bit-identical and +-0 % against
 // bgemm256_kernel on every 3x3 conv of a B = 32 pass: a 256-row conv tile lives ~100 us, its launch and drain are noise.  Not
 // instantiated.)
 
-template <bool LIN>
+template <typename H, bool LIN>
 __global__ __launch_bounds__(256) void bgemm_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_bg[];
     const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
@@ -834,19 +834,19 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const IgemmArgs p) {
     const int n1 = (nrb - tail) * per1;
     if (loc < n1) {
         const int r = loc / per1, j = loc - r * per1;
-        if (j < p.w1) bgemm_tile<128, 128, 2, 2, 128 * 128 * 2, LIN>(p, rb_lo + r, j * 128, smem_bg);
-        else bgemm_tile<128, 64, 2, 2, 128 * 128 * 2, LIN>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_bg);
+        if (j < p.w1) bgemm_tile<H, 128, 128, 2, 2, 128 * 128 * 2, LIN>(p, rb_lo + r, j * 128, smem_bg);
+        else bgemm_tile<H, 128, 64, 2, 2, 128 * 128 * 2, LIN>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_bg);
     } else {
         const int t = loc - n1;
         if (t >= tail * p.s2) return;
         const int r = t / p.s2;
-        bgemm_tile<128, 64, 2, 2, 128 * 128 * 2, LIN>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_bg);
+        bgemm_tile<H, 128, 64, 2, 2, 128 * 128 * 2, LIN>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_bg);
     }
 }
 
 // 256-row tiles: 8 waves (4 x 2, the same 64 x 64 wave tile), 256 x 128 and 256 x 64, 48 KB stages, one workgroup per CU.
 #ifdef E2V_AB          // the two-stage form of the 256-row tile (E2V_BGEMM_S3 = 0): the other arm of the A/B that adopted the three-stage ring
-template <bool LIN>
+template <typename H, bool LIN>
 __global__ __launch_bounds__(512) void bgemm256_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_bg256[];
     constexpr int ST = (256 + 128) * 128;
@@ -858,13 +858,13 @@ __global__ __launch_bounds__(512) void bgemm256_kernel(const IgemmArgs p) {
     const int n1 = (nrb - tail) * per1;
     if (loc < n1) {
         const int r = loc / per1, j = loc - r * per1;
-        if (j < p.w1) bgemm_tile<256, 128, 4, 2, ST, LIN>(p, rb_lo + r, j * 128, smem_bg256);
-        else bgemm_tile<256, 64, 4, 2, ST, LIN>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_bg256);
+        if (j < p.w1) bgemm_tile<H, 256, 128, 4, 2, ST, LIN>(p, rb_lo + r, j * 128, smem_bg256);
+        else bgemm_tile<H, 256, 64, 4, 2, ST, LIN>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_bg256);
     } else {
         const int t = loc - n1;
         if (t >= tail * p.s2) return;
         const int r = t / p.s2;
-        bgemm_tile<256, 64, 4, 2, ST, LIN>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_bg256);
+        bgemm_tile<H, 256, 64, 4, 2, ST, LIN>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_bg256);
     }
 }
 #endif
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(512) void bgemm256_kernel(const IgemmArgs p) {
 // B = 32): with two stages in flight these kernels are not bound by what they fetch.  Removed)
 
 // the same with a three-stage ring (144 KB of stages + the gather table: all of a CU's LDS)
-template <bool LIN>
+template <typename H, bool LIN>
 __global__ __launch_bounds__(512) void bgemm256s3_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_bg256s3[];
     constexpr int ST = (256 + 128) * 128;
@@ -887,13 +887,13 @@ __global__ __launch_bounds__(512) void bgemm256s3_kernel(const IgemmArgs p) {
     const int n1 = (nrb - tail) * per1;
     if (loc < n1) {
         const int r = loc / per1, j = loc - r * per1;
-        if (j < p.w1) bgemm_tile<256, 128, 4, 2, ST, LIN, 3>(p, rb_lo + r, j * 128, smem_bg256s3);
-        else bgemm_tile<256, 64, 4, 2, ST, LIN, 3>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_bg256s3);
+        if (j < p.w1) bgemm_tile<H, 256, 128, 4, 2, ST, LIN, 3>(p, rb_lo + r, j * 128, smem_bg256s3);
+        else bgemm_tile<H, 256, 64, 4, 2, ST, LIN, 3>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_bg256s3);
     } else {
         const int t = loc - n1;
         if (t >= tail * p.s2) return;
         const int r = t / p.s2;
-        bgemm_tile<256, 64, 4, 2, ST, LIN, 3>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_bg256s3);
+        bgemm_tile<H, 256, 64, 4, 2, ST, LIN, 3>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_bg256s3);
     }
 }
 
@@ -923,7 +923,7 @@ bool bgemm_use_256(const IgemmArgs& a) {
 // Launches whose tiles are all 128 x 64 (N <= 64, grids below one round, and -- E2V_BGEMM_N64_MAXK -- short-K layers): 24 KB
 // stages, 53 KB of LDS per workgroup, so THREE workgroups share a CU.  A short-K tile (K = 320: five stages) spends most of its
 // life waiting for its first HBM bytes; a third resident workgroup is one more tile's worth of loads in flight per CU.
-template <bool LIN>
+template <typename H, bool LIN>
 __global__ __launch_bounds__(256) void bgemm_n64_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_bg64[];
     const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(256) void bgemm_n64_kernel(const IgemmArgs p) {
     const int nrb = rb_hi - rb_lo;
     if (loc >= nrb * p.s2) return;
     const int r = loc / p.s2;
-    bgemm_tile<128, 64, 2, 2, (128 + 64) * 128, LIN>(p, rb_lo + r, (loc - r * p.s2) * 64, smem_bg64);
+    bgemm_tile<H, 128, 64, 2, 2, (128 + 64) * 128, LIN>(p, rb_lo + r, (loc - r * p.s2) * 64, smem_bg64);
 }
 
 bool bgemm_all_n64(const IgemmArgs& a) {
@@ -941,20 +941,22 @@ bool bgemm_all_n64(const IgemmArgs& a) {
     return (a.c0 + a.c1) <= maxk && !a.geglu;
 }
 
+// launch KERNEL<H, LIN> for the launch's 16-bit type (IgemmArgs::a_bf16: bf16 / fp16) and gather path, opted into `bytes` of LDS
+#define E2V_BG_LAUNCH(KERNEL, grid, block, bytes)                                                                              \
+    h16_dispatch(a.a_bf16, [&](auto h16_tag) {                                                                                 \
+        using H = decltype(h16_tag);                                                                                           \
+        if (lin) { E2V_KATTR((&KERNEL<H, true>), bytes); E2V_KLAUNCH((KERNEL<H, true>), grid, block, bytes, s, a); }           \
+        else { E2V_KATTR((&KERNEL<H, false>), bytes); E2V_KLAUNCH((KERNEL<H, false>), grid, block, bytes, s, a); }             \
+    })
+
 void bgemm_launch(const IgemmArgs& a_in, int ntiles, hipStream_t s) {
     IgemmArgs a = a_in;
     constexpr size_t smem = (size_t)2 * 128 * 128 * 2 + 9 * 128 * sizeof(unsigned);     // two stages of (128 + 128) rows + gather table
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        configured = true;
-    }
     static const int* const lean = E2V_AB_KNOB("E2V_BGEMM_LIN", 1);        // 0: linears through the gather path
     const bool lin = a.taps == 1 && *lean;
     const double K = (double)a.taps * (a.c0 + a.c1);
     const double rows_in = a.taps == 1 ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
-    std::string pname = "igemm_bf16";
+    std::string pname = a.a_bf16 == H16_FP16 ? "igemm_fp16" : "igemm_bf16";
     if (prof_detail())
         pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t" + std::to_string(a.taps) +
                  (a.stride > 1 ? " s2" : "") + (a.upsample ? " up" : "") + (a.c1 ? " cat" : "") + (a.geglu ? " geglu" : "") +
@@ -980,44 +982,23 @@ void bgemm_launch(const IgemmArgs& a_in, int ntiles, hipStream_t s) {
     // (an fp32 residual, or time-embedding rows of more than two samples under one tile -- toy sizes -- take the kernels below)
     if (pers && !a.out_f32 && !a.bm256 && !(a.resid && !a.resid_bf16) && !(a.rowbias && (lin || a.rows_per_sample < 128))) {
         constexpr size_t smem_p = (size_t)2 * 128 * 128 * 2 + 2 * 9 * 128 * sizeof(unsigned) + 3 * 128 * sizeof(float);   // stages, tables, bias rows
-        static bool cfgp = false;
-        if (!cfgp) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_pers_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_pers_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
-            cfgp = true;
-        }
         const int grid = ntiles < 512 ? ntiles : 512;                                             // two workgroups per CU
         dry_tag(" -> bgemm_pers_kernel 128x128");
-        if (lin) E2V_KLAUNCH(bgemm_pers_kernel<true>, dim3(grid, 1, 1), dim3(256), smem_p, s, a);
-        else E2V_KLAUNCH(bgemm_pers_kernel<false>, dim3(grid, 1, 1), dim3(256), smem_p, s, a);
+        E2V_BG_LAUNCH(bgemm_pers_kernel, dim3(grid, 1, 1), dim3(256), smem_p);
         return;
     }
     static const int* const s3p = E2V_AB_KNOB("E2V_BGEMM_S3", 1);          // 256-row tiles on a three-stage ring
     if (a.bm256 && *s3p && (a.taps == 9 || lin)) {
         constexpr size_t smem256s3 = (size_t)3 * (256 + 128) * 128 + 9 * 256 * sizeof(unsigned);
-        static bool cfg256s3 = false;
-        if (!cfg256s3) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm256s3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem256s3);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm256s3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem256s3);
-            cfg256s3 = true;
-        }
         dry_tag(" -> bgemm256s3_kernel 256x128");
-        if (lin) E2V_KLAUNCH(bgemm256s3_kernel<true>, dim3(ntiles, 1, 1), dim3(512), smem256s3, s, a);
-        else E2V_KLAUNCH(bgemm256s3_kernel<false>, dim3(ntiles, 1, 1), dim3(512), smem256s3, s, a);
+        E2V_BG_LAUNCH(bgemm256s3_kernel, dim3(ntiles, 1, 1), dim3(512), smem256s3);
         return;
     }
 #ifdef E2V_AB
     if (a.bm256) {
         constexpr size_t smem256 = (size_t)2 * (256 + 128) * 128 + 9 * 256 * sizeof(unsigned);
-        static bool cfg256 = false;
-        if (!cfg256) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem256);
-            cfg256 = true;
-        }
         dry_tag(" -> bgemm256_kernel 256x128");
-        if (lin) E2V_KLAUNCH(bgemm256_kernel<true>, dim3(ntiles, 1, 1), dim3(512), smem256, s, a);
-        else E2V_KLAUNCH(bgemm256_kernel<false>, dim3(ntiles, 1, 1), dim3(512), smem256, s, a);
+        E2V_BG_LAUNCH(bgemm256_kernel, dim3(ntiles, 1, 1), dim3(512), smem256);
         return;
     }
 #else
@@ -1025,25 +1006,17 @@ void bgemm_launch(const IgemmArgs& a_in, int ntiles, hipStream_t s) {
 #endif
     if (a.rb1 == 0 && !a.geglu) {          // every row block is cut into 128 x 64 tiles only
         constexpr size_t smem64 = (size_t)2 * (128 + 64) * 128 + 9 * 128 * sizeof(unsigned);
-        static bool cfg64 = false;
-        if (!cfg64) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_n64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_n64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64);
-            cfg64 = true;
-        }
         int nt = 0;
         for (int x = 0; x < 8; ++x) {
             const int nrb = (int)(((long)(x + 1) * a.nbm) >> 3) - (int)(((long)x * a.nbm) >> 3);
             nt = nrb * a.s2 > nt ? nrb * a.s2 : nt;
         }
         dry_tag(" -> bgemm_n64_kernel 128x64");
-        if (lin) E2V_KLAUNCH(bgemm_n64_kernel<true>, dim3(nt * 8, 1, 1), dim3(256), smem64, s, a);
-        else E2V_KLAUNCH(bgemm_n64_kernel<false>, dim3(nt * 8, 1, 1), dim3(256), smem64, s, a);
+        E2V_BG_LAUNCH(bgemm_n64_kernel, dim3(nt * 8, 1, 1), dim3(256), smem64);
         return;
     }
     dry_tag(" -> bgemm_kernel 128x128" + std::string(a.rb1 < a.nbm ? "+128x64" : ""));
-    if (lin) E2V_KLAUNCH(bgemm_kernel<true>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
-    else E2V_KLAUNCH(bgemm_kernel<false>, dim3(ntiles, 1, 1), dim3(256), smem, s, a);
+    E2V_BG_LAUNCH(bgemm_kernel, dim3(ntiles, 1, 1), dim3(256), smem);
 }
 
 }  // namespace e2v

@@ -48,7 +48,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t t256_rsrc(const void* ptr, con
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0, records, 0x00020000);
 }
 
-template <int NT, bool LIN, bool RB = false>      // RB: the launch leaves row-block sums for a following GroupNorm (IgemmArgs::rbsum)
+template <typename H, int NT, bool LIN, bool RB = false>      // RB: the launch leaves row-block sums for a following GroupNorm (IgemmArgs::rbsum)
 __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, const int col_off) {
     constexpr int BM = 256, WN = 16 * NT, BN = 4 * WN;
     constexpr int N0 = (NT + 1) / 2, N1 = NT / 2;            // column tiles of a wave: first group (phases 0, 3), second group (phases 1, 2)
@@ -107,8 +107,8 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
     unsigned x_off[NXO];                                     // conv: pixel index (20 bits) | tap mask << 20
     const int hw_out = p.Ho * p.Wo, hw_in = p.Hs * p.Ws;
     const int img0 = LIN ? 0 : (bm * BM) / hw_out;
-    const __bf16* const a0 = reinterpret_cast<const __bf16*>(p.a0);
-    const __bf16* const a1 = reinterpret_cast<const __bf16*>(p.a1);
+    const H* const a0 = reinterpret_cast<const H*>(p.a0);
+    const H* const a1 = reinterpret_cast<const H*>(p.a1);
     const int kw = p.kw, pad_x = p.pad_x < 0 ? p.pad : p.pad_x;       // (3x3: kw = 3, pad_x = pad; the sub-pixel 2x2 kernels: see bgemm_up2x)
     const long xrow0 = LIN ? (long)bm * BM : (long)img0 * hw_in - (long)(p.pad * p.Ws + pad_x);
     const int xrows = min(BM, p.M - bm * BM);                // valid rows of this tile
@@ -143,7 +143,7 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
     x_setup(ld2);
     bool x_live = true;
     auto x_rsrc = [&]() {
-        const __bf16* base = (k_src ? a1 : a0) + xrow0 * (long)(k_src ? p.lda1 : p.lda0);
+        const H* base = (k_src ? a1 : a0) + xrow0 * (long)(k_src ? p.lda1 : p.lda0);
         return t256_rsrc(base, !x_live ? 0 : LIN ? (int)((unsigned)xrows * ld2) : 0x7FFFFFF0);
     };
     __amdgpu_buffer_rsrc_t rx = x_rsrc();
@@ -208,7 +208,7 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
     // LDS addresses of the fragment reads: per (buffer, 32-deep k step) ONE base register for X and one for W, every tile an immediate
     // offset below 64 KB.  (Made opaque to the compiler: with the second buffer beyond the 16-bit offset field it otherwise
     // materialises one address per read, parks them in scratch and reloads them -- behind vmcnt(0) -- in the loop.)
-    typedef __attribute__((address_space(3))) const bf16x8* lds_frag;
+    typedef __attribute__((address_space(3))) const hx8<H>* lds_frag;
     typedef __attribute__((address_space(3))) const char* lds_cptr;
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_cptr)smem;
     unsigned xa[2], wa[2];
@@ -218,7 +218,7 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
     wa[1] = lds0 + WREG + (wc * WN + fl) * ROWB + fo1;
     asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(wa[0]), "+v"(wa[1]));
     auto ldsf = [](const unsigned addr) { return *(lds_frag)(lds_cptr)(unsigned long long)addr; };
-    bf16x8 xf[4][2], wf0[N0][2], wf1[N1][2];
+    hx8<H> xf[4][2], wf0[N0][2], wf1[N1][2];
     f32x4v acc[2][4][NT];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -256,7 +256,7 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < N0; ++nt)
-                    acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt][ks], xf[mt][ks], acc[half][mt][nt], 0, 0, 0);
+                    acc[half][mt][nt] = mfma_16x16x32(wf0[nt][ks], xf[mt][ks], acc[half][mt][nt]);
         __builtin_amdgcn_s_setprio(0);
     };
     auto mma1 = [&](const int half) {                        // quadrant (half, second column group)
@@ -267,7 +267,7 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < N1; ++nt)
-                    acc[half][mt][N0 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt][ks], xf[mt][ks], acc[half][mt][N0 + nt], 0, 0, 0);
+                    acc[half][mt][N0 + nt] = mfma_16x16x32(wf1[nt][ks], xf[mt][ks], acc[half][mt][N0 + nt]);
         __builtin_amdgcn_s_setprio(0);
     };
     // the two halves of a phase: [reads + DMA of this wave] | barrier | [MFMAs of this wave] | barrier; the fragment reads are
@@ -395,7 +395,7 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
             const int r = orow + it * rpi;
             pfr[set][it] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (pf_resid && lane_on && r < 32 && m0 + r < p.M)
-                pfr[set][it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(p.resid) + out_row(m0 + r) * p.ldr + nn);      // 8 bf16, raw
+                pfr[set][it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const H*>(p.resid) + out_row(m0 + r) * p.ldr + nn);      // 8 bf16, raw
         }
         // one time-embedding row for the chunk if its first and last row belong to the same sample (wave-uniform test)
         const int m_last = min(m0 + 31, p.M - 1);
@@ -423,7 +423,7 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
                         f32x4 y;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            y[e] = (acc[h][mt][nt][e] * p.alpha + bv[e]) * gelu_bf16_grade(acc[h][mt][nt + 2][e] * p.alpha + bg[e]);
+                            y[e] = (acc[h][mt][nt][e] * p.alpha + bv[e]) * gelu_gate16<H>(acc[h][mt][nt + 2][e] * p.alpha + bg[e]);
                         *reinterpret_cast<f32x4*>(st + (t * 16 + fl) * SLD + nt * 16 + 4 * fq) = y;
                     }
                 }
@@ -460,12 +460,12 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
                     y1 += *reinterpret_cast<const f32x4*>(rb + 4);
                 }
                 if (pf_resid) {
-                    const bf16x8 rr = __builtin_bit_cast(bf16x8, pfr[set][it]);
+                    const hx8<H> rr = __builtin_bit_cast(hx8<H>, pfr[set][it]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { y0[e] += (float)rr[e]; y1[e] += (float)rr[4 + e]; }
                 } else if (p.resid) {
                     if (p.resid_bf16) {
-                        const bf16x8 rr = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.resid) + orw * p.ldr + nn);
+                        const hx8<H> rr = *reinterpret_cast<const hx8<H>*>(reinterpret_cast<const H*>(p.resid) + orw * p.ldr + nn);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { y0[e] += (float)rr[e]; y1[e] += (float)rr[4 + e]; }
                     } else {
@@ -483,10 +483,10 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
                 *reinterpret_cast<f32x4*>(o) = y0;
                 *reinterpret_cast<f32x4*>(o + 4) = y1;
             } else {
-                bf16x8 o;
+                hx8<H> o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y0[e]; o[4 + e] = (__bf16)y1[e]; }
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + orw * p.ldc + nn) = o;
+                for (int e = 0; e < 4; ++e) { o[e] = (H)y0[e]; o[4 + e] = (H)y1[e]; }
+                *reinterpret_cast<hx8<H>*>(reinterpret_cast<H*>(p.out) + orw * p.ldc + nn) = o;
             }
         }
     };
@@ -519,20 +519,20 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
         const int nn2 = n0 + wc * WN + ocol2;
         const bool on2 = orow2 < rpi2 && nn2 < p.N;
         float* const rbl = reinterpret_cast<float*>(smem) + wave * 32 * SLD + l2 * 16;   // inside the wave's OWN staging block (dead now; the other waves' may not be)
-        const __bf16* const outp = reinterpret_cast<const __bf16*>(p.out);
+        const H* const outp = reinterpret_cast<const H*>(p.out);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x4 hs0 = {0.f, 0.f, 0.f, 0.f}, hs1 = hs0, hq0 = hs0, hq1 = hs0;
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 const int m0 = bm * BM + wr * 128 + half * 64 + cc * 32;
-                bf16x8 v[ITER_N];
+                hx8<H> v[ITER_N];
 #pragma unroll
                 for (int it = 0; it < ITER_N; ++it) {
                     const int r = orow2 + it * rpi2;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[it][e] = (__bf16)0.f;
-                    if (on2 && r < 32 && m0 + r < p.M) v[it] = *reinterpret_cast<const bf16x8*>(outp + (size_t)(m0 + r) * p.ldc + nn2);
+                    for (int e = 0; e < 8; ++e) v[it][e] = (H)0.f;
+                    if (on2 && r < 32 && m0 + r < p.M) v[it] = *reinterpret_cast<const hx8<H>*>(outp + (size_t)(m0 + r) * p.ldc + nn2);
                 }
                 f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, q0 = s0, q1 = s0;
 #pragma unroll
@@ -576,20 +576,20 @@ __device__ __forceinline__ void t256_body(const IgemmArgs& p, const int vblock, 
     }
 }
 
-template <int NT, bool LIN, bool RB = false>
+template <typename H, int NT, bool LIN, bool RB = false>
 __global__ __launch_bounds__(512) void bgemm_t256_kernel(const IgemmArgs p) {
-    t256_body<NT, LIN, RB>(p, blockIdx.x, p.col_off);
+    t256_body<H, NT, LIN, RB>(p, blockIdx.x, p.col_off);
 }
 
 #ifdef E2V_AB          // measured, not adopted
 // The tail split's two tile widths in ONE launch (two launches on a stream run one after the other, each a third of the chip):
 // groups of eight workgroups alternate between 256 x 192 tiles at column offset col_off and 256 x 128 tiles at col_off2; the low
 // three bits of the block index -- the XCD -- stay what they are.
-template <bool LIN>
+template <typename H, bool LIN>
 __global__ __launch_bounds__(512) void bgemm_t256_tail_kernel(const IgemmArgs p) {
     const int vblock = (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7));
-    if ((blockIdx.x >> 3) & 1) t256_body<2, LIN>(p, vblock, p.col_off2);
-    else t256_body<3, LIN>(p, vblock, p.col_off);
+    if ((blockIdx.x >> 3) & 1) t256_body<H, 2, LIN>(p, vblock, p.col_off2);
+    else t256_body<H, 3, LIN>(p, vblock, p.col_off);
 }
 #endif
 
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(512) void bgemm_t256_tail_kernel(const IgemmArgs p)
 // epilogue reads it from there.  As buffer loads at the head of the epilogue the NT bias quads were the youngest entries of the wave's
 // in-order memory queue: waiting for them drained the DMA of the next tile's first K steps (~0.7 us per tile; the residual-free
 // K = 320 / 640 projections -- QKV, GEGLU -- have no other load there).
-template <int NT, bool GEGLU, bool F32IO, bool BLDS>      // F32IO: fp32 output and residual (the op-level test entry points); else bf16 (the graph)
+template <typename H, int NT, bool GEGLU, bool F32IO, bool BLDS>      // F32IO: fp32 output and residual (the op-level test entry points); else bf16 (the graph)
 __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
     constexpr int BM = 256, WN = 16 * NT, BN = 4 * WN;
     constexpr int N0 = (NT + 1) / 2, N1 = NT / 2;
@@ -642,8 +642,8 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
     const unsigned ldw2 = (unsigned)p.ldw * 2u;
     const unsigned w_off = (unsigned)(wb + r8) * ldw2 + (unsigned)((pp ^ (((wb + r8) >> 1) & 7)) * 16);
     const unsigned x_kcb = (unsigned)((pp ^ (((xb + r8) >> 1) & 7)) * 16);
-    const __bf16* const a0 = reinterpret_cast<const __bf16*>(p.a0);
-    const __bf16* const a1 = reinterpret_cast<const __bf16*>(p.a1);
+    const H* const a0 = reinterpret_cast<const H*>(p.a0);
+    const H* const a1 = reinterpret_cast<const H*>(p.a1);
 
     // ---- issue side: an X cursor and a W cursor, each (tile, K step), running up to two K steps ahead of the compute side and
     // across tile boundaries; past the XCD's last tile they fetch through zero-record descriptors (zeros into rows nobody reads)
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
         const int bm = rb_lo + xt / nct;
         const bool live = xt < ntx;
         const int rows = live ? min(BM, p.M - bm * BM) : 0;
-        const __bf16* base = (x_src ? a1 : a0) + (live ? (long)bm * BM * (x_src ? p.lda1 : p.lda0) : 0L);
+        const H* base = (x_src ? a1 : a0) + (live ? (long)bm * BM * (x_src ? p.lda1 : p.lda0) : 0L);
         return t256_rsrc(base, (int)((unsigned)rows * ld2));
     };
     __amdgpu_buffer_rsrc_t rx = x_rsrc();
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
     const int fl = lane & 15, fq = lane >> 4;
     const int fsw = (fl >> 1) & 7;
     const unsigned fo0 = (unsigned)(((0 + fq) ^ fsw) * 16), fo1 = (unsigned)(((4 + fq) ^ fsw) * 16);
-    typedef __attribute__((address_space(3))) const bf16x8* lds_frag;
+    typedef __attribute__((address_space(3))) const hx8<H>* lds_frag;
     typedef __attribute__((address_space(3))) const char* lds_cptr;
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_cptr)smem;
     unsigned xa[2], wa[2];
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
     wa[1] = lds0 + WREG + (wc * WN + fl) * ROWB + fo1;
     asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(wa[0]), "+v"(wa[1]));
     auto ldsf = [](const unsigned addr) { return *(lds_frag)(lds_cptr)(unsigned long long)addr; };
-    bf16x8 xf[4][2], wf0[N0][2], wf1[N1][2];
+    hx8<H> xf[4][2], wf0[N0][2], wf1[N1][2];
     f32x4v acc[2][4][NT];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < N0; ++nt)
-                    acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt][ks], xf[mt][ks], (FIRST && ks == 0) ? zero4 : acc[half][mt][nt], 0, 0, 0);
+                    acc[half][mt][nt] = mfma_16x16x32(wf0[nt][ks], xf[mt][ks], (FIRST && ks == 0) ? zero4 : acc[half][mt][nt]);
         __builtin_amdgcn_s_setprio(0);
     };
     auto mma1 = [&](const int half, auto firstc) {
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < N1; ++nt)
-                    acc[half][mt][N0 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt][ks], xf[mt][ks], (FIRST && ks == 0) ? zero4 : acc[half][mt][N0 + nt], 0, 0, 0);
+                    acc[half][mt][N0 + nt] = mfma_16x16x32(wf1[nt][ks], xf[mt][ks], (FIRST && ks == 0) ? zero4 : acc[half][mt][N0 + nt]);
         __builtin_amdgcn_s_setprio(0);
     };
     auto phase_sync_a = [&]() {
@@ -860,9 +860,9 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
         const unsigned vop0 = ((unsigned)(wr * 128 + fl) * p.ldc + ocol0 + (fq & 1) * 16 + (fq >> 1) * 8) * 2u;
         const unsigned vrp0 = ((unsigned)(wr * 128 + fl) * p.ldr + n0 + wc * WN + (fq & 1) * 16 + (fq >> 1) * 8) * 2u;      // the residual, paired likewise
         auto store_pair = [&](const f32x4 ya, const f32x4 yb, const unsigned vop, const int nt) {      // tiles nt, nt + 1 (bf16 output)
-            bf16x4 oa, ob;
+            hx4<H> oa, ob;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { oa[e] = (__bf16)ya[e]; ob[e] = (__bf16)yb[e]; }
+            for (int e = 0; e < 4; ++e) { oa[e] = (H)ya[e]; ob[e] = (H)yb[e]; }
             u32x2 a = __builtin_bit_cast(u32x2, oa), b = __builtin_bit_cast(u32x2, ob);
             unsigned a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
             asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
@@ -873,9 +873,9 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
             if constexpr (F32IO) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, vo, (unsigned)(nt * 16) * 4u, 0);
             } else {
-                bf16x4 o;
+                hx4<H> o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (__bf16)y[e];
+                for (int e = 0; e < 4; ++e) o[e] = (H)y[e];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ro, vo, (unsigned)(nt * 16) * 2u, 0);
             }
         };
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            yg[nt][e] = (acc[h][mt][nt][e] * p.alpha + bias[nt][e]) * gelu_bf16_grade(acc[h][mt][nt + 2][e] * p.alpha + bias[nt + 2][e]);
+                            yg[nt][e] = (acc[h][mt][nt][e] * p.alpha + bias[nt][e]) * gelu_gate16<H>(acc[h][mt][nt + 2][e] * p.alpha + bias[nt + 2][e]);
                     if constexpr (F32IO) { store4(yg[0], vo, 0); store4(yg[1], vo, 1); }
                     else store_pair(yg[0], yg[1], vop0 + (unsigned)(h * 64 + mt * 16) * p.ldc * 2u, 0);
                     __builtin_amdgcn_sched_barrier(0);       // one (half, row tile) at a time
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 f32x4 res[4][NT];
-                bf16x4 rb4[4][NT];
+                hx4<H> rb4[4][NT];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const unsigned vr = vr0 + (unsigned)(h * 64 + mt * 16) * p.ldr * osz;
@@ -915,10 +915,10 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
                         } else if constexpr (F32IO) res[mt][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, vr, (unsigned)(nt * 16) * 4u, 0));
                         else if ((nt & 1) == 0 && nt + 1 < NT) {      // two adjacent tiles: 16 bytes per lane (channels 8 (fq >> 1) .. + 7 of tile nt + (fq & 1)), un-paired below
                             const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(rr, vrp0 + (unsigned)(h * 64 + mt * 16) * p.ldr * 2u, (unsigned)(nt * 16) * 2u, 0);
-                            rb4[mt][nt] = __builtin_bit_cast(bf16x4, u32x2{l[0], l[1]});
-                            rb4[mt][nt + 1] = __builtin_bit_cast(bf16x4, u32x2{l[2], l[3]});
+                            rb4[mt][nt] = __builtin_bit_cast(hx4<H>, u32x2{l[0], l[1]});
+                            rb4[mt][nt + 1] = __builtin_bit_cast(hx4<H>, u32x2{l[2], l[3]});
                         } else if (nt == NT - 1 && (NT & 1)) {
-                            rb4[mt][nt] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rr, vr, (unsigned)(nt * 16) * 2u, 0));
+                            rb4[mt][nt] = __builtin_bit_cast(hx4<H>, __builtin_amdgcn_raw_buffer_load_b64(rr, vr, (unsigned)(nt * 16) * 2u, 0));
                         }
                     }
                     if constexpr (F32IO) __builtin_amdgcn_sched_barrier(0);      // (fp32 residual, test entry points: 16 dwords per row tile, one row tile at a time)
@@ -952,8 +952,8 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
                             u32x2 a = __builtin_bit_cast(u32x2, rb4[mt][nt]), b = __builtin_bit_cast(u32x2, rb4[mt][nt + 1]);
                             unsigned l0 = a[0], l1 = a[1], l2 = b[0], l3 = b[1];
                             asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(l0), "+v"(l2), "+v"(l1), "+v"(l3));
-                            rb4[mt][nt] = __builtin_bit_cast(bf16x4, u32x2{l0, l1});
-                            rb4[mt][nt + 1] = __builtin_bit_cast(bf16x4, u32x2{l2, l3});
+                            rb4[mt][nt] = __builtin_bit_cast(hx4<H>, u32x2{l0, l1});
+                            rb4[mt][nt + 1] = __builtin_bit_cast(hx4<H>, u32x2{l2, l3});
                         }
                         f32x4 y[NT];
 #pragma unroll
@@ -1061,69 +1061,64 @@ static void t256_launch_part(IgemmArgs a, const int cols, const int rb0, const i
     const size_t smem = (size_t)2 * (256 + 64 * (nt == 0 ? 3 : nt)) * 128;
     const bool lin = a.taps == 1;
     if (nt == 0) a.col_off2 = col_off + 192;
-    auto go = [&](auto kern) {
-        static bool cfg = false;
-        if (!cfg) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * (256 + 320) * 128));
-            cfg = true;
+    h16_dispatch(a.a_bf16, [&](auto h16_tag) {          // the launch's 16-bit type: bf16 / fp16 instances of the same kernels
+        using H = decltype(h16_tag);
+        auto go = [&](auto kern) {
+            E2V_KATTR(kern, ((size_t)2 * (256 + 320) * 128));
+            E2V_KLAUNCH(kern, dim3(grid), dim3(512), smem, s, a);
+        };
+        // linears: the persistent form (E2V_BGEMM_T256P: 0 never, 2 every linear, 1 launches of at least E2V_BGEMM_T256P_MINTILES tiles).
+        // Same-box A/B over the linears of a B = 32 UNet step (tools/shape_ab.py): with the first register epilogue (8-byte stores, the
+        // residual fetched one 16-row tile at a time) only the GEGLU projections and the K >= 1280 ones with a residual gained
+        // (profiles/r03_shape_ab_t256p.log); with 16-byte paired stores and the residual of a half requested at once
+        // (profiles/r03_shape_ab_t256p_epilogue.log) every linear of >= 256 tiles does: 640 -> 640 with a residual -10 %, 320 -> 960 -6 %,
+        // 320 -> 320 -3 % against bgemm.hip's persistent 128-row kernel, which the K <= 640 projections with a residual used to stay on.
+        static const int* const persp = knob("E2V_BGEMM_T256P", 1);
+        static const int* const pmaxk = knob("E2V_BGEMM_T256P_MAXK", 1 << 30);
+        static const int* const pmint = knob("E2V_BGEMM_T256P_MINTILES", 256);
+        const long ntiles = (long)a.nbm * nct;
+        // (the epilogue reads the residual in the output's type: fp32 with fp32 at the test entry points, bf16 with bf16 in the graph)
+        const bool io_ok = !a.resid || (a.out_f32 ? !a.resid_bf16 : a.resid_bf16 != 0);
+        // (the persistent epilogue adds no per-sample row bias: such a launch -- none in the graph today -- stays on the tile kernel)
+        if (allow_persistent && lin && io_ok && !a.rowbias && !a.rbsum && *persp && (*persp == 2 || (a.c0 + a.c1 <= *pmaxk && ntiles >= *pmint))) {
+            // bias in LDS where it fits behind the operand buffers (160 KB per CU) and the epilogue loads nothing else (no residual)
+            static const int* const bldsp = knob("E2V_BGEMM_T256P_BIAS_LDS", 1);
+            const bool blds = *bldsp && !a.resid && smem + (size_t)a.N * 4 <= (size_t)160 * 1024;      // (no bias: the LDS copy is zeros)
+            auto gop = [&](auto kern) {
+                E2V_KATTR(kern, 160 * 1024);
+                const int per = per_xcd * nct;                   // tiles of the largest XCD share
+                const int slots = per < 32 ? per : 32;
+                dry_tag(std::string(" -> bgemm_t256p_kernel 256x") + std::to_string(cols) + (blds ? " bias-lds" : ""));
+                E2V_KLAUNCH(kern, dim3(8 * slots), dim3(512), smem + (blds ? (size_t)a.N * 4 : (size_t)0), s, a);
+            };
+            const bool f32io = a.out_f32 != 0;
+            auto pick = [&](auto ntc, auto gc) {
+                constexpr int NTc = decltype(ntc)::value;
+                constexpr bool Gc = decltype(gc)::value;
+                if (f32io) { if (blds) gop(bgemm_t256p_kernel<H, NTc, Gc, true, true>); else gop(bgemm_t256p_kernel<H, NTc, Gc, true, false>); }
+                else       { if (blds) gop(bgemm_t256p_kernel<H, NTc, Gc, false, true>); else gop(bgemm_t256p_kernel<H, NTc, Gc, false, false>); }
+            };
+            if (cols == 320) pick(std::integral_constant<int, 5>{}, std::false_type{});
+            else if (a.geglu) pick(std::integral_constant<int, 4>{}, std::true_type{});
+            else pick(std::integral_constant<int, 4>{}, std::false_type{});
+            return;
         }
-        E2V_KLAUNCH(kern, dim3(grid), dim3(512), smem, s, a);
-    };
-    // linears: the persistent form (E2V_BGEMM_T256P: 0 never, 2 every linear, 1 launches of at least E2V_BGEMM_T256P_MINTILES tiles).
-    // Same-box A/B over the linears of a B = 32 UNet step (tools/shape_ab.py): with the first register epilogue (8-byte stores, the
-    // residual fetched one 16-row tile at a time) only the GEGLU projections and the K >= 1280 ones with a residual gained
-    // (profiles/r03_shape_ab_t256p.log); with 16-byte paired stores and the residual of a half requested at once
-    // (profiles/r03_shape_ab_t256p_epilogue.log) every linear of >= 256 tiles does: 640 -> 640 with a residual -10 %, 320 -> 960 -6 %,
-    // 320 -> 320 -3 % against bgemm.hip's persistent 128-row kernel, which the K <= 640 projections with a residual used to stay on.
-    static const int* const persp = knob("E2V_BGEMM_T256P", 1);
-    static const int* const pmaxk = knob("E2V_BGEMM_T256P_MAXK", 1 << 30);
-    static const int* const pmint = knob("E2V_BGEMM_T256P_MINTILES", 256);
-    const long ntiles = (long)a.nbm * nct;
-    // (the epilogue reads the residual in the output's type: fp32 with fp32 at the test entry points, bf16 with bf16 in the graph)
-    const bool io_ok = !a.resid || (a.out_f32 ? !a.resid_bf16 : a.resid_bf16 != 0);
-    // (the persistent epilogue adds no per-sample row bias: such a launch -- none in the graph today -- stays on the tile kernel)
-    if (allow_persistent && lin && io_ok && !a.rowbias && !a.rbsum && *persp && (*persp == 2 || (a.c0 + a.c1 <= *pmaxk && ntiles >= *pmint))) {
-        // bias in LDS where it fits behind the operand buffers (160 KB per CU) and the epilogue loads nothing else (no residual)
-        static const int* const bldsp = knob("E2V_BGEMM_T256P_BIAS_LDS", 1);
-        const bool blds = *bldsp && !a.resid && smem + (size_t)a.N * 4 <= (size_t)160 * 1024;      // (no bias: the LDS copy is zeros)
-        auto gop = [&](auto kern) {
-            static bool cfg = false;
-            if (!cfg) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                cfg = true;
-            }
-            const int per = per_xcd * nct;                   // tiles of the largest XCD share
-            const int slots = per < 32 ? per : 32;
-            dry_tag(std::string(" -> bgemm_t256p_kernel 256x") + std::to_string(cols) + (blds ? " bias-lds" : ""));
-            E2V_KLAUNCH(kern, dim3(8 * slots), dim3(512), smem + (blds ? (size_t)a.N * 4 : (size_t)0), s, a);
-        };
-        const bool f32io = a.out_f32 != 0;
-        auto pick = [&](auto ntc, auto gc) {
-            constexpr int NTc = decltype(ntc)::value;
-            constexpr bool Gc = decltype(gc)::value;
-            if (f32io) { if (blds) gop(bgemm_t256p_kernel<NTc, Gc, true, true>); else gop(bgemm_t256p_kernel<NTc, Gc, true, false>); }
-            else       { if (blds) gop(bgemm_t256p_kernel<NTc, Gc, false, true>); else gop(bgemm_t256p_kernel<NTc, Gc, false, false>); }
-        };
-        if (cols == 320) pick(std::integral_constant<int, 5>{}, std::false_type{});
-        else if (a.geglu) pick(std::integral_constant<int, 4>{}, std::true_type{});
-        else pick(std::integral_constant<int, 4>{}, std::false_type{});
-        return;
-    }
-    dry_tag(nt == 0 ? std::string(" -> bgemm_t256_tail_kernel 256x192+256x128") : std::string(" -> bgemm_t256_kernel 256x") + std::to_string(64 * nt));
-    switch (nt) {
+        dry_tag(nt == 0 ? std::string(" -> bgemm_t256_tail_kernel 256x192+256x128") : std::string(" -> bgemm_t256_kernel 256x") + std::to_string(64 * nt));
+        switch (nt) {
 #ifdef E2V_AB              // (the instances that leave row-block sums: measured and not adopted)
-        case 5: if (lin) go(bgemm_t256_kernel<5, true>); else if (a.rbsum) go(bgemm_t256_kernel<5, false, true>); else go(bgemm_t256_kernel<5, false>); break;
-        case 4: if (lin) go(bgemm_t256_kernel<4, true>); else if (a.rbsum) go(bgemm_t256_kernel<4, false, true>); else go(bgemm_t256_kernel<4, false>); break;
+            case 5: if (lin) go(bgemm_t256_kernel<H, 5, true>); else if (a.rbsum) go(bgemm_t256_kernel<H, 5, false, true>); else go(bgemm_t256_kernel<H, 5, false>); break;
+            case 4: if (lin) go(bgemm_t256_kernel<H, 4, true>); else if (a.rbsum) go(bgemm_t256_kernel<H, 4, false, true>); else go(bgemm_t256_kernel<H, 4, false>); break;
 #else
-        case 5: if (lin) go(bgemm_t256_kernel<5, true>); else go(bgemm_t256_kernel<5, false>); break;
-        case 4: if (lin) go(bgemm_t256_kernel<4, true>); else go(bgemm_t256_kernel<4, false>); break;
+            case 5: if (lin) go(bgemm_t256_kernel<H, 5, true>); else go(bgemm_t256_kernel<H, 5, false>); break;
+            case 4: if (lin) go(bgemm_t256_kernel<H, 4, true>); else go(bgemm_t256_kernel<H, 4, false>); break;
 #endif
 #ifdef E2V_AB
-        default: if (lin) go(bgemm_t256_tail_kernel<true>); else go(bgemm_t256_tail_kernel<false>); break;
+            default: if (lin) go(bgemm_t256_tail_kernel<H, true>); else go(bgemm_t256_tail_kernel<H, false>); break;
 #else
-        default: throw Error(E2V_EINVAL, "bgemm_t256: no kernel instance for this tile width");
+            default: throw Error(E2V_EINVAL, "bgemm_t256: no kernel instance for this tile width");
 #endif
-    }
+        }
+    });
 }
 
 // Will bgemm_t256_launch(a) leave the row-block sums?  Only the staged epilogue does: bf16 output, no GEGLU, no scatter, whole 64-row
@@ -1144,7 +1139,7 @@ bool bgemm_t256_launch(const IgemmArgs& a_in, hipStream_t s) {
     const bool lin = a.taps == 1;
     const double K = (double)a.taps * (a.c0 + a.c1);
     const double rows_in = lin ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
-    std::string pname = "igemm_bf16";
+    std::string pname = a.a_bf16 == H16_FP16 ? "igemm_fp16" : "igemm_bf16";
     if (prof_detail())
         pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t" + std::to_string(a.taps) +
                  (a.stride > 1 ? " s2" : "") + (a.c1 ? " cat" : "") + (a.geglu ? " geglu" : "") + " T" + std::to_string(cols);
@@ -1234,7 +1229,7 @@ void bgemm_up2x_launch(const IgemmArgs& g, const void* w16_up2, hipStream_t s) {
     const size_t per = (size_t)g.N * conv_up2x_packed_ld(g.c0);
     for (int par = 0; par < 4; ++par) {
         IgemmArgs q = up2x_parity_args(g, par >> 1, par & 1);
-        q.w16 = static_cast<const __bf16*>(w16_up2) + (size_t)par * per;
+        q.w16 = static_cast<const char*>(w16_up2) + (size_t)par * per * 2;
         q.w = nullptr;
         if (!bgemm_t256_launch(q, s)) throw Error(E2V_EINVAL, "bgemm_up2x_launch: the layer is not eligible (bgemm_up2x_applies first)");
     }

@@ -7,29 +7,28 @@
 // loads, 1 KB per wave-instruction (12 waves per CU keep the stream busy); x is staged once per block in LDS as fp32 (rounded to
 // bf16 first in the bf16 mode, so that the operands are the ones the MFMA path would multiply) and read with conflict-free
 // 16-byte LDS reads; fp32 accumulation, one butterfly reduction per (row, batch entry) at the end.
+#include "h16.h"
 #include "kernels.h"
 #include "prof.h"
 
 namespace e2v {
 
 typedef float gf32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
 
-template <typename WT> struct WVec;
+template <typename H> struct WVec {                               // H: bf16 / fp16 (h16.h)
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const H* p, float (&v)[8]) {
+        const hx8<H> a = *reinterpret_cast<const hx8<H>*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+    }
+};
 template <> struct WVec<float> {
     static constexpr int N = 4;                                  // elements per 16-byte load
     static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
         const gf32x4 a = *reinterpret_cast<const gf32x4*>(p);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = a[e];
-    }
-};
-template <> struct WVec<__bf16> {
-    static constexpr int N = 8;
-    static __device__ __forceinline__ void load(const __bf16* p, float (&v)[8]) {
-        const gbf16x8 a = *reinterpret_cast<const gbf16x8*>(p);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
     }
 };
 
@@ -44,7 +43,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
     for (int i = threadIdx.x; i < B * Kp; i += 256) {
         const int b = i / Kp, k = i - b * Kp;
         float v = k < K ? x[(size_t)b * ldx + k] : 0.f;
-        if (round_x) v = (float)(__bf16)v;
+        if constexpr (!__is_same(WT, float)) { if (round_x) v = (float)(WT)v; }
         xs[i] = v;
     }
     __syncthreads();
@@ -111,25 +110,20 @@ void gemv_rows(const float* x, int ldx, const void* w, int ldw, int w_bf16, cons
     const dim3 grid((N + 4 * RW - 1) / (4 * RW));
     ProfScope ps("gemv_weight_stream", 2.0 * B * N * K, (w_bf16 ? 2.0 : 4.0) * (double)N * K + 4.0 * B * (K + N), s);
     if (w_bf16) {
-        auto k4 = gemv_rows_kernel<__bf16, 4, RW>;
-        auto k16 = gemv_rows_kernel<__bf16, 16, RW>;
-        static bool cfg = false;
-        if (!cfg) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            cfg = true;
-        }
-        if (B <= 4) E2V_KLAUNCH(k4, grid, dim3(256), smem, s, x, ldx, static_cast<const __bf16*>(w), ldw, bias, out, ldo, B, N, K, relu, 1);
-        else E2V_KLAUNCH(k16, grid, dim3(256), smem, s, x, ldx, static_cast<const __bf16*>(w), ldw, bias, out, ldo, B, N, K, relu, 1);
+        h16_dispatch(w_bf16, [&](auto h16_tag) {
+            using H = decltype(h16_tag);
+            auto k4 = gemv_rows_kernel<H, 4, RW>;
+            auto k16 = gemv_rows_kernel<H, 16, RW>;
+            E2V_KATTR(k4, 160 * 1024);
+            E2V_KATTR(k16, 160 * 1024);
+            if (B <= 4) E2V_KLAUNCH(k4, grid, dim3(256), smem, s, x, ldx, static_cast<const H*>(w), ldw, bias, out, ldo, B, N, K, relu, 1);
+            else E2V_KLAUNCH(k16, grid, dim3(256), smem, s, x, ldx, static_cast<const H*>(w), ldw, bias, out, ldo, B, N, K, relu, 1);
+        });
     } else {
         auto k4 = gemv_rows_kernel<float, 4, RW>;
         auto k16 = gemv_rows_kernel<float, 16, RW>;
-        static bool cfg = false;
-        if (!cfg) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            cfg = true;
-        }
+        E2V_KATTR(k4, 160 * 1024);
+        E2V_KATTR(k16, 160 * 1024);
         if (B <= 4) E2V_KLAUNCH(k4, grid, dim3(256), smem, s, x, ldx, static_cast<const float*>(w), ldw, bias, out, ldo, B, N, K, relu, 0);
         else E2V_KLAUNCH(k16, grid, dim3(256), smem, s, x, ldx, static_cast<const float*>(w), ldw, bias, out, ldo, B, N, K, relu, 0);
     }

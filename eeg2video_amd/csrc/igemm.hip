@@ -494,13 +494,9 @@ __global__ __launch_bounds__(256) void igemm_x3_kernel(const IgemmArgs p) {
 static void launch_igemm_x3(const IgemmArgs& a, int ntiles, hipStream_t s) {
     static const int ablx = [] { const char* e = std::getenv("E2V_X3_ABLATE"); return e ? std::atoi(e) : 0; }();   // timing experiments only
     constexpr size_t smem = (size_t)3 * (128 + 128) * 80 + 128 * sizeof(unsigned);   // tile planes + gather table (epilogue staging: 34 KB)
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        configured = true;
-    }
+    E2V_KATTR(&igemm_x3_kernel<0>, smem);
+    E2V_KATTR(&igemm_x3_kernel<1>, smem);
+    E2V_KATTR(&igemm_x3_kernel<2>, smem);
     const double K = (double)(a.c0 + a.c1);
     std::string pname = "igemm_f32x3";
     if (prof_detail())
@@ -698,13 +694,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 
 template <int ABL>
 static void launch_igemm(const IgemmArgs& a, int ntiles, const char* cls, hipStream_t s) {
-    static bool configured = false;
     constexpr size_t smem = (size_t)2 * (128 + 128) * LDS_LD * sizeof(float) + 9 * 128 * sizeof(unsigned);   // tiles + gather table
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<ABL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        configured = true;
-    }
+    E2V_KATTR(&igemm_kernel<ABL>, smem);
     dim3 grid(ntiles, 1, 1);
     const double K = (double)a.taps * (a.c0 + a.c1);
     const double rows_in = a.taps == 1 ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
@@ -819,11 +810,7 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
     if (use_x3) { launch_igemm_x3(a, ntiles, s); return; }
     if (k16 && !use_bf16 && a.taps == 1 && abl == 0) {
         constexpr size_t smem16 = (size_t)2 * (128 + 128) * 20 * sizeof(float);   // 40 KB (epilogue staging: 4 x 32 x 68 floats = 34 KB)
-        static bool cfgd = false;
-        if (!cfgd) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_k16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
-            cfgd = true;
-        }
+        E2V_KATTR(&igemm_k16_kernel, smem16);
         const double K = (double)(a.c0 + a.c1);
         std::string pname = cls;
         if (prof_detail())
@@ -883,14 +870,19 @@ void split_bf16x3(const float* in, void* out, size_t n, size_t plane, hipStream_
     E2V_KLAUNCH(split_bf16x3_kernel, dim3(blocks), dim3(256), 0, s, in, static_cast<unsigned short*>(out), n, plane);
 }
 
-__global__ void to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (__bf16)in[i];
+template <typename H>
+__global__ void to_h16_kernel(const float* __restrict__ in, H* __restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (H)in[i];
 }
-void to_bf16(const float* in, void* out, size_t n, hipStream_t s) {
+void to_h16(const float* in, void* out, size_t n, int mode, hipStream_t s) {
     if (!n) return;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    E2V_KLAUNCH(to_bf16_kernel, dim3(blocks), dim3(256), 0, s, in, static_cast<__bf16*>(out), n);
+    h16_dispatch(mode, [&](auto h16_tag) {
+        using H = decltype(h16_tag);
+        E2V_KLAUNCH(to_h16_kernel<H>, dim3(blocks), dim3(256), 0, s, in, static_cast<H*>(out), n);
+    });
 }
+void to_bf16(const float* in, void* out, size_t n, hipStream_t s) { to_h16(in, out, n, H16_BF16, s); }
 
 __global__ void copy_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows,
                                  int cols) {

@@ -1,6 +1,7 @@
 // Pieces shared by the fp32 (igemm.hip) and bf16-activation (bgemm.hip) implicit-GEMM kernels: vector typedefs, the GEGLU gate's
 // erf-GELU and the epilogues that take 32x32 MFMA accumulators (WEIGHT fragment as the A operand) to memory.
 #pragma once
+#include "h16.h"
 #include "kernels.h"
 
 namespace e2v {
@@ -37,11 +38,16 @@ __device__ __forceinline__ float gelu_bf16_grade(float x) {
     const float t = x * fmaf(-0.06940179f * 1.44269504088896340736f, u, -1.60031415f * 1.44269504088896340736f);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
-// (fast: wave-uniform, IgemmArgs::a_bf16 -- the arithmetic mode, never the kernel or the batch, picks the form)
+// (fast: wave-uniform, IgemmArgs::a_bf16 -- the arithmetic mode, never the kernel or the batch, picks the form: the logistic form in
+// bf16 mode only; fp16 rounds 8x finer than bf16, so the fp16 mode keeps the erf form like fp32)
 __device__ __forceinline__ float gelu_gate(float x, const bool fast) { return fast ? gelu_bf16_grade(x) : gelu_erf(x); }
+template <typename H> __device__ __forceinline__ float gelu_gate16(float x) {       // the same choice at compile time, by the kernel's 16-bit type
+    if constexpr (__is_same(H, __bf16)) return gelu_bf16_grade(x);
+    else return gelu_erf(x);
+}
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef hx4<__bf16> bf16x4;        // (the split-bf16 fp32 path of igemm.hip names its operands)
+typedef hx8<__bf16> bf16x8;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Epilogue shared by the fp32, bf16 and split-bf16 tiles (all use 32x32 MFMA results with the WEIGHT fragment as the A
@@ -71,7 +77,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
                         f32x4 y;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + bg[e], p.a_bf16 != 0);
+                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + bg[e], p.a_bf16 == H16_BF16);
                         *reinterpret_cast<f32x4*>(st + mrow * SLD + 8 * g + nq) = y;
                     }
 #pragma unroll
@@ -164,8 +170,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
 // SWZ (the persistent kernel): the staging area is the stage buffer the tile has just consumed and no byte more -- 32 rows x WN
 // floats per wave, UNPADDED, the 16-byte chunk of a row XOR-swizzled with the row (256-byte rows: row & 15; 128-byte rows:
 // (row >> 1) & 7) so that the column-major writes and the row-major reads both cover all 64 banks once per 16 lanes.
-template <int BM, int TM, int TN, int WM, int WN, bool SWZ = false>
-__device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (&acc)[TM][TN], __bf16* __restrict__ out, const int bm,
+template <int BM, int TM, int TN, int WM, int WN, bool SWZ = false, typename H = __bf16>      // H: the 16-bit type (deduced from `out`)
+__device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (&acc)[TM][TN], H* __restrict__ out, const int bm,
                                                     const int n0, const int wm, const int wn, const int lane, float* stage) {
     const int mrow = lane & 31;
     const int nq = (lane >> 5) * 4;
@@ -185,7 +191,7 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
                         f32x4 y;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + bg[e], p.a_bf16 != 0);
+                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + bg[e], p.a_bf16 == H16_BF16);
                         *reinterpret_cast<f32x4*>(st + mrow * SLD + 8 * g + nq) = y;
                     }
 #pragma unroll
@@ -195,10 +201,10 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
                         if (m < p.M) {
                             const f32x4 y0 = *reinterpret_cast<const f32x4*>(st + row * SLD + col);
                             const f32x4 y1 = *reinterpret_cast<const f32x4*>(st + row * SLD + col + 4);
-                            bf16x8 o;
+                            hx8<H> o;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y0[e]; o[4 + e] = (__bf16)y1[e]; }
-                            *reinterpret_cast<bf16x8*>(out + (size_t)m * p.ldc + nb / 2 + col) = o;
+                            for (int e = 0; e < 4; ++e) { o[e] = (H)y0[e]; o[4 + e] = (H)y1[e]; }
+                            *reinterpret_cast<hx8<H>*>(out + (size_t)m * p.ldc + nb / 2 + col) = o;
                         }
                     }
                 }
@@ -249,7 +255,7 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
                 }
                 if (p.resid) {
                     if (p.resid_bf16) {
-                        const bf16x8 r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.resid) + (size_t)m * p.ldr + n);
+                        const hx8<H> r = *reinterpret_cast<const hx8<H>*>(reinterpret_cast<const H*>(p.resid) + (size_t)m * p.ldr + n);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { y0[e] += (float)r[e]; y1[e] += (float)r[4 + e]; }
                     } else {
@@ -261,10 +267,10 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { y0[e] = fmaxf(y0[e], 0.f); y1[e] = fmaxf(y1[e], 0.f); }
                 }
-                bf16x8 o;
+                hx8<H> o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y0[e]; o[4 + e] = (__bf16)y1[e]; }
-                *reinterpret_cast<bf16x8*>(out + (size_t)m * p.ldc + n) = o;
+                for (int e = 0; e < 4; ++e) { o[e] = (H)y0[e]; o[4 + e] = (H)y1[e]; }
+                *reinterpret_cast<hx8<H>*>(out + (size_t)m * p.ldc + n) = o;
             }
         }
         return;
@@ -275,7 +281,7 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
         const int m = bm * BM + wm * WM + mi * 32 + mrow;
         if (m >= p.M) continue;
         const float* rbp = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.rb_ld : nullptr;
-        __bf16* orow = out + (size_t)m * p.ldc;
+        H* orow = out + (size_t)m * p.ldc;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -286,10 +292,10 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
                     if (n + e >= p.N) break;
                     float v = acc[mi][ni][4 * g + e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
                     if (rbp) v += rbp[n + e];
-                    if (p.resid) v += p.resid_bf16 ? (float)reinterpret_cast<const __bf16*>(p.resid)[(size_t)m * p.ldr + n + e]
+                    if (p.resid) v += p.resid_bf16 ? (float)reinterpret_cast<const H*>(p.resid)[(size_t)m * p.ldr + n + e]
                                                    : p.resid[(size_t)m * p.ldr + n + e];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    orow[n + e] = (__bf16)v;
+                    orow[n + e] = (H)v;
                 }
             }
     }
@@ -302,10 +308,10 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
 // rowbias of sample s_lo + j, j = 0, 1 (a tile's rows belong to at most two samples; sample of row m = m / rows_per_sample).  `finish` stages the
 // accumulators through `st` (this wave's 32 x WN floats, unpadded and chunk-swizzled as above), adds, rounds once and stores.
 // Residuals are bf16 (the launcher sends an fp32 residual to the non-persistent kernels).
-template <int BM, int TM, int TN, int WM, int WN, bool ROWBIAS = true>      // ROWBIAS false: launches that never carry one (linears)
+template <typename H, int BM, int TM, int TN, int WM, int WN, bool ROWBIAS = true>      // H: bf16 / fp16; ROWBIAS false: launches that never carry one (linears)
 struct BgEpilogue {
     static constexpr int LPR = WN / 8, RPI = 64 / LPR, NI = 32 / RPI;
-    bf16x8 res[TM][NI];
+    hx8<H> res[TM][NI];
     bool vec;
 
     __device__ __forceinline__ void prefetch(const IgemmArgs& p, const int bm, const int n0, const int wm, const int wn, const int lane) {
@@ -315,7 +321,7 @@ struct BgEpilogue {
         // -- the next tile's DMA included -- at the first use): buffer loads against a descriptor based at the tile's first
         // residual row, rows / columns outside the matrix as out-of-window offsets
         const int n = n0 + wn * WN + (lane % LPR) * 8;
-        const unsigned long long base = reinterpret_cast<unsigned long long>(reinterpret_cast<const __bf16*>(p.resid) + (size_t)bm * BM * p.ldr);
+        const unsigned long long base = reinterpret_cast<unsigned long long>(reinterpret_cast<const H*>(p.resid) + (size_t)bm * BM * p.ldr);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
         const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), (short)0,
@@ -332,7 +338,7 @@ struct BgEpilogue {
                 const bool ok = bm * BM + row < p.M && n < p.N;
                 const unsigned off = ok ? off0 + (unsigned)((mi * 32 + RPI * i) * p.ldr * 2) : 0x80000000u;
                 const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-                res[mi][i] = __builtin_bit_cast(bf16x8, r);
+                res[mi][i] = __builtin_bit_cast(hx8<H>, r);
             }
     }
 
@@ -340,7 +346,7 @@ struct BgEpilogue {
     // of their stores: STORES each, when vec / geglu hold)
     static constexpr int STORES = TM * NI, STORES_GEGLU = TM * 2;
     template <bool WAIT = true>
-    __device__ __forceinline__ void finish(const IgemmArgs& p, f32x16 (&acc)[TM][TN], __bf16* __restrict__ out, const int bm, const int n0,
+    __device__ __forceinline__ void finish(const IgemmArgs& p, f32x16 (&acc)[TM][TN], H* __restrict__ out, const int bm, const int n0,
                                            const int wm, const int wn, const int lane, float* st, const float* brow, const int s_lo) {
         const int mrow = lane & 31;
         const int nq = (lane >> 5) * 4;
@@ -376,7 +382,7 @@ struct BgEpilogue {
                         f32x4 y;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + gv[g][e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + gg[g][e], p.a_bf16 != 0);
+                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + gv[g][e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + gg[g][e], p.a_bf16 == H16_BF16);
                         *reinterpret_cast<f32x4*>(st + mrow * 32 + (((2 * g + (lane >> 5)) ^ wsw) << 2)) = y;
                     }
 #pragma unroll
@@ -386,9 +392,9 @@ struct BgEpilogue {
                         const int rsw = (row >> 1) & 7;
                         const f32x4 y0 = *reinterpret_cast<const f32x4*>(st + row * 32 + (((col >> 2) ^ rsw) << 2));
                         const f32x4 y1 = *reinterpret_cast<const f32x4*>(st + row * 32 + ((((col >> 2) + 1) ^ rsw) << 2));
-                        bf16x8 o;
+                        hx8<H> o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y0[e]; o[4 + e] = (__bf16)y1[e]; }
+                        for (int e = 0; e < 4; ++e) { o[e] = (H)y0[e]; o[4 + e] = (H)y1[e]; }
                         const unsigned off = (m < p.M && !drop) ? (unsigned)(((wm * WM + mi * 32 + row) * p.ldc + nb / 2 + col) * 2) : 0x80000000u;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ors, off, 0, 0);
                     }
@@ -406,7 +412,7 @@ struct BgEpilogue {
                 if (m >= p.M) continue;
                 const float* bb = brow + wn * WN;
                 const float* br = brow + 128 + ((ROWBIAS && p.rowbias) ? (m / p.rows_per_sample - s_lo) * 128 : 0) + wn * WN;
-                __bf16* orow = out + (size_t)m * p.ldc;
+                H* orow = out + (size_t)m * p.ldc;
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -418,9 +424,9 @@ struct BgEpilogue {
                             if (n + e >= p.N) break;
                             float v = acc[mi][ni][4 * g + e] * p.alpha + bb[c + e];
                             if (ROWBIAS && p.rowbias) v += br[c + e];
-                            if (p.resid) v += (float)reinterpret_cast<const __bf16*>(p.resid)[(size_t)m * p.ldr + n + e];
+                            if (p.resid) v += (float)reinterpret_cast<const H*>(p.resid)[(size_t)m * p.ldr + n + e];
                             if (p.relu) v = fmaxf(v, 0.f);
-                            orow[n + e] = (__bf16)v;
+                            orow[n + e] = (H)v;
                         }
                     }
             }
@@ -468,9 +474,9 @@ struct BgEpilogue {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { y0[e] = fmaxf(y0[e], 0.f); y1[e] = fmaxf(y1[e], 0.f); }
                 }
-                bf16x8 o;
+                hx8<H> o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y0[e]; o[4 + e] = (__bf16)y1[e]; }
+                for (int e = 0; e < 4; ++e) { o[e] = (H)y0[e]; o[4 + e] = (H)y1[e]; }
                 const unsigned off = (m < p.M && n < p.N && !drop) ? ooff0 + (unsigned)((mi * 32 + RPI * i) * p.ldc * 2) : 0x80000000u;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ors, off, 0, 0);
             }

@@ -102,6 +102,7 @@ int conv3x3_packed_ld(int cin, int bke);
 void pack_conv3x3(const float* w_oihw, float* w_packed, int cout, int cin, int bke, hipStream_t s);
 void copy_rows(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t s);
 void to_bf16(const float* in, void* out_bf16, size_t n, hipStream_t s);
+void to_h16(const float* in, void* out16, size_t n, int mode, hipStream_t s);      // mode: 1 bf16 / 2 fp16 (h16.h), round to nearest even
 void split_bf16x3(const float* in, void* out_planes, size_t n, size_t plane_stride, hipStream_t s);   // exact 3-way truncation split
 
 // ---------------------------------------------------------------------------------------
@@ -185,7 +186,7 @@ bool flash_attention_q64(const AttnArgs& a, hipStream_t s);
 void temporal_attention(const float* qkv, int ld, float* out, int ldo, int n, int F, int HW, int heads, int D,
                         float scale, hipStream_t s, int bf16 = 0);          // bf16: qkv / out are bf16 rows
 // in place (VAE attention); out_bf16 != null: the normalised probabilities are written there as bf16 ([rows][ld]) instead
-void softmax_rows(float* x, int ld, int rows, int cols, hipStream_t s, void* out_bf16 = nullptr);
+void softmax_rows(float* x, int ld, int rows, int cols, hipStream_t s, void* out_bf16 = nullptr, int out_mode = 1);   // out_mode: 1 bf16 / 2 fp16
 
 // ---------------------------------------------------------------------------------------
 // element-wise / layout (misc.hip)

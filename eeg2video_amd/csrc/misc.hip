@@ -1,6 +1,7 @@
 // Element-wise and layout kernels of the path (all HBM-bound, grid-stride, 16-byte lanes where the
 // layout allows): boundary layout conversion NCFHW <-> channel-last, the fused classifier-free
 // guidance + DDIM update, the timestep sinusoid, SiLU, and a tiled transpose for the VAE attention.
+#include "h16.h"
 #include "kernels.h"
 #include "prof.h"
 #include "act_io.h"
@@ -30,8 +31,10 @@ __global__ void ncfhw_to_cl_kernel(const float* __restrict__ in, T* __restrict__
 void ncfhw_to_cl(const float* in, float* out, int n, int C, int Cpad, int FHW, float scale, hipStream_t s, int out_bf16) {
     const size_t total = (size_t)n * FHW * Cpad;
     if (out_bf16)
-        E2V_KLAUNCH(ncfhw_to_cl_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s, in, reinterpret_cast<__bf16*>(out), n, C, Cpad,
-                           FHW, scale);
+        h16_dispatch(out_bf16, [&](auto h16_tag) {
+            using H = decltype(h16_tag);
+            E2V_KLAUNCH(ncfhw_to_cl_kernel<H>, dim3(grid_for(total)), dim3(256), 0, s, in, reinterpret_cast<H*>(out), n, C, Cpad, FHW, scale);
+        });
     else
         E2V_KLAUNCH(ncfhw_to_cl_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, in, out, n, C, Cpad, FHW, scale);
 }
@@ -139,9 +142,9 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in
 void transpose2d(const float* in, int ld_in, float* out, int ld_out, int rows, int cols, int batch, long long sb_in,
                  long long sb_out, hipStream_t s, int bf16) {
     dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
-    if (bf16)
-        E2V_KLAUNCH(transpose_kernel<__bf16>, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(in), ld_in,
-                           reinterpret_cast<__bf16*>(out), ld_out, rows, cols, sb_in, sb_out);
+    if (bf16)            // (a 2-byte payload: one instance serves bf16 and fp16)
+        E2V_KLAUNCH(transpose_kernel<unsigned short>, grid, dim3(256), 0, s, reinterpret_cast<const unsigned short*>(in), ld_in,
+                           reinterpret_cast<unsigned short*>(out), ld_out, rows, cols, sb_in, sb_out);
     else
         E2V_KLAUNCH(transpose_kernel<float>, grid, dim3(256), 0, s, in, ld_in, out, ld_out, rows, cols, sb_in, sb_out);
 }
@@ -255,8 +258,10 @@ __global__ void pad_cols_kernel(const float* __restrict__ in, int cols, T* __res
 void pad_cols(const float* in, int cols, float* out, int cols_pad, long long rows, hipStream_t s, int out_bf16) {
     if (rows <= 0) return;
     if (out_bf16)
-        E2V_KLAUNCH(pad_cols_kernel<__bf16>, dim3(grid_for((size_t)rows * cols_pad)), dim3(256), 0, s, in, cols,
-                           reinterpret_cast<__bf16*>(out), cols_pad, (size_t)rows);
+        h16_dispatch(out_bf16, [&](auto h16_tag) {
+            using H = decltype(h16_tag);
+            E2V_KLAUNCH(pad_cols_kernel<H>, dim3(grid_for((size_t)rows * cols_pad)), dim3(256), 0, s, in, cols, reinterpret_cast<H*>(out), cols_pad, (size_t)rows);
+        });
     else
         E2V_KLAUNCH(pad_cols_kernel<float>, dim3(grid_for((size_t)rows * cols_pad)), dim3(256), 0, s, in, cols, out, cols_pad, (size_t)rows);
 }
@@ -275,12 +280,17 @@ void cvt_rows(const void* in, int ld_in, int in_bf16, void* out, int ld_out, int
               hipStream_t s) {
     if (rows <= 0 || cols_out <= 0) return;
     const dim3 g(grid_for((size_t)rows * cols_out)), b(256);
-    if (in_bf16 && out_bf16)
-        E2V_KLAUNCH((cvt_rows_kernel<__bf16, __bf16>), g, b, 0, s, static_cast<const __bf16*>(in), ld_in, static_cast<__bf16*>(out), ld_out, (size_t)rows, cols, cols_out);
-    else if (in_bf16)
-        E2V_KLAUNCH((cvt_rows_kernel<__bf16, float>), g, b, 0, s, static_cast<const __bf16*>(in), ld_in, static_cast<float*>(out), ld_out, (size_t)rows, cols, cols_out);
-    else if (out_bf16)
-        E2V_KLAUNCH((cvt_rows_kernel<float, __bf16>), g, b, 0, s, static_cast<const float*>(in), ld_in, static_cast<__bf16*>(out), ld_out, (size_t)rows, cols, cols_out);
+    if (in_bf16 || out_bf16) {           // (both 16-bit: the same type -- a run has one 16-bit mode)
+        h16_dispatch(in_bf16 ? in_bf16 : out_bf16, [&](auto h16_tag) {
+            using H = decltype(h16_tag);
+            if (in_bf16 && out_bf16)
+                E2V_KLAUNCH((cvt_rows_kernel<H, H>), g, b, 0, s, static_cast<const H*>(in), ld_in, static_cast<H*>(out), ld_out, (size_t)rows, cols, cols_out);
+            else if (in_bf16)
+                E2V_KLAUNCH((cvt_rows_kernel<H, float>), g, b, 0, s, static_cast<const H*>(in), ld_in, static_cast<float*>(out), ld_out, (size_t)rows, cols, cols_out);
+            else
+                E2V_KLAUNCH((cvt_rows_kernel<float, H>), g, b, 0, s, static_cast<const float*>(in), ld_in, static_cast<H*>(out), ld_out, (size_t)rows, cols, cols_out);
+        });
+    }
     else
         E2V_KLAUNCH((cvt_rows_kernel<float, float>), g, b, 0, s, static_cast<const float*>(in), ld_in, static_cast<float*>(out), ld_out, (size_t)rows, cols, cols_out);
 }

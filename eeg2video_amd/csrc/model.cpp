@@ -1,5 +1,6 @@
 // Model graphs of the EEG2Video generation hot path on one HIP stream (see model.h).
 #include "model.h"
+#include "h16.h"
 
 #include <algorithm>
 #include <cmath>
@@ -185,25 +186,31 @@ void e2v_ctx::conv_form(const ConvW& w, ConvForm f, hipStream_t s) {
             }
             break;
         case FORM_BF16:
-            if (!w.w16) {
+        case FORM_F16: {
+            const void*& dst = f == FORM_F16 ? w.w16h : w.w16;
+            if (!dst) {
                 const size_t n = (size_t)w.cout * w.ldw16;
                 Act tmp(pool, (int64_t)((n + 1023) / 1024), 1024);            // fp32 staging of the 64-channel-chunk layout
                 pack_conv3x3(w.raw, tmp.p, w.cout, w.cin, 64, s);
                 float* d16 = dev_alloc((n + 1) / 2);
-                to_bf16(tmp.p, d16, n, s);
-                w.w16 = d16;
+                to_h16(tmp.p, d16, n, f == FORM_F16 ? H16_FP16 : H16_BF16, s);
+                dst = d16;
             }
             break;
+        }
         case FORM_BF16_UP2:
-            if (!w.w16_up2) {
+        case FORM_F16_UP2: {
+            const void*& dst = f == FORM_F16_UP2 ? w.w16h_up2 : w.w16_up2;
+            if (!dst) {
                 const size_t n = 4 * (size_t)w.cout * conv_up2x_packed_ld(w.cin);
                 Act tmp(pool, (int64_t)((n + 1023) / 1024), 1024);            // fp32 staging: the tap sums are formed in fp32, rounded once
                 pack_conv_up2x(w.raw, tmp.p, w.cout, w.cin, s);
                 float* d16 = dev_alloc((n + 1) / 2);
-                to_bf16(tmp.p, d16, n, s);
-                w.w16_up2 = d16;
+                to_h16(tmp.p, d16, n, f == FORM_F16_UP2 ? H16_FP16 : H16_BF16, s);
+                dst = d16;
             }
             break;
+        }
         case FORM_WINO2:
         case FORM_WINO4: {
             const int m = f == FORM_WINO4 ? 4 : 2;
@@ -219,6 +226,26 @@ void e2v_ctx::conv_form(const ConvW& w, ConvForm f, hipStream_t s) {
             break;
         }
     }
+}
+
+// fp16 mode: the IEEE-half copy of a linear's weight, derived on first use from the fp32 matrix finalize() kept (same layout as the
+// bf16 copy: rows zero-padded to in16), filed under the finalize() group that owns the layer.
+const void* e2v_ctx::lin_f16(const LinW& w, hipStream_t s) {
+    if (w.w16h) return w.w16h;
+    const int saved = alloc_part;
+    struct Restore { e2v_ctx* c; int v; ~Restore() { c->alloc_part = v; } } restore{this, saved};
+    alloc_part = w.part;
+    const size_t n = (size_t)w.out * w.in16;
+    float* d16 = dev_alloc((n + 1) / 2);
+    if (w.in16 == w.in) {
+        to_h16(w.w, d16, n, H16_FP16, s);
+    } else {
+        Act tmp(pool, (int64_t)((n + 1023) / 1024), 1024);
+        pad_cols(w.w, w.in, tmp.p, w.in16, w.out, s);
+        to_h16(tmp.p, d16, n, H16_FP16, s);
+    }
+    w.w16h = d16;
+    return d16;
 }
 
 void e2v_ctx::enter_stream(hipStream_t s) {
@@ -266,10 +293,11 @@ struct Packer {
             pad_cols(w, in, tmp, in16, out, s);
             w16 = half(tmp, (size_t)out * in16);
             E2V_HIP(hipStreamSynchronize(s));
-            (void)hipFree(tmp);
+            if (!dry_run()) (void)hipFree(tmp);
         }
         LinW l{w, b, in, out, w16, split3(w, (size_t)out * in)};
         l.in16 = in16;
+        l.part = c->alloc_part >= 0 ? c->alloc_part : 0;
         return l;
     }
     const void* split3(const float* w, size_t n) {           // three bf16 planes (f32x3 mode only)
@@ -504,11 +532,14 @@ struct Runner {
     // bf16-activation mode (e2v_set_compute_dtype(E2V_BF16)): every activation the graph stores in HBM is bf16; accumulation,
     // GroupNorm / LayerNorm statistics, softmax and the time-embedding rows stay fp32
     bool bf() const { return c->bf16_compute; }
+    int h16() const { return c->bf16_compute ? c->h16_mode : 0; }      // the mode flag of every 16-bit launch: 1 bf16, 2 fp16 (h16.h)
+    bool fp16() const { return h16() == H16_FP16; }
+    const void* w16_of(const LinW& w) { return fp16() ? c->lin_f16(w, s) : w.w16; }
     Act new_act(int64_t rows, int C) { return Act(pool(), rows, C, bf()); }
     // fp32 rows -> bf16 rows padded to `cpad` channels (boundary tensors: latents, z, images, conditioning)
     Act to_act16(const float* x, int cols, int cpad, int64_t rows) {
         Act o(pool(), rows, cpad, true);
-        pad_cols(x, cols, o.p, cpad, rows, s, 1);
+        pad_cols(x, cols, o.p, cpad, rows, s, h16());
         return o;
     }
 
@@ -540,7 +571,7 @@ struct Runner {
         gn_ws(samples, P, C);
         Act out = new_act((int64_t)samples * P, C);
         GroupNormArgs a;
-        a.bf16 = bf() ? 1 : 0;
+        a.bf16 = h16();
         a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1; a.ld0 = c0; a.ld1 = c1;
         a.gamma = w.g; a.beta = w.b; a.out = out.p; a.ldo = C;
         a.samples = samples; a.P = P; a.groups = groups; a.eps = eps; a.silu = act ? 1 : 0;
@@ -556,7 +587,7 @@ struct Runner {
         E2V_REQUIRE(C == w.c && C % groups == 0 && c0 % 4 == 0 && c1 % 4 == 0, E2V_ESHAPE, "GroupNorm channel mismatch");
         gn_ws(samples, P, C);
         GroupNormArgs a;
-        a.bf16 = bf() ? 1 : 0;
+        a.bf16 = h16();
         a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1; a.ld0 = c0; a.ld1 = c1;
         a.gamma = w.g; a.beta = w.b; a.samples = samples; a.P = P; a.groups = groups; a.eps = eps;
         a.ws_part = c->gn_part; a.ws_scale = c->gn_scale;
@@ -579,7 +610,7 @@ struct Runner {
     Act ln(const NormW& w, const Act& x) {
         E2V_REQUIRE(x.C == w.c && x.C % 4 == 0 && x.C <= 1280, E2V_ESHAPE, "LayerNorm width unsupported");
         Act out = new_act(x.rows, x.C);
-        layernorm(x.p, x.C, w.g, w.b, out.p, x.C, (int)x.rows, x.C, 1e-5f, s, bf() ? 1 : 0);
+        layernorm(x.p, x.C, w.g, w.b, out.p, x.C, (int)x.rows, x.C, 1e-5f, s, h16());
         return out;
     }
 
@@ -598,8 +629,7 @@ struct Runner {
         g.a0 = a; g.c0 = K0; g.lda0 = lda; g.a1 = a1; g.c1 = c1; g.lda1 = lda1;
         g.w = w.w; g.ldw = w.in; g.ldw16 = w.in16; g.out = out.p; g.ldc = out.C; g.bias = w.b;
         g.resid = resid; g.ldr = ldr; g.M = (int)M; g.N = w.out; g.taps = 1; g.geglu = geglu ? 1 : 0;
-        g.w16 = w.w16;
-        if (b16) { g.a_bf16 = 1; g.out_f32 = out_f32 ? 1 : 0; g.resid_bf16 = resid ? 1 : 0; }
+        if (b16) { g.w16 = w16_of(w); g.a_bf16 = h16(); g.out_f32 = out_f32 ? 1 : 0; g.resid_bf16 = resid ? 1 : 0; }
         if (c->x3_compute && w.w3) { g.x3 = 1; g.w3 = w.w3; g.w3_plane = (long long)w.out * w.in; }
         igemm(g, s);
         return out;
@@ -644,7 +674,7 @@ struct Runner {
         g.rowbias = rowbias; g.rb_ld = rb_ld; g.rows_per_sample = rows_per_sample;
         g.resid = resid; g.ldr = w.cout;
         g.M = (int)out.rows; g.N = w.cout; g.taps = 9;
-        if (bf()) { g.a_bf16 = 1; g.out_f32 = out_f32 ? 1 : 0; g.resid_bf16 = resid ? 1 : 0; }
+        if (bf()) { g.a_bf16 = h16(); g.out_f32 = out_f32 ? 1 : 0; g.resid_bf16 = resid ? 1 : 0; }
         g.Ho = Ho; g.Wo = Wo; g.Hi = Hi; g.Wi = Wi; g.Hs = geo.H; g.Ws = geo.W; g.stride = stride; g.pad = pad;
         if (Hi != geo.H || Wi != geo.W) {
             g.upsample = 1;
@@ -652,12 +682,12 @@ struct Runner {
             g.ups_w = (float)geo.W / (float)Wi;
         }
         if (bf() && c0 == w.cin && bgemm_up2x_applies(g)) {       // exact 2x resize (Upsample3D): four 2x2 convs on the source map
-            c->conv_form(w, e2v_ctx::FORM_BF16_UP2, s);
-            bgemm_up2x_launch(g, w.w16_up2, s);
+            c->conv_form(w, fp16() ? e2v_ctx::FORM_F16_UP2 : e2v_ctx::FORM_BF16_UP2, s);
+            bgemm_up2x_launch(g, fp16() ? w.w16h_up2 : w.w16_up2, s);
             return out;
         }
-        c->conv_form(w, bf() ? e2v_ctx::FORM_BF16 : e2v_ctx::FORM_DIRECT32, s);
-        g.w = w.w; g.w16 = w.w16;
+        c->conv_form(w, fp16() ? e2v_ctx::FORM_F16 : bf() ? e2v_ctx::FORM_BF16 : e2v_ctx::FORM_DIRECT32, s);
+        g.w = w.w; g.w16 = fp16() ? w.w16h : w.w16;
         // GroupNorm statistics from the producer -- BUILT, BIT-EXACT, MEASURED AND NOT ADOPTED (`make ab` builds, E2V_GN_RB = 1; DESIGN
         // section 9, profiles/r04_shape_ab_gn_producer_sums.log): the sums are ALWAYS the canonical ones -- from the epilogue when the
         // launch runs on the 256-row staged kernel (E2V_GN_RB_EPILOGUE = 0: never, for the bit-identity test), else from rowblock_sums
@@ -667,7 +697,7 @@ struct Runner {
         static const int* const rb_on = E2V_AB_KNOB("E2V_GN_RB", 0);
         static const int* const rb_epi = E2V_AB_KNOB("E2V_GN_RB_EPILOGUE", 1);
         bool epilogue_sums = false;
-        if (*rb_on && want_rb && bf() && !out_f32 && rbsum_capable(out.rows, w.cout)) {
+        if (*rb_on && want_rb && h16() == H16_BF16 && !out_f32 && rbsum_capable(out.rows, w.cout)) {
             out.rb = pool().get((size_t)(out.rows / 64) * w.cout * 2);
             if (*rb_epi) { g.rbsum = out.rb; epilogue_sums = igemm_writes_rbsum(g); if (!epilogue_sums) g.rbsum = nullptr; }
         }
@@ -746,7 +776,7 @@ struct Runner {
         const Act* xp = &x_in;
         const float scale = 1.0f / std::sqrt((float)D);
         E2V_REQUIRE(C % heads == 0 && D % 8 == 0, E2V_EINVAL, "attention head dim must be a multiple of 8");
-        const int io16 = bf() ? 1 : 0;
+        const int io16 = h16();
         Act t;
         {
             Act hn = gn(w.norm, xp->p, C, nullptr, 0, n1 * F, HW, groups, 1e-6f, false, xp->rb);      // :99 (per frame)
@@ -826,12 +856,12 @@ struct Runner {
             g.a0 = qkv.p; g.c0 = C; g.lda0 = 3 * C; g.w = qkv.at(C); g.ldw = 3 * C;
             g.out = sc.p; g.ldc = HW; g.M = HW; g.N = HW; g.taps = 1; g.alpha = 1.0f / std::sqrt((float)C);
             g.batch = nimg; g.sa0 = (long long)HW * 3 * C; g.sw = (long long)HW * 3 * C; g.sout = (long long)HW * HW;
-            if (bf()) { g.a_bf16 = 1; g.out_f32 = 1; g.w16 = qkv.at(C); g.ldw16 = 3 * C; }
+            if (bf()) { g.a_bf16 = h16(); g.out_f32 = 1; g.w16 = qkv.at(C); g.ldw16 = 3 * C; }
             igemm(g, s);
         }
         Act p16;
         if (bf()) p16 = Act(pool(), rows, HW, true);
-        softmax_rows(sc.p, HW, (int)rows, HW, s, bf() ? p16.p : nullptr);
+        softmax_rows(sc.p, HW, (int)rows, HW, s, bf() ? p16.p : nullptr, bf() ? h16() : H16_BF16);
         Act vt = new_act((int64_t)nimg * C, HW);
         transpose2d(qkv.at(2 * C), 3 * C, vt.p, HW, HW, C, nimg, (long long)HW * 3 * C, (long long)C * HW, s, bf() ? 1 : 0);
         qkv.reset();
@@ -841,7 +871,7 @@ struct Runner {
             g.a0 = bf() ? p16.p : sc.p; g.c0 = HW; g.lda0 = HW; g.w = vt.p; g.ldw = HW; g.out = o.p; g.ldc = C;
             g.M = HW; g.N = C; g.taps = 1; g.batch = nimg;
             g.sa0 = (long long)HW * HW; g.sw = (long long)C * HW; g.sout = (long long)HW * C;
-            if (bf()) { g.a_bf16 = 1; g.w16 = vt.p; g.ldw16 = HW; }
+            if (bf()) { g.a_bf16 = h16(); g.w16 = vt.p; g.ldw16 = HW; }
             igemm(g, s);
         }
         return linear(w.proj, o.p, C, rows, x.p, C);
@@ -877,7 +907,7 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
         Act wide;
         if (a.bf16) {
             wide = Act(pool, a.rows, a.C);
-            cvt_rows(a.p, a.C, 1, wide.p, a.C, 0, a.rows, a.C, a.C, s);
+            cvt_rows(a.p, a.C, h16_mode, wide.p, a.C, 0, a.rows, a.C, a.C, s);
             rows = wide.p;
         }
         cl_to_ncfhw(rows, a.C, t.buf + t.used, n, C, (int)fhw, 1.0f, 0.0f, 0, 0.f, 0.f, s);

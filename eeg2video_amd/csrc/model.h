@@ -15,7 +15,9 @@ namespace e2v {
 struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
 struct LinW { const float* w = nullptr; const float* b = nullptr; int in = 0, out = 0; const void* w16 = nullptr;
               const void* w3 = nullptr;         // three bf16 planes of w (out*in elements apart) for the f32x3 mode
-              int in16 = 0; };                  // row length of w16: `in` rounded up to 8 (zero columns; 16-byte DMA pieces)
+              int in16 = 0;                     // row length of w16: `in` rounded up to 8 (zero columns; 16-byte DMA pieces)
+              int part = 0;                     // which finalize() group owns the lazily built fp16 form
+              mutable const void* w16h = nullptr; };   // the same matrix as IEEE half (fp16 mode), built on first use (e2v_ctx::lin_f16)
 // A 3x3 conv keeps its torch-layout weight and builds the kernel layouts ON FIRST USE (e2v_ctx::conv_form): which of them a
 // layer ever needs depends on the arithmetic mode and on the map size it is called with -- fp32 direct-packed, F(2x2) / F(4x4)
 // Winograd-domain (x2.25 / x4 the raw size), bf16 direct-packed -- and building all of them cost 18 GiB where one mode uses 4-9.
@@ -30,6 +32,8 @@ struct ConvW {
     mutable const float* w = nullptr;            // [O][chunk32][tap][32]
     mutable const void* w16 = nullptr;           // [O][chunk64][tap][64] bf16
     mutable const void* w16_up2 = nullptr;       // [4 parities][O][chunk64][4 taps][64] bf16: the sub-pixel form of resize + conv (bgemm_up2x)
+    mutable const void* w16h = nullptr;          // the two 16-bit layouts as IEEE half (fp16 mode)
+    mutable const void* w16h_up2 = nullptr;
     mutable const float* wino = nullptr;         // [16][O][I]
     mutable const float* wino4 = nullptr;        // [36][O][I]
     mutable const void* wino_x3 = nullptr; mutable const void* wino4_x3 = nullptr;   // three-plane bf16 splits (f32x3 mode)
@@ -108,7 +112,9 @@ struct e2v_ctx {
     int wino_min_c = 256;                                        // auto: F(2x2,3x3) when min(Cin, Cout) >= this (E2V_WINO_MIN_C)
     size_t wino_ws_floats = (size_t)1 << 30;                     // workspace cap per pass (E2V_WINO_WS_MB)
     bool x3_compute = false;                                     // E2V_F32X3: fp32 products from split bf16 pieces on the bf16 MFMA
-    bool bf16_compute = false;                                   // e2v_set_compute_dtype: bf16 MFMA for convs / linears
+    bool bf16_compute = false;                                   // e2v_set_compute_dtype: a 16-bit activation mode (16-bit MFMA, 16-bit rows in HBM) ...
+    int h16_mode = 0;                                            // ... and which: 0 none, 1 bf16 (E2V_BF16), 2 fp16 (E2V_F16) -- the flag every 16-bit launch carries (h16.h)
+    void set_h16_mode(int m) { h16_mode = m; bf16_compute = m != 0; }
     std::vector<e2v::LinW> sem;                                  // semantic predictor layers (first one K-padded to 4)
     int sem_in_pad = 0;
     std::vector<float> alphas;                                   // host alpha-bar table
@@ -136,7 +142,8 @@ struct e2v_ctx {
     void free_part(int part);
 
     float* dev_alloc(size_t floats);
-    enum ConvForm { FORM_DIRECT32, FORM_BF16, FORM_WINO2, FORM_WINO4, FORM_BF16_UP2 };
+    enum ConvForm { FORM_DIRECT32, FORM_BF16, FORM_WINO2, FORM_WINO4, FORM_BF16_UP2, FORM_F16, FORM_F16_UP2 };
+    const void* lin_f16(const e2v::LinW& w, hipStream_t s);              // the fp16 copy of a linear's weight (built on first use)
     void conv_form(const e2v::ConvW& w, ConvForm f, hipStream_t s);     // build the layout if this is its first use
     bool conv_has_wino(const e2v::ConvW& w, int m) const;               // would the policy allow the F(m x m) form for this layer?
     void expected_keys();

@@ -8,6 +8,7 @@
 // partials of its channels in fp64 and emits per-(slab, channel) scale/shift; (3) a streaming pass
 // applies y = act(x*scale + shift).  Two sources = the channel concat of the up blocks
 // (unet_blocks.py:487), whose groups may straddle the seam (1920/32 = 60 does not divide 1280).
+#include "h16.h"
 #include "kernels.h"
 #include "prof.h"
 #include "act_io.h"
@@ -168,24 +169,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
 // The templated kernels above move 4 channels per lane: 16 bytes of fp32 but only 8 of bf16, and at half the bytes per
 // instruction the bf16 passes ran at 2.2-2.9 TB/s effective.  These variants give every lane 8 channels (one 16-byte load /
 // store), the arithmetic is unchanged (fp32 sums of <= 64 values per thread, fp64 fold, fp32 affine).
-typedef __bf16 nbf16x8 __attribute__((ext_vector_type(8)));
 struct F8 { f32x4 lo, hi; };
-__device__ __forceinline__ F8 ld8(const __bf16* p) {
-    const nbf16x8 v = *reinterpret_cast<const nbf16x8*>(p);
+template <typename H>      // H: bf16 / fp16 (h16.h)
+__device__ __forceinline__ F8 ld8(const H* p) {
+    const hx8<H> v = *reinterpret_cast<const hx8<H>*>(p);
     F8 r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { r.lo[e] = (float)v[e]; r.hi[e] = (float)v[4 + e]; }
     return r;
 }
-__device__ __forceinline__ void st8(__bf16* p, const f32x4& lo, const f32x4& hi) {
-    nbf16x8 v;
+template <typename H>
+__device__ __forceinline__ void st8(H* p, const f32x4& lo, const f32x4& hi) {
+    hx8<H> v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { v[e] = (__bf16)lo[e]; v[4 + e] = (__bf16)hi[e]; }
-    *reinterpret_cast<nbf16x8*>(p) = v;
+    for (int e = 0; e < 4; ++e) { v[e] = (H)lo[e]; v[4 + e] = (H)hi[e]; }
+    *reinterpret_cast<hx8<H>*>(p) = v;
 }
 
 // grid (chunks, slabs); same partial layout as gn_partial_kernel; OT = octets handled side by side (divides C / 8, <= 64)
-__global__ __launch_bounds__(256) void gn_partial8_kernel(const __bf16* __restrict__ x, int ld, int C, int P, int chunks,
+template <typename H>
+__global__ __launch_bounds__(256) void gn_partial8_kernel(const H* __restrict__ x, int ld, int C, int P, int chunks,
                                                           float* __restrict__ part, int Ctot, int coff, int OT, int chunk_rows) {
     __shared__ f32x4 red[4][256];
     const int chunk = blockIdx.x, slab = blockIdx.y;
@@ -193,13 +196,13 @@ __global__ __launch_bounds__(256) void gn_partial8_kernel(const __bf16* __restri
     const int q = threadIdx.x % OT, r = threadIdx.x / OT;
     const int p0 = chunk * chunk_rows;
     const int p1 = min(P, p0 + chunk_rows);
-    const __bf16* base = x + (size_t)slab * P * ld;
+    const H* base = x + (size_t)slab * P * ld;
     float* dst = part + ((size_t)(slab * chunks + chunk) * Ctot + coff) * 2;
     const int CO = C / 8;
     for (int q0 = 0; q0 < CO; q0 += OT) {
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, ss0 = s0, ss1 = s0;
         if (r < R) {
-            const __bf16* col = base + (q0 + q) * 8;
+            const H* col = base + (q0 + q) * 8;
             int pr = p0 + r;
             for (; pr + 3 * R < p1; pr += 4 * R) {          // four rows in flight per thread
                 const F8 a = ld8(col + (size_t)pr * ld), b = ld8(col + (size_t)(pr + R) * ld);
@@ -270,9 +273,9 @@ __global__ __launch_bounds__(256) void gn_apply8_kernel(const __bf16* __restrict
 __device__ __forceinline__ float silu_fast(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
 }
-template <bool ACT>
-__global__ __launch_bounds__(256) void gn_apply8_rows_kernel(const __bf16* __restrict__ x0, const __bf16* __restrict__ x1, int c0, int c1,
-                                                             int ld0, int ld1, const float* __restrict__ scsh, __bf16* __restrict__ out,
+template <typename H, bool ACT>
+__global__ __launch_bounds__(256) void gn_apply8_rows_kernel(const H* __restrict__ x0, const H* __restrict__ x1, int c0, int c1,
+                                                             int ld0, int ld1, const float* __restrict__ scsh, H* __restrict__ out,
                                                              int ldo, int P, int OT, int chunk_rows) {
     const int chunk = blockIdx.x, slab = blockIdx.y;
     const int R = 256 / OT;
@@ -285,9 +288,9 @@ __global__ __launch_bounds__(256) void gn_apply8_rows_kernel(const __bf16* __res
     const float* scb = scsh + (size_t)slab * Ctot * 2;
     for (int q0 = 0; q0 < Ctot / 8; q0 += OT) {             // (OT divides c0 / 8 and c1 / 8: a column tile has one source)
         const int c = (q0 + q) * 8;
-        const __bf16* col = c < c0 ? x0 + row0 * ld0 + c : x1 + row0 * ld1 + (c - c0);
+        const H* col = c < c0 ? x0 + row0 * ld0 + c : x1 + row0 * ld1 + (c - c0);
         const int ld = c < c0 ? ld0 : ld1;
-        __bf16* dst = out + row0 * ldo + c;
+        H* dst = out + row0 * ldo + c;
         const float* sc = scb + (size_t)c * 2;
         const f32x4 a = *reinterpret_cast<const f32x4*>(sc), b = *reinterpret_cast<const f32x4*>(sc + 4);
         const f32x4 d = *reinterpret_cast<const f32x4*>(sc + 8), e = *reinterpret_cast<const f32x4*>(sc + 12);
@@ -381,11 +384,7 @@ __global__ __launch_bounds__(256) void rowblock_sums_kernel(const __bf16* __rest
 void rowblock_sums(const void* x, int ld, int C, long long rows, int rpp, float* out, hipStream_t s) {
     if (rows <= 0) return;
     const size_t smem = (size_t)(C / 8) * rpp * 16 * sizeof(float);
-    static size_t configured = 0;
-    if (smem > configured && smem > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowblock_sums_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        configured = smem;
-    }
+    if (smem > 48 * 1024) E2V_KATTR(rowblock_sums_kernel, smem);
     ProfScope ps("rowblock_sums", 3.0 * rows * C, 2.0 * rows * C, s);
     E2V_KLAUNCH(rowblock_sums_kernel, dim3((unsigned)(rows / 64)), dim3(256), smem, s, static_cast<const __bf16*>(x), ld, C, rpp, out);
 }
@@ -440,12 +439,17 @@ static void groupnorm_stats_launch(const GroupNormArgs& a, hipStream_t s) {
     const int chunks = (a.P + crows - 1) / crows;
     auto part = [&](const float* x, int ld, int C, int coff) {
         const int qt = quad_tile(C / 4);
-        if (a.bf16 && C % 8 == 0 && ld % 8 == 0)
-            E2V_KLAUNCH(gn_partial8_kernel, dim3(chunks, a.samples), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), ld, C, a.P,
-                               chunks, a.ws_part, Ctot, coff, oct_tile(C / 8), crows);
-        else if (a.bf16)
-            E2V_KLAUNCH(gn_partial_kernel<__bf16>, dim3(chunks, a.samples), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), ld, C,
-                               a.P, chunks, a.ws_part, Ctot, coff, qt, crows);
+        if (a.bf16) {
+            h16_dispatch(a.bf16, [&](auto h16_tag) {
+                using H = decltype(h16_tag);
+                if (C % 8 == 0 && ld % 8 == 0)
+                    E2V_KLAUNCH(gn_partial8_kernel<H>, dim3(chunks, a.samples), dim3(256), 0, s, reinterpret_cast<const H*>(x), ld, C, a.P,
+                                chunks, a.ws_part, Ctot, coff, oct_tile(C / 8), crows);
+                else
+                    E2V_KLAUNCH(gn_partial_kernel<H>, dim3(chunks, a.samples), dim3(256), 0, s, reinterpret_cast<const H*>(x), ld, C,
+                                a.P, chunks, a.ws_part, Ctot, coff, qt, crows);
+            });
+        }
         else
             E2V_KLAUNCH(gn_partial_kernel<float>, dim3(chunks, a.samples), dim3(256), 0, s, x, ld, C, a.P, chunks, a.ws_part, Ctot,
                                coff, qt, crows);
@@ -500,12 +504,15 @@ static void groupnorm_bf16_launch(const GroupNormArgs& a, hipStream_t s) {
         const int ot = oct_tile(a.c1 > 0 ? gcd_int(a.c0 / 8, a.c1 / 8) : a.c0 / 8);
         const int crows = gn_chunk_rows(a.P);
         const dim3 grid((a.P + crows - 1) / crows, a.samples);
-        auto go = [&](auto kern) {
-            E2V_KLAUNCH(kern, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0), reinterpret_cast<const __bf16*>(a.x1), a.c0,
-                               a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<__bf16*>(a.out), a.ldo, a.P, ot, crows);
-        };
         dry_tag(" + gn_apply8_rows_kernel rows" + std::to_string(crows));
-        if (a.silu) go(gn_apply8_rows_kernel<true>); else go(gn_apply8_rows_kernel<false>);
+        h16_dispatch(a.bf16, [&](auto h16_tag) {
+            using H = decltype(h16_tag);
+            auto go = [&](auto kern) {
+                E2V_KLAUNCH(kern, grid, dim3(256), 0, s, reinterpret_cast<const H*>(a.x0), reinterpret_cast<const H*>(a.x1), a.c0,
+                            a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<H*>(a.out), a.ldo, a.P, ot, crows);
+            };
+            if (a.silu) go(gn_apply8_rows_kernel<H, true>); else go(gn_apply8_rows_kernel<H, false>);
+        });
         return;
     }
 #ifdef E2V_AB
@@ -549,9 +556,9 @@ void groupnorm(const GroupNormArgs& a, hipStream_t s) {
             GroupNormArgs b = a;
             b.samples = g0 + per <= a.samples ? per : a.samples - g0;
             const size_t r0 = (size_t)g0 * a.P;
-            b.x0 = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x0) + r0 * a.ld0);
-            if (a.c1 > 0) b.x1 = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x1) + r0 * a.ld1);
-            b.out = reinterpret_cast<float*>(reinterpret_cast<__bf16*>(a.out) + r0 * a.ldo);
+            b.x0 = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.x0) + r0 * a.ld0);       // (2-byte elements)
+            if (a.c1 > 0) b.x1 = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.x1) + r0 * a.ld1);
+            b.out = reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(a.out) + r0 * a.ldo);
             b.ws_part = a.ws_part + (size_t)g0 * chunks * Ctot * 2;
             b.ws_scale = a.ws_scale + (size_t)g0 * Ctot * 2;
             groupnorm_bf16_launch(b, s);
@@ -561,9 +568,12 @@ void groupnorm(const GroupNormArgs& a, hipStream_t s) {
     groupnorm_stats_launch(a, s);
     dry_tag(" + gn_apply_kernel");
     if (a.bf16)
-        E2V_KLAUNCH(gn_apply_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0),
-                           reinterpret_cast<const __bf16*>(a.x1), a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<__bf16*>(a.out), a.ldo,
-                           a.P, rows, a.silu);
+        h16_dispatch(a.bf16, [&](auto h16_tag) {
+            using H = decltype(h16_tag);
+            E2V_KLAUNCH(gn_apply_kernel<H>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const H*>(a.x0),
+                        reinterpret_cast<const H*>(a.x1), a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<H*>(a.out), a.ldo,
+                        a.P, rows, a.silu);
+        });
     else
         E2V_KLAUNCH(gn_apply_kernel<float>, dim3(blocks), dim3(256), 0, s, a.x0, a.x1, a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, a.out,
                            a.ldo, a.P, rows, a.silu);
@@ -626,9 +636,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 
 // bf16 rows: 8 channels (16 bytes) per lane and R rows per wave, all loads of the R rows issued before the first reduction
 // (a wave that owns one 640-byte row spends its life on launch, two shuffle chains and a store: 2.9 TB/s effective)
-template <int NV, int R>
-__global__ __launch_bounds__(256) void layernorm_bf16_kernel(const __bf16* __restrict__ x, int ldx, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, __bf16* __restrict__ out, int ldo,
+template <typename H, int NV, int R>
+__global__ __launch_bounds__(256) void layernorm_bf16_kernel(const H* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, H* __restrict__ out, int ldo,
                                                              int rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
@@ -639,7 +649,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const __bf16* __res
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int row = min(row0 + r, rows - 1);
-        const __bf16* xr = x + (size_t)row * ldx;
+        const H* xr = x + (size_t)row * ldx;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int q = lane + 64 * k;
@@ -719,9 +729,9 @@ __device__ __forceinline__ float rowlanes_allreduce(float x) {
     if constexpr (LPR >= 32) x += __shfl_xor(x, 16);
     return x;
 }
-template <int LPR, int G>
-__global__ __launch_bounds__(256) void layernorm_bf16_rows_kernel(const __bf16* __restrict__ x, int ldx, const float* __restrict__ gamma,
-                                                                  const float* __restrict__ beta, __bf16* __restrict__ out, int ldo,
+template <typename H, int LPR, int G>
+__global__ __launch_bounds__(256) void layernorm_bf16_rows_kernel(const H* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, H* __restrict__ out, int ldo,
                                                                   int rows, float eps) {
     constexpr int NV = 5, RW = 64 / LPR, C = LPR * NV * 8;
     const int lane = threadIdx.x & 63;
@@ -732,7 +742,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16_rows_kernel(const __bf16* 
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int row = min(row0 + g * RW, rows - 1);
-        const __bf16* xr = x + (size_t)row * ldx + c * 8;
+        const H* xr = x + (size_t)row * ldx + c * 8;
 #pragma unroll
         for (int k = 0; k < NV; ++k) v[g][k] = ld8(xr + k * LPR * 8);
     }
@@ -863,26 +873,30 @@ void layernorm(const float* x, int ldx, const float* gamma, const float* beta, f
         dry_tag(std::string(" -> ") + (shared ? (bf16 ? "layernorm_bf16_rows_kernel" : "layernorm_f32_rows_kernel")
                                        : (bf16 && C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && C <= 1536 ? "layernorm_bf16_kernel" : "layernorm_kernel")));
     }
-    if (bf16 && *rowsp && (C == 320 || C == 640 || C == 1280) && ldx % 8 == 0 && ldo % 8 == 0) {
-        const __bf16* xi = reinterpret_cast<const __bf16*>(x);
-        __bf16* xo = reinterpret_cast<__bf16*>(out);
-        auto go = [&](auto kern, const int rows_per_wave) {
-            const int blocks = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
-            E2V_KLAUNCH(kern, dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, eps);
-        };
-        if (C == 320) go(layernorm_bf16_rows_kernel<8, 2>, 16);
-        else if (C == 640) go(layernorm_bf16_rows_kernel<16, 2>, 8);
-        else go(layernorm_bf16_rows_kernel<32, 2>, 4);
-    } else if (bf16 && C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && C <= 1536) {
-        constexpr int R = 4;
-        const int blocks = (rows + 4 * R - 1) / (4 * R);
-        const __bf16* xi = reinterpret_cast<const __bf16*>(x);
-        __bf16* xo = reinterpret_cast<__bf16*>(out);
-        if (C <= 512) E2V_KLAUNCH((layernorm_bf16_kernel<1, R>), dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, C, eps);
-        else if (C <= 1024) E2V_KLAUNCH((layernorm_bf16_kernel<2, R>), dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, C, eps);
-        else E2V_KLAUNCH((layernorm_bf16_kernel<3, R>), dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, C, eps);
-    } else if (bf16)
-        layernorm_launch(reinterpret_cast<const __bf16*>(x), ldx, gamma, beta, reinterpret_cast<__bf16*>(out), ldo, rows, C, eps, s);
+    if (bf16) {
+        h16_dispatch(bf16, [&](auto h16_tag) {
+            using H = decltype(h16_tag);
+            const H* xi = reinterpret_cast<const H*>(x);
+            H* xo = reinterpret_cast<H*>(out);
+            if (*rowsp && (C == 320 || C == 640 || C == 1280) && ldx % 8 == 0 && ldo % 8 == 0) {
+                auto go = [&](auto kern, const int rows_per_wave) {
+                    const int blocks = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
+                    E2V_KLAUNCH(kern, dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, eps);
+                };
+                if (C == 320) go(layernorm_bf16_rows_kernel<H, 8, 2>, 16);
+                else if (C == 640) go(layernorm_bf16_rows_kernel<H, 16, 2>, 8);
+                else go(layernorm_bf16_rows_kernel<H, 32, 2>, 4);
+            } else if (C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && C <= 1536) {
+                constexpr int R = 4;
+                const int blocks = (rows + 4 * R - 1) / (4 * R);
+                if (C <= 512) E2V_KLAUNCH((layernorm_bf16_kernel<H, 1, R>), dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, C, eps);
+                else if (C <= 1024) E2V_KLAUNCH((layernorm_bf16_kernel<H, 2, R>), dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, C, eps);
+                else E2V_KLAUNCH((layernorm_bf16_kernel<H, 3, R>), dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, C, eps);
+            } else {
+                layernorm_launch(xi, ldx, gamma, beta, xo, ldo, rows, C, eps, s);
+            }
+        });
+    }
     else if (*rowsp && (C == 320 || C == 640 || C == 1280) && ldx % 4 == 0 && ldo % 4 == 0) {
         auto go = [&](auto kern, const int rows_per_wave) {
             const int blocks = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);

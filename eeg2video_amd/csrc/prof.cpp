@@ -4,7 +4,23 @@
 #include <cstdlib>
 #include <map>
 
+#include <mutex>
+#include <utility>
+
 namespace e2v {
+
+void kattr_max_lds(const void* kernel, int bytes) {
+    if (dry_run()) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    static std::mutex m;
+    static std::map<std::pair<const void*, int>, int> set;      // (kernel, device) -> bytes the attribute holds
+    std::lock_guard<std::mutex> lk(m);
+    int& have = set[{kernel, dev}];
+    if (bytes <= have) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    have = bytes;
+}
 
 Profiler& profiler() {
     static Profiler p;

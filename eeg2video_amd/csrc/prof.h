@@ -35,6 +35,14 @@ inline float* dry_fake_ptr(size_t bytes) {                  // distinct, 256-byt
 
 namespace e2v {
 
+// Opt a kernel into its dynamic LDS size (hipFuncAttributeMaxDynamicSharedMemorySize; the default ceiling is 64 KB) -- once per
+// (kernel, DEVICE): the attribute belongs to the device's code object, so a context on another device has to set it again; the
+// largest size asked for so far is kept.  Never in a dry run: e2v_op_describe_dispatch makes no HIP call and leaves no state behind.
+void kattr_max_lds(const void* kernel, int bytes);
+}  // namespace e2v
+#define E2V_KATTR(kernel, bytes) ::e2v::kattr_max_lds(reinterpret_cast<const void*>(kernel), (int)(bytes))
+namespace e2v {
+
 struct ProfEntry {
     std::string name;
     double flops, bytes;

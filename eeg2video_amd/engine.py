@@ -64,6 +64,7 @@ class Engine:
             raise _ERRORS.get(st, RuntimeError)(self.lib.e2v_last_error(None).decode())
         self.ctx = ctx
         self.ready = 0
+        self.compute_dtype = "fp32"
 
     def __del__(self):
         ctx, self.ctx = getattr(self, "ctx", None), None
@@ -112,10 +113,13 @@ class Engine:
         self._check(self.lib.e2v_finalize_weights(self.ctx, which))
         self.ready |= which
 
-    def set_compute_dtype(self, dtype: str) -> None:
-        """'fp32' (default, parity configuration) or 'bf16' (bf16 MFMA with fp32 accumulate for convs / linears)."""
-        code = {"fp32": _lib.E2V_F32, "f32": _lib.E2V_F32, "bf16": _lib.E2V_BF16, "f32x3": _lib.E2V_F32X3}[dtype]
+    def set_compute_dtype(self, dtype) -> None:
+        """'fp32' (default, parity configuration), 'bf16' (BASELINE configs[2]: bf16 MFMA, bf16 activations in HBM, fp32 accumulate /
+        statistics / softmax) or 'fp16' (the same kernels on IEEE half: the reference's own inference dtype,
+        ``inference_eeg2video.py:69-70`` ``torch_dtype=torch.float16``).  A ``torch.dtype`` is accepted too."""
+        code = compute_dtype_code(dtype)
         self._check(self.lib.e2v_set_compute_dtype(self.ctx, code))
+        self.compute_dtype = {_lib.E2V_F32: "fp32", _lib.E2V_F16: "fp16", _lib.E2V_BF16: "bf16", _lib.E2V_F32X3: "f32x3"}[code]
 
     def set_conv_algo(self, algo: str) -> None:
         """'auto' (default: Winograd F(2x2,3x3) for the wide stride-1 3x3 convs, direct implicit GEMM elsewhere),
@@ -452,6 +456,17 @@ class Engine:
         return out
 
 
+def compute_dtype_code(dtype) -> int:
+    """The ``e2v_dtype`` of an arithmetic mode named as a string or as the ``torch.dtype`` a caller of the reference passes."""
+    names = {"fp32": _lib.E2V_F32, "f32": _lib.E2V_F32, "float32": _lib.E2V_F32, "bf16": _lib.E2V_BF16, "bfloat16": _lib.E2V_BF16,
+             "fp16": _lib.E2V_F16, "f16": _lib.E2V_F16, "half": _lib.E2V_F16, "float16": _lib.E2V_F16, "f32x3": _lib.E2V_F32X3}
+    if isinstance(dtype, torch.dtype):
+        dtype = str(dtype).replace("torch.", "")
+    if dtype not in names:
+        raise ValueError(f"compute dtype {dtype!r}: one of {sorted(names)}")
+    return names[dtype]
+
+
 def describe_dispatch(dtype: str = "bf16", batch: int = 32, frames: int = 6, h: int = 36, w: int = 64, tokens: int = 77, config=None):
     """Which kernel and tile every launch of ``e2v_generate`` (one guided DDIM step + decode of ``batch`` clips) takes, as a list of
     ``"<launches>x <class> <shape> -> <kernel> <tile>"`` lines -- ``e2v_op_describe_dispatch`` on a host-only context: no GPU, no
@@ -466,7 +481,7 @@ def describe_dispatch(dtype: str = "bf16", batch: int = 32, frames: int = 6, h: 
     if lib.e2v_create(C.byref(cfg), -1, C.byref(ctx)) != _lib.E2V_OK:
         raise RuntimeError("e2v_create(host-only) failed")
     try:
-        code = {"fp32": _lib.E2V_F32, "bf16": _lib.E2V_BF16}[dtype]
+        code = compute_dtype_code(dtype)
         need = C.c_int64(0)
         st = lib.e2v_op_describe_dispatch(ctx, code, batch, frames, h, w, tokens, None, 0, C.byref(need))
         if st != _lib.E2V_OK:

@@ -57,9 +57,10 @@ class TuneAVideoPipeline:
         (``inference_eeg2video.py:70``) for a LOCAL Stable-Diffusion directory: ``model_index.json`` names the components,
         ``vae/`` (config.json + weights) and ``scheduler/scheduler_config.json`` (DDIM in the tuned checkpoints, PNDM in the
         stock SD-v1-4 one; any of the six types the constructor accepts) are loaded here, components passed in are used as
-        they are.  The VAE is created on the UNet's engine so that the fused device loop applies.  ``torch_dtype`` is accepted
-        for drop-in use: checkpoints of any float type are widened to fp32 at load and the arithmetic is chosen with
-        ``pipe.unet.engine.set_compute_dtype`` (fp32 by default; ``"bf16"`` is the reduced-precision mode of this library)."""
+        they are.  The VAE is created on the UNet's engine so that the fused device loop applies.  Checkpoints of any float type are
+        widened to fp32 at load; ``torch_dtype`` selects the ARITHMETIC of the shared engine as it does for the reference pipeline:
+        ``torch.float16`` (the reference script) -> the fp16 mode, ``torch.bfloat16`` -> the bf16 mode, ``torch.float32`` -> fp32,
+        ``None`` -> whatever the UNet passed in was set to (``pipe.unet.engine.set_compute_dtype`` changes it afterwards)."""
         import json
         import os
         index_file = os.path.join(pretrained_model_path, "model_index.json")
@@ -86,6 +87,8 @@ class TuneAVideoPipeline:
                 tokenizer = CLIPTokenizer.from_pretrained(os.path.join(pretrained_model_path, "tokenizer"))
             except Exception:
                 tokenizer = None
+        if torch_dtype is not None:
+            unet.to(torch_dtype)
         return cls(vae=vae, tokenizer=tokenizer, unet=unet, scheduler=scheduler)
 
     # -- small API of DiffusionPipeline the callers use ------------------------------------------------
@@ -95,7 +98,8 @@ class TuneAVideoPipeline:
 
     _execution_device = device
 
-    def to(self, *a, **k):
+    def to(self, *a, **k):                  # a device is a no-op; a floating dtype selects the arithmetic (see UNet3DConditionModel.to)
+        self.unet.to(*a, **k)
         return self
 
     def enable_vae_slicing(self):                                                                # :115-116

@@ -141,14 +141,26 @@ class UNet3DConditionModel:
     def device(self) -> torch.device:
         return self.engine.device
 
-    def to(self, *args, **kwargs):          # weights live on the engine's GPU in fp32; a no-op for drop-in use
+    def to(self, *args, **kwargs):
+        """Weights live on the engine's GPU; a device argument is a no-op.  A floating dtype selects the ARITHMETIC as it does for
+        the reference module: ``.to(torch.float16)`` / ``torch_dtype=torch.float16`` (``inference_eeg2video.py:69-70``) = the fp16
+        mode, ``torch.bfloat16`` = the bf16 mode, ``torch.float32`` = the fp32 mode."""
+        dt = kwargs.get("dtype")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dt = a
+        if dt is not None and dt.is_floating_point:
+            self.engine.set_compute_dtype(dt)
         return self
 
     def eval(self):
         return self
 
-    def half(self):
-        return self
+    def half(self):                         # the reference's `.half()` run: the same kernels on IEEE half
+        return self.to(torch.float16)
+
+    def float(self):
+        return self.to(torch.float32)
 
     def requires_grad_(self, flag: bool = False):
         return self
@@ -240,9 +252,11 @@ class UNet3DConditionModel:
 
     @classmethod
     def from_pretrained(cls, pretrained_model_path, subfolder=None, torch_dtype=None, **kw):
-        """Local directory only (``inference_eeg2video.py:69``); ``torch_dtype`` is accepted and ignored
-        (weights are widened to fp32 at load)."""
-        return cls._from_dir(pretrained_model_path, subfolder, inflate_2d=False, **kw)
+        """Local directory only (``inference_eeg2video.py:69``).  Checkpoints of any float type are widened to fp32 at load (the
+        engine derives its own 16-bit layouts); ``torch_dtype`` selects the arithmetic as it does for the reference module:
+        ``torch.float16`` -> the fp16 mode (what the reference's inference script runs), ``torch.bfloat16`` -> bf16, else fp32."""
+        model = cls._from_dir(pretrained_model_path, subfolder, inflate_2d=False, **kw)
+        return model.to(torch_dtype) if torch_dtype is not None else model
 
     @classmethod
     def from_pretrained_2d(cls, pretrained_model_path, subfolder=None, **kw):

@@ -281,7 +281,7 @@ def test_temporal_attention(eng, d, f, hw):
     close(y, ref, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("d,f,hw", [(40, 6, 50), (80, 6, 33), (160, 6, 7)])
 def test_temporal_attention_wave_kernel_vs_staged_kernel(eng, mode, d, f, hw):
     """attn_temp (attention.py:261-267) has two kernels: temporal_attn_wave_kernel (registers only, the default) and the LDS-staged
@@ -290,7 +290,7 @@ def test_temporal_attention_wave_kernel_vs_staged_kernel(eng, mode, d, f, hw):
     heads, n = 8, 2
     c = heads * d
     qkv = rnd(n * f * hw, 3 * c, seed=254)
-    src = qkv.to(torch.bfloat16).float() if mode == "bf16" else qkv
+    src = qkv.to(H16_TYPES[mode]).float() if mode != "fp32" else qkv
     t = src.reshape(n, f, hw, 3 * c).permute(0, 2, 1, 3).reshape(n * hw, f, 3 * c)
     q, k, v = t[..., :c], t[..., c:2 * c], t[..., 2 * c:]
     ref = _unheads(_ref_attn(_heads(q, heads), _heads(k, heads), _heads(v, heads), d ** -0.5), heads)
@@ -305,7 +305,7 @@ def test_temporal_attention_wave_kernel_vs_staged_kernel(eng, mode, d, f, hw):
     finally:
         eng.set_knob("E2V_TATTN_WAVE", 1)
         eng.set_compute_dtype("fp32")
-    tol = 8e-3 if mode == "bf16" else 1e-4
+    tol = {"bf16": 8e-3, "fp16": 1e-3, "fp32": 1e-4}[mode]
     close(wave, ref, rtol=tol, atol=tol)
     close(staged, ref, rtol=tol, atol=tol)
     close(wave, staged, rtol=tol, atol=tol)
@@ -316,15 +316,36 @@ def test_temporal_attention_wave_kernel_vs_staged_kernel(eng, mode, d, f, hw):
 # runs in that mode (bgemm.hip LDS-DMA tiles, flash_attn_b16io, the bf16-I/O norm kernels).  GEMM-shaped ops return fp32, so
 # they are compared TIGHTLY with the same op on bf16-rounded operands in fp32 (summation order only), and loosely with
 # the fp32 op (bf16 has 8 mantissa bits).
+# The same tests run in BOTH 16-bit modes -- "bf16" (configs[2]) and "fp16" (IEEE half: the reference's own inference dtype,
+# inference_eeg2video.py:69-70) -- the kernels are one template over the element type (csrc/h16.h).  H16 holds the type the running
+# test was parametrised with; rb() rounds a reference operand the way that mode's kernels do.
+H16 = {"name": "bf16", "dtype": torch.bfloat16}
+H16_TYPES = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+@pytest.fixture(params=["bf16", "fp16"])
+def h16(request):
+    """Name of the 16-bit mode of this test instance (for `eng.set_compute_dtype(h16)`); rb() follows it."""
+    H16.update(name=request.param, dtype=H16_TYPES[request.param])
+    yield request.param
+    H16.update(name="bf16", dtype=torch.bfloat16)
+
+
 @pytest.fixture
-def bf(eng):
-    eng.set_compute_dtype("bf16")
+def bf(eng, h16):
+    eng.set_compute_dtype(h16)
     yield eng
     eng.set_compute_dtype("fp32")
 
 
 def rb(t):
-    return t.to(torch.bfloat16).float()
+    return t.to(H16["dtype"]).float()
+
+
+def tol16(bf16_tol, fp16_tol=None):
+    """Tolerance of "one rounding of the output" checks: the bf16 figure, or 1/4 of it in fp16 mode (three more mantissa bits: the errors
+    are 1/8, the bound keeps a factor of two of slack)."""
+    return bf16_tol if H16["name"] == "bf16" else (fp16_tol if fp16_tol is not None else bf16_tol / 4)
 
 
 def ab_build(eng):
@@ -339,8 +360,11 @@ def ab_build(eng):
 
 
 def gelu_bf16_grade(x):
-    """The GEGLU gate of the bf16-activation mode as the kernels evaluate it (igemm_epi.h: gelu_bf16_grade): x / (1 + exp(-(a x + b x^3))),
-    |error| <= 2.8e-4 against the exact erf form (bounded in tests/test_oracle_anchors.py)."""
+    """The GEGLU gate as the kernels of the running 16-bit mode evaluate it (igemm_epi.h: gelu_gate16).  bf16 mode:
+    x / (1 + exp(-(a x + b x^3))), |error| <= 2.8e-4 against the exact erf form (bounded in tests/test_oracle_anchors.py) -- 1/14 of a
+    bf16 rounding; fp16 mode rounds 8x finer and keeps the erf form (A&S 7.1.26, 1.5e-7) like fp32."""
+    if H16["name"] == "fp16":
+        return F.gelu(x)
     return x / (1.0 + torch.exp(-(1.60031415 * x + 0.06940179 * x ** 3)))
 
 
@@ -349,14 +373,14 @@ def test_bf16_conv_and_linear(bf):
     x, wt, b = rnd(n, c, h, w, seed=60), rnd(128, c, 3, 3, seed=61, scale=0.1), rnd(128, seed=62)
     y = from_cl(bf.op_conv3x3(to_cl(x).cuda(), wt.cuda(), b.cuda(), n_img=n, Hs=h, Ws=w), n, h, w)
     close(y, F.conv2d(rb(x), rb(wt), b, padding=1), rtol=1e-4, atol=1e-4)
-    close(y, F.conv2d(x, wt, b, padding=1), rtol=2e-2, atol=2e-2)
+    close(y, F.conv2d(x, wt, b, padding=1), rtol=tol16(2e-2), atol=tol16(2e-2))
     xl, wl, bl, r = rnd(300, 320, seed=63), rnd(960, 320, seed=64, scale=0.05), rnd(960, seed=65), rnd(300, 960, seed=66)
     close(bf.op_linear(xl.cuda(), wl.cuda(), bl.cuda(), r.cuda()), F.linear(rb(xl), rb(wl), bl) + r, rtol=1e-4, atol=1e-4)
     xg, wg, bg = rnd(200, 64, seed=67), rnd(512, 64, seed=68, scale=0.1), rnd(512, seed=69)
     hh, gg = F.linear(rb(xg), rb(wg), bg).chunk(2, dim=-1)
     yg = bf.op_linear(xg.cuda(), wg.cuda(), bg.cuda(), geglu=True)
     close(yg, hh * gelu_bf16_grade(gg), rtol=1e-4, atol=1e-4)           # the kernel's own gate formula: summation order only
-    close(yg, hh * F.gelu(gg), rtol=4e-4, atol=4e-4)                    # the exact erf form: + |value| x 2.8e-4 of the gate approximation
+    close(yg, hh * F.gelu(gg), rtol=tol16(4e-4, 1e-4), atol=tol16(4e-4, 1e-4))                    # the exact erf form: + |value| x 2.8e-4 of the gate approximation
     # input channels not a multiple of 8 (conv_in: 4 latent channels): zero-padded to the 16-byte granule, still bf16
     x4, w4 = rnd(1, 4, 5, 6, seed=70), rnd(64, 4, 3, 3, seed=71)
     close(from_cl(bf.op_conv3x3(to_cl(x4).cuda(), w4.cuda(), n_img=1, Hs=5, Ws=6), 1, 5, 6), F.conv2d(rb(x4), rb(w4), padding=1),
@@ -419,10 +443,10 @@ def test_bf16_norms_and_temporal_attention(bf):
     xin = torch.cat([rb(a), rb(s)], 1).reshape(samples, P, c0 + c1).permute(0, 2, 1)
     ref = F.silu(F.group_norm(xin, groups, g, be, 1e-5)).permute(0, 2, 1).reshape(samples * P, c0 + c1)
     y = bf.op_groupnorm(a.cuda(), g.cuda(), be.cuda(), samples=samples, P=P, groups=groups, eps=1e-5, silu=True, x1=s.cuda())
-    close(y, ref, rtol=8e-3, atol=8e-3)
+    close(y, ref, rtol=tol16(8e-3), atol=tol16(8e-3))
     x = rnd(77, 320, seed=34)
     gl, bl = rnd(320, seed=35), rnd(320, seed=36)
-    close(bf.op_layernorm(x.cuda(), gl.cuda(), bl.cuda()), F.layer_norm(rb(x), (320,), gl, bl), rtol=8e-3, atol=8e-3)
+    close(bf.op_layernorm(x.cuda(), gl.cuda(), bl.cuda()), F.layer_norm(rb(x), (320,), gl, bl), rtol=tol16(8e-3), atol=tol16(8e-3))
     d, f, hw, n, heads = 40, 6, 33, 2, 8
     c = heads * d
     qkv = rnd(n * f * hw, 3 * c, seed=37)
@@ -431,7 +455,7 @@ def test_bf16_norms_and_temporal_attention(bf):
     ref = _unheads(_ref_attn(_heads(q, heads), _heads(k, heads), _heads(v, heads), d ** -0.5), heads)
     ref = ref.reshape(n, hw, f, c).permute(0, 2, 1, 3).reshape(n * f * hw, c)
     y = bf.op_temporal_attention(qkv.cuda(), n=n, F=f, HW=hw, heads=heads, D=d, scale=d ** -0.5)
-    close(y, ref, rtol=8e-3, atol=8e-3)
+    close(y, ref, rtol=tol16(8e-3), atol=tol16(8e-3))
 
 
 @pytest.mark.parametrize("c,rows", [(320, 128), (640, 192), (1280, 64), (256, 320), (512, 64), (64, 128)])
@@ -461,8 +485,8 @@ def test_bf16_layernorm_sub_wave_rows(bf, c, rows):
         y0 = bf.op_layernorm(x.cuda(), gl.cuda(), bl.cuda())
     finally:
         bf.set_knob("E2V_LN_ROWS", 1)
-    close(y, ref, rtol=8e-3, atol=8e-3)
-    close(y, y0, rtol=8e-3, atol=8e-3)
+    close(y, ref, rtol=tol16(8e-3), atol=tol16(8e-3))
+    close(y, y0, rtol=tol16(8e-3), atol=tol16(8e-3))
 
 
 @pytest.mark.parametrize("c0,c1,groups,silu", [(320, 0, 32, True), (320, 320, 32, True), (640, 320, 32, True), (1280, 640, 32, False), (128, 0, 32, True)])
@@ -481,7 +505,7 @@ def test_bf16_groupnorm_row_tiled_and_sample_runs(bf, c0, c1, groups, silu):
     run = lambda: bf.op_groupnorm(a.cuda(), g.cuda(), be.cuda(), samples=samples, P=P, groups=groups, eps=1e-5, silu=silu,
                                   x1=s.cuda() if c1 else None)
     whole = run()
-    close(whole, ref, rtol=8e-3, atol=8e-3)
+    close(whole, ref, rtol=tol16(8e-3), atol=tol16(8e-3))
     if not ab_build(bf):
         return                                                # (the two other arms exist in `make AB=1` builds only)
     try:
@@ -492,18 +516,18 @@ def test_bf16_groupnorm_row_tiled_and_sample_runs(bf, c0, c1, groups, silu):
     finally:
         bf.set_knob("E2V_GN_ROWS", 1); bf.set_knob("E2V_GN_GROUP_MB", 0)
     assert torch.equal(whole, runs)
-    close(whole, flat, rtol=8e-3, atol=8e-3)
+    close(whole, flat, rtol=tol16(8e-3), atol=tol16(8e-3))
 
 
 @pytest.mark.parametrize("d,nq,f,n,mode", [(8, 108, 3, 2, 0), (16, 30, 4, 1, 0), (32, 9, 3, 2, 0), (40, 200, 6, 1, 0), (80, 144, 3, 1, 0),
                                            (160, 40, 6, 2, 0), (64, 70, 2, 1, 0), (40, 300, 3, 2, 1), (160, 40, 3, 2, 1)])
-def test_bf16_attention(eng, d, nq, f, n, mode):
+def test_bf16_attention(eng, d, nq, f, n, mode, h16):
     """bf16 MFMA attention (configs[2]): Q, K, V, P rounded to bf16, fp32 softmax / accumulate; tolerance 2e-2 of the
     output scale against the fp32 reference."""
     heads = 8 if d != 160 else 4
     c = heads * d
     try:
-        eng.set_compute_dtype("bf16")
+        eng.set_compute_dtype(h16)
         if mode == 0:
             qkv = rnd(n * f * nq, 3 * c, seed=80)
             q, k, v = (qkv[:, i * c:(i + 1) * c].reshape(n * f, nq, c) for i in range(3))
@@ -521,14 +545,14 @@ def test_bf16_attention(eng, d, nq, f, n, mode):
             ref = _unheads(_ref_attn(_heads(q.reshape(n * f, nq, c), heads), _heads(rep(k), heads), _heads(rep(v), heads), d ** -0.5), heads)
             gq, gkv = q.cuda(), kv.cuda()
             y = eng.op_attention(gq, gkv[:, :c], gkv[:, c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nk, mode=1, scale=d ** -0.5)
-        close(y.reshape(n * f, nq, c), ref, rtol=2e-2, atol=2e-2)
+        close(y.reshape(n * f, nq, c), ref, rtol=tol16(2e-2), atol=tol16(2e-2))
     finally:
         eng.set_compute_dtype("fp32")
 
 
 @pytest.mark.parametrize("d,nq,f,n,nk,qboost", [(40, 333, 6, 9, 77, 1.0), (80, 100, 3, 2, 77, 1.0), (160, 40, 3, 10, 77, 1.0), (40, 50, 2, 1, 96, 1.0),
                                                  (40, 70, 2, 3, 33, 1.0), (40, 200, 2, 2, 77, 30.0), (8, 45, 2, 1, 5, 1.0)])
-def test_bf16_cross_attention_resident_keys(eng, d, nq, f, n, nk, qboost):
+def test_bf16_cross_attention_resident_keys(eng, d, nq, f, n, nk, qboost, h16):
     """Cross-attention with the conditioning's K / V resident in LDS (cross_attn_resident_kernel: one-pass softmax over <= 96 keys, no
     barrier in the query loop): 77 keys and other counts (96 = all three key tiles full, 33, 5), >= 8 samples (whole samples per XCD)
     and fewer, a last query tile that is ragged, several tiles per wave, and queries scaled 30x so that |max score| > 8 takes the
@@ -544,7 +568,7 @@ def test_bf16_cross_attention_resident_keys(eng, d, nq, f, n, nk, qboost):
     gq, gkv = q.cuda(), kv.cuda()
     run = lambda: eng.op_attention(gq, gkv[:, :c], gkv[:, c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nk, mode=1, scale=d ** -0.5)
     try:
-        eng.set_compute_dtype("bf16")
+        eng.set_compute_dtype(h16)
         eng.set_knob("E2V_ATTN_CROSS_RESIDENT", 1)
         y = run()
         eng.set_knob("E2V_ATTN_CROSS_RESIDENT", 0)
@@ -552,8 +576,8 @@ def test_bf16_cross_attention_resident_keys(eng, d, nq, f, n, nk, qboost):
     finally:
         eng.set_knob("E2V_ATTN_CROSS_RESIDENT", 1)
         eng.set_compute_dtype("fp32")
-    close(y.reshape(n * f, nq, c), ref, rtol=2e-2, atol=2e-2)
-    close(y, y0, rtol=2e-2, atol=2e-2)
+    close(y.reshape(n * f, nq, c), ref, rtol=tol16(2e-2), atol=tol16(2e-2))
+    close(y, y0, rtol=tol16(2e-2), atol=tol16(2e-2))
     assert torch.isfinite(y).all()
 
 
@@ -651,7 +675,7 @@ def test_bf16_t256_geglu(bf256, m, k, n):
         finally:
             bf.set_knob("E2V_BGEMM_T256P", 1)
     close(outs[0], hh * gelu_bf16_grade(gg), rtol=1e-4, atol=1e-4)
-    close(outs[0], hh * F.gelu(gg), rtol=4e-4, atol=4e-4)
+    close(outs[0], hh * F.gelu(gg), rtol=tol16(4e-4, 1e-4), atol=tol16(4e-4, 1e-4))
     assert torch.equal(outs[0], outs[1])
 
 
@@ -756,11 +780,11 @@ def test_bf16_upsample_conv_sub_pixel_form(bf256, n, c, cout, hs, ws):
     close(from_cl(y, n, 2 * hs, 2 * ws), ref, rtol=1e-4, atol=1e-4)
     close(from_cl(y0, n, 2 * hs, 2 * ws), F.conv2d(F.interpolate(rb(x), scale_factor=2, mode="nearest"), rb(wt), b, padding=1), rtol=1e-4, atol=1e-4)
     assert not torch.equal(y, y0)                          # (the sub-pixel form did run: its weight rounding differs)
-    close(y, y0, rtol=4e-3, atol=4e-3)
+    close(y, y0, rtol=tol16(4e-3), atol=tol16(4e-3))
 
 
 @pytest.mark.parametrize("d,nq,f,n", [(40, 256, 3, 1), (40, 333, 4, 9), (40, 192, 2, 2), (40, 130, 3, 1), (40, 2304, 2, 1)])
-def test_bf16_attention_64_queries_per_wave(eng, d, nq, f, n):
+def test_bf16_attention_64_queries_per_wave(eng, d, nq, f, n, h16):
     """flash_attn_b16q64_kernel (attn_q64.hip; SparseCausalAttention, attention.py:272-328): a wave owns two 32-query blocks.  Whole
     workgroups of 4 / 3 / 2 waves (256 / 192 / 128 queries), a ragged last query block (333, 130: a wave whose second block is empty, a
     wave with no query at all), a ragged last key tile, >= 8 samples (whole samples per XCD) and fewer, frames 0 / 1 (one key segment) and
@@ -778,7 +802,7 @@ def test_bf16_attention_64_queries_per_wave(eng, d, nq, f, n):
     gather = lambda t: torch.cat([t.reshape(n, f, nq, c)[:, [0] * f], t.reshape(n, f, nq, c)[:, former]], dim=2).reshape(n * f, 2 * nq, c)
     ref = _unheads(_ref_attn(_heads(q, heads), _heads(gather(k), heads), _heads(gather(v), heads), d ** -0.5), heads)
     try:
-        eng.set_compute_dtype("bf16")
+        eng.set_compute_dtype(h16)
         g = qkv.cuda()
         run = lambda: eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5)
         ab = ab_build(eng)
@@ -795,14 +819,14 @@ def test_bf16_attention_64_queries_per_wave(eng, d, nq, f, n):
         eng.set_compute_dtype("fp32")
     # pipelined form: the reference maximum is a bf16 number carried in Q, so P rounds differently: same softmax, other roundings
     assert not torch.equal(y, y32)
-    close(y.reshape(n * f, nq, c), ref, rtol=1e-2, atol=1e-2)            # bf16 rounding of P and of the output
-    close(y32.reshape(n * f, nq, c), ref, rtol=1e-2, atol=1e-2)
-    close(y, y32, rtol=1e-2, atol=1e-2)
+    close(y.reshape(n * f, nq, c), ref, rtol=tol16(1e-2), atol=tol16(1e-2))            # bf16 rounding of P and of the output
+    close(y32.reshape(n * f, nq, c), ref, rtol=tol16(1e-2), atol=tol16(1e-2))
+    close(y, y32, rtol=tol16(1e-2), atol=tol16(1e-2))
     if ab:      # phase form: same MFMA sequence per (query, key tile) and the same maximum decisions per 32-query block as the 32-query kernel
         assert torch.equal(yp, y32)
 
 
-def test_bf16_attention_64_queries_per_wave_random_shapes(eng):
+def test_bf16_attention_64_queries_per_wave_random_shapes(eng, h16):
     """A sweep of ragged shapes through the 64-query kernel -- query counts that leave the last workgroup one, two, three or four waves,
     waves with one query block or none, key counts that end a 64-key stage after 1 .. 63 keys (marker-column masking) or exactly on
     it, 1 .. 6 frames (one or two key segments), fewer and more than 8 samples (the two XCD mappings) -- each against the 32-query
@@ -812,7 +836,7 @@ def test_bf16_attention_64_queries_per_wave_random_shapes(eng):
     heads, d = 8, 40
     c = heads * d
     try:
-        eng.set_compute_dtype("bf16")
+        eng.set_compute_dtype(h16)
         for case in range(14):
             nq = rng.choice([128, 129, 191, 192, 193, 255, 256, 257, 320, 383, 448, 511, 577, 640])
             f = rng.randint(1, 6)
@@ -826,13 +850,13 @@ def test_bf16_attention_64_queries_per_wave_random_shapes(eng):
             y32 = run()
             assert torch.isfinite(y).all(), (nq, f, n)
             err = (y - y32).abs().max().item() / (y32.abs().max().item() + 1e-30)
-            assert err < 1e-2, (nq, f, n, err)
+            assert err < tol16(1e-2), (nq, f, n, err)
     finally:
         eng.set_knob("E2V_ATTN_Q64", 1)
         eng.set_compute_dtype("fp32")
 
 
-def test_bf16_attention_64_queries_per_wave_huge_scores(eng):
+def test_bf16_attention_64_queries_per_wave_huge_scores(eng, h16):
     """The pipelined 64-query kernel carries a row's reference maximum in Q as the sum of two bf16 numbers.  Queries scaled 400x put
     the scores in the thousands (one bf16 number would be off by up to 16 there and a far larger factor beyond): the softmax is then
     nearly one-hot, must stay finite, and must pick the same keys as the fp32 reference on the bf16-rounded operands."""
@@ -848,17 +872,17 @@ def test_bf16_attention_64_queries_per_wave_huge_scores(eng):
     gather = lambda t: torch.cat([t.reshape(n, f, nq, c)[:, [0] * f], t.reshape(n, f, nq, c)[:, former]], dim=2).reshape(n * f, 2 * nq, c)
     ref = _unheads(_ref_attn(_heads(q, heads), _heads(gather(k), heads), _heads(gather(v), heads), d ** -0.5), heads)
     try:
-        eng.set_compute_dtype("bf16")
+        eng.set_compute_dtype(h16)
         g = qkv.cuda()
         y = eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5)
     finally:
         eng.set_compute_dtype("fp32")
     assert torch.isfinite(y).all()
-    close(y.reshape(n * f, nq, c), ref, rtol=2e-2, atol=2e-2)
+    close(y.reshape(n * f, nq, c), ref, rtol=tol16(2e-2), atol=tol16(2e-2))
 
 
 @pytest.mark.parametrize("boost", [3.0, 25.0])
-def test_bf16_attention_deferred_maximum_branches(eng, boost):
+def test_bf16_attention_deferred_maximum_branches(eng, boost, h16):
     """bf16 attention keeps a row's reference maximum until a score exceeds it by more than 2^8 (the rescale of the accumulators is
     a wave-level branch that would otherwise run on most key tiles).  Both sides of that threshold against a FULL fp32 reference on
     the bf16-rounded inputs: late keys (3rd and 5th 32-key tile, second key segment too) boosted 3x -- their scores top the running
@@ -869,14 +893,14 @@ def test_bf16_attention_deferred_maximum_branches(eng, boost):
     qkv = rnd(n * f * nq, 3 * c, seed=153)
     for key in (70, 150, 2 * nq + 130, nq + 190):
         qkv[key, c:2 * c] *= boost
-    qb = qkv.to(torch.bfloat16).float()
+    qb = rb(qkv)
     q, k, v = (qb[:, i * c:(i + 1) * c].reshape(n * f, nq, c) for i in range(3))
     former = torch.arange(f) - 1
     former[0] = 0
     gather = lambda t: torch.cat([t.reshape(n, f, nq, c)[:, [0] * f], t.reshape(n, f, nq, c)[:, former]], dim=2).reshape(n * f, 2 * nq, c)
     ref = _unheads(_ref_attn(_heads(q, heads), _heads(gather(k), heads), _heads(gather(v), heads), d ** -0.5), heads)
     try:
-        eng.set_compute_dtype("bf16")
+        eng.set_compute_dtype(h16)
         g = qkv.cuda()
         outs = []
         ab = ab_build(eng)
@@ -896,4 +920,97 @@ def test_bf16_attention_deferred_maximum_branches(eng, boost):
     if ab:
         assert torch.equal(outs[2], outs[1])                 # both sides of the threshold: the phase form and the 32-query kernel decide and round alike
     for y in outs:
-        close(y.reshape(n * f, nq, c), ref, rtol=2e-2, atol=2e-2)
+        close(y.reshape(n * f, nq, c), ref, rtol=tol16(2e-2), atol=tol16(2e-2))
+
+
+def _sparse_causal_ref(q, k, v, n, f, nq, c, heads, d):
+    former = torch.arange(f) - 1
+    former[0] = 0
+    gather = lambda t: torch.cat([t.reshape(n, f, nq, c)[:, [0] * f], t.reshape(n, f, nq, c)[:, former]], dim=2).reshape(n * f, 2 * nq, c)
+    return _unheads(_ref_attn(_heads(q, heads), _heads(gather(k), heads), _heads(gather(v), heads), d ** -0.5), heads)
+
+
+@pytest.mark.parametrize("q64", [1, 0])
+def test_h16_attention_hugely_negative_scores_with_a_ragged_key_stage(eng, h16, q64):
+    """Keys past the end of a segment (Nk % 64 != 0) are masked on the matrix pipe in the 64-query kernel: a marker column of their K rows
+    times a mask slot of Q.  The masked score is (-reference maximum) - marker^2, so the marker product must drown ANY reference: every
+    real score here sits near -46 000 (log2 units), where a mask of -2^15 (what the kernel used before round 5) would have turned the
+    padded keys into +13 000 -> exp2 overflow.  Both kernels (64- and 32-query), both 16-bit types, against fp32 on the rounded operands."""
+    heads, d, n, f, nq = 8, 40, 1, 3, 200                  # 200 keys: the last 64-key stage holds 8
+    c = heads * d
+    qkv = rnd(n * f * nq, 3 * c, seed=501)
+    for hh in range(heads):                                # 32 of a head's 40 dims carry +80 (q) / -80 (k): q . k ~ -204 800 per (query, key)
+        qkv[:, hh * d:hh * d + 32] = 80.0
+        qkv[:, c + hh * d:c + hh * d + 32] = -80.0
+    qs = d ** -0.5 * 1.4426950408889634
+    q = (rb(rb(qkv[:, :c]) * qs) / qs).reshape(n * f, nq, c)
+    k, v = (rb(qkv[:, i * c:(i + 1) * c]).reshape(n * f, nq, c) for i in (1, 2))
+    ref = _sparse_causal_ref(q, k, v, n, f, nq, c, heads, d)
+    assert (q[0, 0, :d] * k[0, 0, :d]).sum().item() * qs < -40000
+    try:
+        eng.set_compute_dtype(h16)
+        eng.set_knob("E2V_ATTN_Q64", q64)
+        g = qkv.cuda()
+        y = eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5)
+    finally:
+        eng.set_knob("E2V_ATTN_Q64", 1)
+        eng.set_compute_dtype("fp32")
+    assert torch.isfinite(y).all()
+    close(y.reshape(n * f, nq, c), ref, rtol=tol16(2e-2), atol=tol16(2e-2))
+
+
+@pytest.mark.parametrize("q64", [1, 0])
+def test_fp16_attention_scores_near_the_top_of_the_fp16_range(eng, q64):
+    """Range of the fp16 mode: the reference's .half() run stores q . k * scale as fp16, so scores up to 65 504 stay finite THERE.  The
+    kernels keep scores in log2 units (x 1.4427: up to 94 500) in fp32 accumulators; the one fp16 number that scales with them is the
+    reference maximum riding in Q in the 64-query kernel -- held as -m / 2 against marker columns of 2.0 (H16Traits<_Float16>).  Scores
+    near 5.2e4 (7.6e4 in log2 units, past fp16's 65 504): finite, and the softmax over the small differences is still right."""
+    H16.update(name="fp16", dtype=torch.float16)
+    try:
+        heads, d, n, f, nq = 8, 40, 1, 3, 256
+        c = heads * d
+        qkv = rnd(n * f * nq, 3 * c, seed=502)
+        for hh in range(heads):                            # 36 dims at 96 in q and k: q . k * scale ~ 52 460; 4 dims of noise: a real softmax
+            qkv[:, hh * d:hh * d + 36] = 96.0
+            qkv[:, c + hh * d:c + hh * d + 36] = 96.0
+        qs = d ** -0.5 * 1.4426950408889634
+        q = (rb(rb(qkv[:, :c]) * qs) / qs).reshape(n * f, nq, c)
+        k, v = (rb(qkv[:, i * c:(i + 1) * c]).reshape(n * f, nq, c) for i in (1, 2))
+        s00 = (q[0, 0, :d] * k[0, 0, :d]).sum().item() * d ** -0.5
+        assert 5.0e4 < s00 < 6.5504e4 and s00 * 1.4427 > 6.5504e4
+        ref = _sparse_causal_ref(q, k, v, n, f, nq, c, heads, d)
+        try:
+            eng.set_compute_dtype("fp16")
+            eng.set_knob("E2V_ATTN_Q64", q64)
+            g = qkv.cuda()
+            y = eng.op_attention(g[:, :c], g[:, c:2 * c], g[:, 2 * c:], n=n, F=f, heads=heads, D=d, Nq=nq, Nk=nq, mode=0, scale=d ** -0.5)
+        finally:
+            eng.set_knob("E2V_ATTN_Q64", 1)
+            eng.set_compute_dtype("fp32")
+        assert torch.isfinite(y).all()
+        close(y.reshape(n * f, nq, c), ref, rtol=1e-2, atol=1e-2)
+    finally:
+        H16.update(name="bf16", dtype=torch.bfloat16)
+
+
+def test_fp16_activations_near_the_top_of_the_fp16_range(eng):
+    """fp16 mode, values a .half() run of the reference can hold: a linear whose accumulators reach 5.8e4 -- and 7.7e4, past 65 504:
+    the accumulator is fp32 and the op entry returns it unrounded -- comes back exact; a stored fp16 tensor of +-6e4 goes through
+    GroupNorm (fp32 statistics: a sum of squares of 7e12) and comes out +-1."""
+    H16.update(name="fp16", dtype=torch.float16)
+    try:
+        eng.set_compute_dtype("fp16")
+        x = torch.full((256, 64), 30.0)
+        w = torch.zeros(320, 64)
+        w[:, :] = 30.0                                       # 64 * 900 = 57 600
+        w[7] = 40.0                                          # 64 * 1200 = 76 800 > 65 504
+        y = eng.op_linear(x.cuda(), w.cuda())                # the op entry returns fp32: the accumulator before the fp16 rounding
+        assert torch.isfinite(y).all() and y[0, 0].item() == 57600.0 and y[0, 7].item() == 76800.0
+        # through a stored fp16 tensor: GroupNorm in -> out rounds to fp16 storage
+        big = torch.full((64, 32), 6.0e4)
+        big[::2] = -6.0e4
+        out = eng.op_groupnorm(big.cuda(), torch.ones(32).cuda(), torch.zeros(32).cuda(), samples=1, P=64, groups=4, eps=1e-5, silu=False)
+        assert torch.isfinite(out).all() and (out.abs() - 1.0).abs().max().item() < 2e-3      # +-6e4 is representable: normalised to +-1
+    finally:
+        eng.set_compute_dtype("fp32")
+        H16.update(name="bf16", dtype=torch.bfloat16)
