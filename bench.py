@@ -231,12 +231,13 @@ def roofline_of(table, ddim_steps, B, dtype, value_per_gpu, kernel_table_path=""
                 traffic_source = f"profiles/pmc_dominant_kernel.json (static: {rec.get('_source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes')})"
         except Exception:
             traffic = None
-    mfma_peak = PEAK_BF16_MFMA_TFLOPS / 6 if dtype == "f32x3" else PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    # (v_mfma_f32_*_f16 and _bf16 run at the same dense rate: one 16-bit peak)
+    mfma_peak = PEAK_BF16_MFMA_TFLOPS / 6 if dtype == "f32x3" else PEAK_BF16_MFMA_TFLOPS if dtype in ("bf16", "fp16") else PEAK_F32_MFMA_TFLOPS
     if dom in HBM_BOUND:
         roof = {"bound": "hbm", "achieved": d["gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": d["gbps"] / PEAK_HBM_GBPS}
     else:
         # f32x3 executes 6 bf16 MFMA flops per fp32 flop counted: its fp32-equivalent ceiling is the bf16 peak / 6
-        peak = PEAK_BF16_MFMA_TFLOPS / 6 if "f32x3" in dom else PEAK_BF16_MFMA_TFLOPS if "bf16" in dom else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_BF16_MFMA_TFLOPS / 6 if "f32x3" in dom else PEAK_BF16_MFMA_TFLOPS if ("bf16" in dom or "fp16" in dom) else PEAK_F32_MFMA_TFLOPS
         roof = {"bound": "mfma", "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": d["tflops"] / peak}
     roof.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": dom, "launches": d["launches"],
                  "avg_launch_us": d["avg_us"], "flops_per_launch": d["flops"] / max(d["launches"], 1),

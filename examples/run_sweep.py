@@ -28,7 +28,7 @@ def main(argv=None, engine=None):
     ap.add_argument("--per-concept", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="clips per e2v_generate call")
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp16"])
     ap.add_argument("--out", default="", help="directory for <concept>_<k>.gif (empty: frames are produced but not written)")
     ap.add_argument("--npy", action="store_true", help="write .npy instead of .gif")
     args = ap.parse_args(argv)

@@ -40,3 +40,14 @@ def test_describe_needs_a_host_only_context_and_leaves_no_state():
     from eeg2video_amd.engine import describe_dispatch
     a, b = describe_dispatch("bf16", 1), describe_dispatch("bf16", 1)
     assert a == b and a != describe_dispatch("bf16", 32)
+
+
+@pytest.mark.parametrize("batch", [1, 32])
+def test_fp16_mode_takes_the_same_kernels_and_tiles_as_bf16(batch):
+    """The fp16 mode (E2V_F16: the reference's own inference dtype) is the SAME launch rules over the other instance of every 16-bit
+    kernel template (csrc/h16.h): its dispatch is the bf16 table with the two profile class names changed, launch for launch."""
+    from eeg2video_amd.engine import describe_dispatch
+    want = [l.replace("igemm_bf16", "igemm_fp16").replace("flash_attn_bf16", "flash_attn_fp16") for l in json.load(open(GOLDEN))[f"bf16_b{batch}"]]
+    got = describe_dispatch("fp16", batch)
+    if got != want:
+        pytest.fail("fp16 dispatch differs from bf16's:\n" + "\n".join(difflib.unified_diff(want, got, "bf16 golden (renamed)", "fp16", lineterm="", n=0)))
