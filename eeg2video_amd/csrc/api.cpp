@@ -699,6 +699,14 @@ e2v_status e2v_op_conv3x3(e2v_ctx* c, const float* x0, int c0, const float* x1, 
             g.Ho = Ho; g.Wo = Wo; g.Hi = Hi; g.Wi = Wi; g.Hs = Hs; g.Ws = Ws; g.stride = stride; g.pad = pad_lo;
             if (Hi != Hs || Wi != Ws) { g.upsample = 1; g.ups_h = (float)Hs / (float)Hi; g.ups_w = (float)Ws / (float)Wi; }
             g.a_bf16 = c->h16_mode; g.out_f32 = 1;
+            // test aid: E2V_SPLITK_FORCE = S runs the launch as split-K with S runs where it is eligible (the graph asks for it by itself
+            // in the small-batch family, model.cpp Runner::sk_setup)
+            static const int* const sk_force = knob("E2V_SPLITK_FORCE", 0);
+            Act skws;
+            if (*sk_force >= 2 && !g.upsample) {
+                const int runs = splitk_plan(g, *sk_force);
+                if (runs >= 2) { skws = Act(c->pool, (int64_t)runs * g.M, g.N); g.sk = *sk_force; g.sk_ws = skws.p; }
+            }
             if (c1 == 0 && c0p == c0 && bgemm_up2x_applies(g)) {   // exact 2x resize: the sub-pixel form the graph runner takes
                 const size_t n = 4 * (size_t)cout * conv_up2x_packed_ld(cin);
                 Act u32(c->pool, (int64_t)((n + 1023) / 1024), 1024), u16(c->pool, (int64_t)((n + 2047) / 2048), 1024);
@@ -796,6 +804,12 @@ e2v_status e2v_op_linear(e2v_ctx* c, const float* x, int ldx, int64_t M, int K, 
             g.a0 = a16.p; g.c0 = K8; g.lda0 = K8;
             g.a_bf16 = c->h16_mode; g.out_f32 = 1; g.w16 = w16.p; g.ldw16 = K8;
         }
+        static const int* const sk_force = knob("E2V_SPLITK_FORCE", 0);      // test aid, as in e2v_op_conv3x3
+        Act skws;
+        if (c->bf16_compute && *sk_force >= 2) {
+            const int runs = splitk_plan(g, *sk_force);
+            if (runs >= 2) { skws = Act(c->pool, (int64_t)runs * g.M, g.N); g.sk = *sk_force; g.sk_ws = skws.p; }
+        }
         Act w3;
         if (c->x3_compute) {
             const size_t n = (size_t)g.N * K;
@@ -827,6 +841,8 @@ e2v_status e2v_op_groupnorm(e2v_ctx* c, const float* x0, int c0, const float* x1
             cvt_rows(x0, c0, 0, b0.p, c0, c->h16_mode, rows, c0, c0, s);
             if (c1 > 0) { b1 = Act(c->pool, rows, c1, true); cvt_rows(x1, c1, 0, b1.p, c1, c->h16_mode, rows, c1, c1, s); }
             a.bf16 = c->h16_mode; a.x0 = b0.p; a.x1 = c1 > 0 ? b1.p : nullptr; a.out = bo.p;
+            static const int* const fused = knob("E2V_GN_FUSED_SMALL", 1);      // 2 (test aid): the one-kernel form of the small-batch family here too
+            a.fused_small = *fused == 2 ? 1 : 0;
             groupnorm(a, s);
             cvt_rows(bo.p, C, c->h16_mode, out, C, 0, rows, C, C, s);
         } else {

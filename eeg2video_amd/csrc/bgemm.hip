@@ -45,7 +45,8 @@ bool set_knob(const char* name, int value) {
         static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_256LIN", "E2V_BGEMM_256_MINROUNDS", "E2V_BGEMM_256", "E2V_BGEMM_T256",
                                             "E2V_BGEMM_T256_MINK", "E2V_BGEMM_T256_MINTILES", "E2V_BGEMM_T256P", "E2V_BGEMM_T256P_MAXK", "E2V_BGEMM_T256P_MINTILES",
                                             "E2V_BGEMM_T256P_BIAS_LDS", "E2V_ATTN_KT64", "E2V_ATTN_Q64", "E2V_ATTN_CROSS_RESIDENT", "E2V_TATTN_WAVE",
-                                            "E2V_GN_CHUNK_ROWS", "E2V_GN_CHUNK_ROWS_SMALL", "E2V_IGEMM_HALF_BELOW", "E2V_LN_ROWS", "E2V_BGEMM_UP2X"
+                                            "E2V_GN_CHUNK_ROWS", "E2V_GN_CHUNK_ROWS_SMALL", "E2V_IGEMM_HALF_BELOW", "E2V_LN_ROWS", "E2V_BGEMM_UP2X",
+                                            "E2V_SPLITK", "E2V_SPLITK_MIN_DEPTH", "E2V_SPLITK_FORCE", "E2V_GN_FUSED_SMALL"
 #ifdef E2V_AB                                // variants measured and not adopted / the other arm of an A/B: `make AB=1` builds only
                                             , "E2V_BGEMM_S3", "E2V_BGEMM_LIN", "E2V_BGEMM_T256_TAIL", "E2V_ATTN_FOLD", "E2V_ATTN_Q64P", "E2V_ATTN_Q64_NW", "E2V_GN_ROWS", "E2V_GN_GROUP_MB", "E2V_GN_SKIP_PARTIAL", "E2V_GN_RB", "E2V_GN_RB_EPILOGUE"
 #endif
@@ -73,7 +74,9 @@ __device__ __forceinline__ void static_for_taps(F&& f, std::integer_sequence<int
 
 // NST: LDS stages.  2: the next stage's DMA is in flight while this one is multiplied.  3 (one 512-thread workgroup per CU: nothing
 // else on the CU covers a wait): TWO stages in flight, the consumer waits with a counted vmcnt that leaves the younger one outstanding.
-template <typename H, int BM, int BN, int WGM, int WGN, int STAGE = 128 * 128 * 2, bool LIN = false, int NST = 2>      // H: bf16 / fp16 (h16.h); STAGE: stage stride, sized for the largest tile of the launch
+// (CALLER: a tag that only makes the specialisation distinct per calling kernel -- two kernels calling the SAME specialisation of this
+// inlined template fail the host pass of hipcc 7.2 with "no matching function: substitution failure" at the second call site)
+template <typename H, int BM, int BN, int WGM, int WGN, int STAGE = 128 * 128 * 2, bool LIN = false, int NST = 2, int CALLER = 0>      // H: bf16 / fp16 (h16.h); STAGE: stage stride, sized for the largest tile of the launch
 __device__ __forceinline__ void bgemm_tile(const IgemmArgs& p, const int rbg, const int n0, char* smem) {
     constexpr int BKE = 64;                         // bf16 elements per stage
     constexpr int ROWB = 128;                       // bytes per LDS tile row
@@ -844,6 +847,82 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const IgemmArgs p) {
     }
 }
 
+// ---- split-K: the small-batch dispatch family ------------------------------------------------------------------------------------
+// The reference generates clip by clip (inference_eeg2video.py:90-100): one clip is two UNet samples, and the deep levels then hand
+// the tile kernels 480 or 1728 rows -- 40 to 140 tiles of 128 x 128 for 256 CUs, each walking K = 11 520 .. 23 040 alone (measured at
+// B = 1: 95 TFLOP/s on the 5x8 level, 148 us per conv whose 29 MB of weights an idle chip streams in 10).  Here blockIdx.y cuts K into
+// runs of whole 64-channel chunks -- each inside ONE source of a concat, so a run is the same tile kernel on shifted pointers: source
+// rows + first channel, weight rows + first k of the run, no epilogue, fp32 partial tile to IgemmArgs::sk_ws[run] -- and
+// splitk_reduce_kernel adds the runs in order and applies the epilogue (bias, time-embedding row, residual, ReLU, one rounding).
+// Deterministic; equal to the unsplit kernels up to fp32 summation order (the family is held to the oracle bounds, not to bit-identity).
+template <typename H, bool LIN>
+__global__ __launch_bounds__(256) void bgemm_splitk_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_sk[];
+    IgemmArgs q = p;
+    const int run = blockIdx.y;
+    const bool src1 = run >= p.sk_s0;
+    const int per = src1 ? p.sk_q1 : p.sk_q0;
+    const int qlo = (src1 ? run - p.sk_s0 : run) * per;                  // first 64-channel chunk of the run, within its source
+    const int cseg = src1 ? p.c1 : p.c0;
+    const int clo = qlo * 64;
+    const int chi = min(cseg, clo + per * 64);
+    q.a0 = reinterpret_cast<const float*>(reinterpret_cast<const H*>(src1 ? p.a1 : p.a0) + clo);
+    q.lda0 = src1 ? p.lda1 : p.lda0;
+    q.c0 = chi - clo; q.c1 = 0; q.a1 = nullptr;
+    // first k of the run in a weight row: taps = 1: channel (c0 +) clo; 3x3: chunk-major [chunk][tap][64], chunks of source 1 behind source 0's
+    const long kfirst = p.taps == 1 ? (long)(src1 ? p.c0 : 0) + clo : (long)((src1 ? (p.c0 + 63) / 64 : 0) + qlo) * p.taps * 64;
+    q.w16 = reinterpret_cast<const char*>(p.w16) + kfirst * 2;
+    q.out = p.sk_ws + (size_t)run * p.M * p.N; q.ldc = p.N; q.out_f32 = 1;
+    q.bias = nullptr; q.rowbias = nullptr; q.resid = nullptr; q.alpha = 1.f; q.relu = 0;
+    const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
+    const int nrb = rb_hi - rb_lo;
+    const int per_rb = p.w1 + p.s1;
+    if (loc >= nrb * per_rb) return;
+    const int r = loc / per_rb, j = loc - r * per_rb;
+    if (j < p.w1) bgemm_tile<H, 128, 128, 2, 2, 128 * 128 * 2, LIN, 2, 1>(q, rb_lo + r, j * 128, smem_sk);
+    else bgemm_tile<H, 128, 64, 2, 2, 128 * 128 * 2, LIN, 2, 1>(q, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_sk);
+}
+
+// out[m][n .. n+3] = epilogue(sum over runs, run 0 first); one thread = four consecutive columns of a row
+template <typename H>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, const int runs) {
+    const int nq = p.N >> 2;
+    const long total = (long)p.M * nq;
+    const size_t plane = (size_t)p.M * p.N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / nq;
+        const int n = (int)(i - m * nq) * 4;
+        const float* src = p.sk_ws + (size_t)m * p.N + n;
+        f32x4 y = *reinterpret_cast<const f32x4*>(src);
+        for (int r = 1; r < runs; ++r) y += *reinterpret_cast<const f32x4*>(src + r * plane);
+        if (p.alpha != 1.0f) y *= p.alpha;
+        if (p.bias) y += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.rowbias) y += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)(m / p.rows_per_sample) * p.rb_ld + n);
+        if (p.resid) {
+            if (p.resid_bf16) {
+                const hx4<H> rr = *reinterpret_cast<const hx4<H>*>(reinterpret_cast<const H*>(p.resid) + (size_t)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] += (float)rr[e];
+            } else {
+                y += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + n);
+            }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+        }
+        if (p.out_f32) {
+            *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.ldc + n) = y;
+        } else {
+            hx4<H> o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (H)y[e];
+            *reinterpret_cast<hx4<H>*>(reinterpret_cast<H*>(p.out) + (size_t)m * p.ldc + n) = o;
+        }
+    }
+}
+
 // 256-row tiles: 8 waves (4 x 2, the same 64 x 64 wave tile), 256 x 128 and 256 x 64, 48 KB stages, one workgroup per CU.
 #ifdef E2V_AB          // the two-stage form of the 256-row tile (E2V_BGEMM_S3 = 0): the other arm of the A/B that adopted the three-stage ring
 template <typename H, bool LIN>
@@ -948,6 +1027,61 @@ bool bgemm_all_n64(const IgemmArgs& a) {
         if (lin) { E2V_KATTR((&KERNEL<H, true>), bytes); E2V_KLAUNCH((KERNEL<H, true>), grid, block, bytes, s, a); }           \
         else { E2V_KATTR((&KERNEL<H, false>), bytes); E2V_KLAUNCH((KERNEL<H, false>), grid, block, bytes, s, a); }             \
     })
+
+static int splitk_layout(const IgemmArgs& a, int want, int& s0, int& q0, int& q1) {
+    if (want < 2 || !a.a_bf16 || a.batch != 1 || a.geglu || a.rbsum || a.osy || (a.taps != 1 && a.taps != 9)) return 0;
+    if (((a.N | a.ldc) & 3) || (a.resid && (a.ldr & 3)) || (a.rowbias && (a.rb_ld & 3)) || a.M <= 0) return 0;
+    if (a.c1 > 0 && a.c0 % 64) return 0;                          // (a run starts on a whole chunk of the weight row)
+    const int Q0 = (a.c0 + 63) / 64, Q1 = (a.c1 + 63) / 64, Q = Q0 + Q1;
+    if (want > Q) want = Q;
+    if (want < 2) return 0;
+    int s1 = 0;
+    if (Q1 > 0) {
+        s0 = (int)((double)want * Q0 / Q + 0.5);
+        s0 = s0 < 1 ? 1 : (s0 > want - 1 ? want - 1 : s0);
+        s1 = want - s0;
+    } else {
+        s0 = want;
+    }
+    q0 = (Q0 + s0 - 1) / s0; s0 = (Q0 + q0 - 1) / q0;
+    q1 = 0;
+    if (Q1 > 0) { q1 = (Q1 + s1 - 1) / s1; s1 = (Q1 + q1 - 1) / q1; }
+    return s0 + s1 >= 2 ? s0 + s1 : 0;
+}
+int splitk_plan(const IgemmArgs& a, int want) {
+    int s0 = 0, q0 = 0, q1 = 0;
+    return splitk_layout(a, want, s0, q0, q1);
+}
+
+// igemm() has filled the 128-row tile schedule (full-size tiles: rb1 = nbm)
+void bgemm_splitk_launch(const IgemmArgs& a_in, hipStream_t s) {
+    IgemmArgs a = a_in;
+    const int runs = splitk_layout(a, a.sk, a.sk_s0, a.sk_q0, a.sk_q1);
+    if (runs < 2 || !a.sk_ws) throw Error(E2V_EINVAL, "split-K launch without a plan (splitk_plan) or workspace");
+    constexpr size_t smem = (size_t)2 * 128 * 128 * 2 + 9 * 128 * sizeof(unsigned);
+    const bool lin = a.taps == 1;
+    const double K = (double)a.taps * (a.c0 + a.c1);
+    const double rows_in = a.taps == 1 ? (double)a.M : (double)a.M * a.Hs * a.Ws / ((double)a.Ho * a.Wo);
+    std::string pname = a.a_bf16 == H16_FP16 ? "igemm_fp16" : "igemm_bf16";
+    if (prof_detail())
+        pname += " M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " K" + std::to_string((long)K) + " t" + std::to_string(a.taps) +
+                 (a.stride > 1 ? " s2" : "") + (a.upsample ? " up" : "") + (a.c1 ? " cat" : "");
+    ProfScope ps(pname.c_str(), 2.0 * a.M * a.N * K, 2.0 * rows_in * (a.c0 + a.c1) + 2.0 * a.N * K + (a.out_f32 ? 4.0 : 2.0) * a.M * a.N, s);
+    int per_xcd = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int nrb = (int)(((long)(x + 1) * a.nbm) >> 3) - (int)(((long)x * a.nbm) >> 3);
+        per_xcd = nrb > per_xcd ? nrb : per_xcd;
+    }
+    const dim3 grid(8 * per_xcd * (a.w1 + a.s1), runs, 1);
+    dry_tag(" -> bgemm_splitk_kernel 128x128 x" + std::to_string(runs) + " + splitk_reduce_kernel");
+    E2V_BG_LAUNCH(bgemm_splitk_kernel, grid, dim3(256), smem);
+    const long quads = (long)a.M * (a.N / 4);
+    const int blocks = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
+    h16_dispatch(a.a_bf16, [&](auto h16_tag) {
+        using H = decltype(h16_tag);
+        E2V_KLAUNCH(splitk_reduce_kernel<H>, dim3(blocks), dim3(256), 0, s, a, runs);
+    });
+}
 
 void bgemm_launch(const IgemmArgs& a_in, int ntiles, hipStream_t s) {
     IgemmArgs a = a_in;

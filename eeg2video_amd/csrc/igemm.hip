@@ -737,7 +737,9 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
     // bf16-activation launches with enough row blocks run 256-row tiles (bgemm256_kernel: 8 waves, one workgroup per CU): the
     // fill rate of a CU's LDS (~35 B/clk through L1) bounds a 128 x 128 x 64 bf16 tile at ~55 % of the matrix pipe; a 256 x 128
     // tile moves 0.75x the bytes per flop.  The schedule below is the same with 256-row blocks and 256 resident tiles.
-    const int BMrows = (a.a_bf16 && bgemm_use_256(a)) ? 256 : 128;
+    // split-K (the small-batch family, bgemm.hip): asked for by the caller (a.sk runs, a.sk_ws) and taken when the launch is eligible
+    const bool want_sk = a.a_bf16 && a.sk >= 2 && a.sk_ws && splitk_plan(a, a.sk) >= 2;
+    const int BMrows = (a.a_bf16 && !want_sk && bgemm_use_256(a)) ? 256 : 128;
     a.bm256 = BMrows == 256 ? 1 : 0;
     a.nbm_per = (a.M + BMrows - 1) / BMrows;
     const int nbm = a.nbm_per * a.batch;                     // batch entries are just more row blocks (dealt to the XCDs together)
@@ -761,13 +763,14 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
             (reinterpret_cast<uintptr_t>(a.a0) & 15) || (reinterpret_cast<uintptr_t>(a.a1) & 15))
             throw Error(E2V_ESHAPE, "bf16 GEMM: channel counts / row strides must be multiples of 8 (concat seam of a 3x3 conv: 64) and rows 16-byte aligned");
         a.ldw = a.ldw16;
-        if (bgemm_t256_launch(a, s)) return;                 // 256 x 256 / 256 x 320 deep-pipelined tiles (bgemm256.hip), by layer shape
+        if (!want_sk && bgemm_t256_launch(a, s)) return;     // 256 x 256 / 256 x 320 deep-pipelined tiles (bgemm256.hip), by layer shape
     }
     const char* cls = "igemm_f32";
     if (a.geglu) {                                           // the GEGLU epilogue pairs the two 32-column halves of a wave
         a.w1 = (a.N + 127) / 128; a.s1 = 0;
     } else if (a.w1 == 0) {                                  // N <= 64
         a.rb1 = 0;
+    } else if (want_sk) {                                    // full-size tiles: the runs multiply the workgroup count
     } else if (sched == 1) {
         // per XCD: 64 resident tiles per round.  Keep whole rounds of full-size tiles; if what is left of the XCD's
         // chunk is at most half a round, run it as half-size tiles (it then takes about half a round's time).
@@ -806,6 +809,7 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
         ntiles = t > ntiles ? t : ntiles;
     }
     ntiles *= 8;
+    if (want_sk) { bgemm_splitk_launch(a, s); return; }
     if (a.a_bf16) { bgemm_launch(a, ntiles, s); return; }
     if (use_x3) { launch_igemm_x3(a, ntiles, s); return; }
     if (k16 && !use_bf16 && a.taps == 1 && abl == 0) {

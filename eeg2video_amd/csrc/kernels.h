@@ -64,7 +64,19 @@ struct IgemmArgs {
     // rowblock_sums over the tensor instead -- same sums, bit for bit, so that which kernel serves a layer (a function of the
     // batch) never shows in a result.
     float* rbsum = nullptr;
+    // Split-K (bgemm.hip: bgemm_splitk_kernel + splitk_reduce_kernel; 16-bit modes, the SMALL-BATCH dispatch family -- the reference
+    // generates clip by clip, inference_eeg2video.py:90-100: two UNet samples leave a deep-level 3x3 conv 40 tiles for 256 CUs).
+    // sk >= 2 and sk_ws != null: the K range is cut into sk runs of whole 64-channel chunks (each inside one source of a concat), run
+    // z = blockIdx.y leaves its fp32 partial tile in sk_ws[z][M][N] and a second kernel adds the runs IN ORDER (run 0 first) and applies
+    // the epilogue -- deterministic, but a different summation order than the unsplit kernels: results are equal to theirs up to fp32
+    // rounding, not bit for bit (DESIGN: bit-identity across batch sizes holds within a dispatch family).  splitk_plan() sizes it.
+    int sk = 0;
+    float* sk_ws = nullptr;
+    int sk_s0 = 0, sk_q0 = 0, sk_q1 = 0;      // filled by the launcher: runs inside source 0, chunks per run in source 0 / source 1
 };
+// The split a launch of `a` would take for a request of `want` runs: 0 = none (the launch is not eligible), else the number of runs
+// actually used (<= want: whole chunks, every run non-empty); the caller then provides sk_ws of that many [M][N] fp32 planes.
+int splitk_plan(const IgemmArgs& a, int want);
 void igemm(const IgemmArgs& a, hipStream_t s);
 bool igemm_writes_rbsum(const IgemmArgs& a);       // will igemm(a) fill a.rbsum?  (same rules as the launch itself)
 // rows per lane pass of the canonical order: the staged epilogue of a 256 x 320 tile finishes 6 rows per pass, of a 256 x 256 tile 8
@@ -85,6 +97,7 @@ template <int V> inline const int* ab_const() { static const int v = V; return &
 #define E2V_AB_KNOB(name, dflt) ::e2v::ab_const<dflt>()
 #endif      // false: no kernel has asked for a knob of that name yet and it is not a known one
 void bgemm_launch(const IgemmArgs& a, int ntiles, hipStream_t s);
+void bgemm_splitk_launch(const IgemmArgs& a, hipStream_t s);            // the split-K form (a.sk, a.sk_ws; schedule filled by igemm())
 bool bgemm_all_n64(const IgemmArgs& a);
 bool bgemm_t256_writes_rbsum(const IgemmArgs& a);                         // bgemm256.hip: would that launch fill a.rbsum?
 bool bgemm_t256_launch(const IgemmArgs& a, hipStream_t s);                 // bgemm256.hip: true = the layer was eligible and has been launched
@@ -148,6 +161,9 @@ struct GroupNormArgs {
     // row-block sums that came with a source tensor (IgemmArgs::rbsum / rowblock_sums: [rows / 64][c_i][2]): the statistics pass
     // over that source is skipped and the fold reads them (needs P % 64 == 0; bf16 mode)
     const float* rb0 = nullptr; const float* rb1 = nullptr;
+    // small-batch dispatch family (16-bit modes): where a (sample, group) slice fits LDS, ONE kernel reads it once, folds and applies
+    // (gn_fused_small_kernel) instead of the three launches -- another summation order, so the family picks it, never the batch
+    int fused_small = 0;
 };
 // the canonical row-block sums of a stored bf16 tensor x[rows][C] (rows % 64 == 0): out[rows / 64][C][2], bit-identical to what the
 // staged epilogue of bgemm_t256_kernel leaves for a tensor of the same width (rpp = rbsum_rows_per_pass(C))

@@ -543,6 +543,25 @@ struct Runner {
         return o;
     }
 
+    // Small-batch family: ask for split-K where the launch leaves most of the chip idle AND K is deep enough to pay for the fp32
+    // partials (each run at least E2V_SPLITK_MIN_DEPTH deep: the partial planes cost 8 bytes per output and run, a run of depth d
+    // 2 d flops per output).  Returns the workspace the launch needs (kept alive by the caller until the launch is queued).
+    Act sk_setup(IgemmArgs& g) {
+        Act ws;
+        static const int* const on = knob("E2V_SPLITK", 1);
+        static const int* const min_depth = knob("E2V_SPLITK_MIN_DEPTH", 2048);
+        if (!c->small_family || !g.a_bf16 || !*on || *min_depth < 64) return ws;
+        const long K = (long)g.taps * (g.c0 + g.c1);
+        const long tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+        if (tiles >= 256 || K < 2L * *min_depth) return ws;
+        const int want = (int)std::min<long>(std::min<long>((512 + tiles - 1) / tiles, K / *min_depth), 16);
+        const int runs = splitk_plan(g, want);
+        if (runs < 2) return ws;
+        ws = Act(pool(), (int64_t)runs * g.M, g.N);
+        g.sk = want; g.sk_ws = ws.p;
+        return ws;
+    }
+
     void gn_ws(int samples, int P, int C) {
         const size_t need_p = (size_t)samples * groupnorm_chunks(P) * C * 2;
         const size_t need_s = (size_t)samples * C * 2;
@@ -577,6 +596,7 @@ struct Runner {
         a.samples = samples; a.P = P; a.groups = groups; a.eps = eps; a.silu = act ? 1 : 0;
         a.ws_part = c->gn_part; a.ws_scale = c->gn_scale;
         if (bf() && P % 64 == 0) { a.rb0 = rb0; a.rb1 = c1 > 0 ? rb1 : nullptr; }
+        a.fused_small = c->small_family ? 1 : 0;
         groupnorm(a, s);
         return out;
     }
@@ -631,6 +651,7 @@ struct Runner {
         g.resid = resid; g.ldr = ldr; g.M = (int)M; g.N = w.out; g.taps = 1; g.geglu = geglu ? 1 : 0;
         if (b16) { g.w16 = w16_of(w); g.a_bf16 = h16(); g.out_f32 = out_f32 ? 1 : 0; g.resid_bf16 = resid ? 1 : 0; }
         if (c->x3_compute && w.w3) { g.x3 = 1; g.w3 = w.w3; g.w3_plane = (long long)w.out * w.in; }
+        Act skws = sk_setup(g);
         igemm(g, s);
         return out;
     }
@@ -701,6 +722,7 @@ struct Runner {
             out.rb = pool().get((size_t)(out.rows / 64) * w.cout * 2);
             if (*rb_epi) { g.rbsum = out.rb; epilogue_sums = igemm_writes_rbsum(g); if (!epilogue_sums) g.rbsum = nullptr; }
         }
+        Act skws = sk_setup(g);
         igemm(g, s);
         if (epilogue_sums) dry_tag(" +rbsum");
         if (out.rb && !epilogue_sums) rowblock_sums(out.p, w.cout, w.cout, out.rows, rbsum_rows_per_pass(w.cout), out.rb, s);
@@ -893,6 +915,7 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
     // conditioning -- conv_in, the first resnet, the first transformer block up to its cross-attention -- is computed once
     E2V_REQUIRE(!cfg_pair || (N % 2 == 0 && n_t == 1 && !unet.down[0].attn.empty()), E2V_EINVAL, "cfg_pair needs an even batch, one timestep and a first block with attention");
     const int N1 = cfg_pair ? N / 2 : N;
+    small_family = N <= 4;                                    // B <= 2 clips with their guidance pairs (model.h)
     Runner R{this, s};
     const int heads = cfg.attention_heads, groups = cfg.norm_num_groups;
     const float eps = cfg.norm_eps;
@@ -1061,6 +1084,7 @@ void e2v_ctx::build_step_caches(const int64_t* ts, int steps, const float* cond,
 // -----------------------------------------------------------------------------------------------------
 void e2v_ctx::vae_decode_frames(const float* z_cl, int nf, int h, int w, float* out_cl, hipStream_t s) {
     E2V_REQUIRE(vae_ready, E2V_ESTATE, "VAE weights are not finalized");
+    small_family = nf <= 12;                                  // the frames of at most two clips
     Runner R{this, s};
     const int g = cfg.vae_norm_num_groups;
     const float eps = cfg.vae_norm_eps;
@@ -1101,6 +1125,7 @@ void e2v_ctx::vae_decode_frames(const float* z_cl, int nf, int h, int w, float* 
 
 void e2v_ctx::vae_encode_frames(const float* img_cl4, int n, int H0, int W0, float* moments_cl, hipStream_t s) {
     E2V_REQUIRE(vae_ready, E2V_ESTATE, "VAE weights are not finalized");
+    small_family = n <= 12;
     Runner R{this, s};
     const int g = cfg.vae_norm_num_groups;
     const float eps = cfg.vae_norm_eps;

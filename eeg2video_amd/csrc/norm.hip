@@ -428,6 +428,78 @@ __global__ __launch_bounds__(64) void gn_finalize_mixed_kernel(const float* __re
     }
 }
 
+// ---- one kernel for a small (sample, group): the small-batch family ---------------------------------------------------------------
+// Two UNet samples (the reference's clip-by-clip loop) turn the three-launch GroupNorm above -- statistics per row chunk, fold, apply --
+// into three dependent launches of a few dozen workgroups each: 38-46 us per call at the deep levels for tensors of 1-5 MB, 13 % of a
+// B = 1 pass.  Here ONE workgroup owns a (sample, group): its P x cpg slice (both sources of a concat; <= 144 KB as 16-bit) is read
+// once into LDS with the sums taken on the way, the fold is a workgroup reduction in fp64, and the affine (+ SiLU) is applied from LDS.
+// Pieces are channel PAIRS (4 bytes): cpg is even for every width of the model (10, 20, 30, 40, 60, 80) while 8-channel pieces would
+// straddle group boundaries.  Another summation order than the chunked path, so the choice is the dispatch family's (GroupNormArgs::
+// fused_small), never the batch's within a family.
+template <typename H, bool ACT>
+__global__ __launch_bounds__(1024) void gn_fused_small_kernel(const H* __restrict__ x0, const H* __restrict__ x1, int c0, int c1, int ld0,
+                                                             int ld1, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             H* __restrict__ out, int ldo, int P, int groups, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char gnf_lds[];
+    const int g = blockIdx.x, slab = blockIdx.y, tid = threadIdx.x;
+    const int Ctot = c0 + c1, cpg = Ctot / groups, ppr = cpg / 2;      // channel pairs per row of the slice
+    unsigned* const tile = reinterpret_cast<unsigned*>(gnf_lds);       // [P][ppr] packed pairs
+    float* const gb = reinterpret_cast<float*>(tile + (size_t)P * ppr);   // [2][cpg]: gamma, beta -> scale, shift
+    double* const red = reinterpret_cast<double*>(gb + 2 * cpg + ((2 * cpg) & 1));      // [2][16] wave sums (8-byte aligned: P * ppr + 2 cpg is even or padded)
+    const int cbase = g * cpg;
+    const size_t row0 = (size_t)slab * P;
+    const int items = P * ppr;
+    float s = 0.f, ss = 0.f;
+    for (int i = tid; i < items; i += 1024) {
+        const int r = i / ppr, c = cbase + 2 * (i - r * ppr);
+        const H* src = c < c0 ? x0 + (row0 + r) * ld0 + c : x1 + (row0 + r) * ld1 + (c - c0);
+        const unsigned u = *reinterpret_cast<const unsigned*>(src);
+        tile[i] = u;
+        const float a = h16_unpack_lo<H>(u), b = h16_unpack_hi<H>(u);
+        s += a + b;
+        ss = fmaf(a, a, fmaf(b, b, ss));
+    }
+    for (int c = tid; c < cpg; c += 1024) { gb[c] = gamma[cbase + c]; gb[cpg + c] = beta[cbase + c]; }
+    double ds = (double)s, dss = (double)ss;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { ds += __shfl_xor(ds, off); dss += __shfl_xor(dss, off); }
+    if ((tid & 63) == 0) { red[tid >> 6] = ds; red[16 + (tid >> 6)] = dss; }
+    __syncthreads();
+    double ts = 0.0, tss = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { ts += red[w]; tss += red[16 + w]; }      // every thread: the same order
+    const double cnt = (double)cpg * (double)P;
+    const double mean = ts / cnt;
+    double var = tss / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const float fr = (float)rstd, fm = (float)(mean * rstd);
+    for (int i = tid; i < items; i += 1024) {
+        const int r = i / ppr, cl = 2 * (i - r * ppr);
+        const unsigned u = tile[i];
+        // scale / shift as the chunked path forms them: (rstd * gamma) x + (beta - mean * rstd * gamma), both rounded to fp32 once
+        float a = fmaf(h16_unpack_lo<H>(u), fr * gb[cl], gb[cpg + cl] - fm * gb[cl]);
+        float b = fmaf(h16_unpack_hi<H>(u), fr * gb[cl + 1], gb[cpg + cl + 1] - fm * gb[cl + 1]);
+        if (ACT) { a = silu_f(a); b = silu_f(b); }
+        hx2<H> o;
+        o[0] = (H)a; o[1] = (H)b;
+        *reinterpret_cast<hx2<H>*>(out + (row0 + r) * ldo + cbase + cl) = o;
+    }
+}
+
+// Does the fused kernel serve this call?  16-bit rows, even group width and strides, the (sample, group) slice within 144 KB of LDS.
+static size_t gn_fused_small_bytes(const GroupNormArgs& a) {
+    const int Ctot = a.c0 + a.c1, cpg = Ctot / a.groups;
+    return (size_t)a.P * cpg * 2 + (size_t)(2 * cpg + 1) * 4 + 2 * 16 * 8 + 8;
+}
+static bool gn_fused_small_applies(const GroupNormArgs& a) {
+    static const int* const on = knob("E2V_GN_FUSED_SMALL", 1);
+    if (!*on || !a.fused_small || !a.bf16 || !a.out || a.rb0 || a.rb1) return false;
+    const int Ctot = a.c0 + a.c1, cpg = Ctot / a.groups;
+    if ((cpg & 1) || (a.c0 & 1) || ((a.ld0 | a.ld1 | a.ldo) & 1)) return false;
+    return gn_fused_small_bytes(a) <= (size_t)144 * 1024;
+}
+
 static std::string gn_shape_tag(const GroupNormArgs& a) {
     return " S" + std::to_string(a.samples) + " P" + std::to_string(a.P) + " C" + std::to_string(a.c0) + (a.c1 ? "+" + std::to_string(a.c1) : "") + " g" +
            std::to_string(a.groups);
@@ -533,6 +605,20 @@ void groupnorm(const GroupNormArgs& a, hipStream_t s) {
     std::string pname = a.silu ? "groupnorm_silu" : "groupnorm";
     if (prof_detail()) pname += gn_shape_tag(a);
     ProfScope ps(pname.c_str(), 8.0 * elems, 2.0 * (a.bf16 ? 2.0 : 4.0) * elems, s);   // algorithmic: read + write
+    if (gn_fused_small_applies(a)) {
+        const size_t smem = gn_fused_small_bytes(a);
+        dry_tag(" -> gn_fused_small_kernel");
+        h16_dispatch(a.bf16, [&](auto h16_tag) {
+            using H = decltype(h16_tag);
+            auto go = [&](auto kern) {
+                E2V_KATTR(kern, 144 * 1024);
+                E2V_KLAUNCH(kern, dim3(a.groups, a.samples), dim3(1024), smem, s, reinterpret_cast<const H*>(a.x0), reinterpret_cast<const H*>(a.x1),
+                            a.c0, a.c1, a.ld0, a.ld1, a.gamma, a.beta, reinterpret_cast<H*>(a.out), a.ldo, a.P, a.groups, a.eps);
+            };
+            if (a.silu) go(gn_fused_small_kernel<H, true>); else go(gn_fused_small_kernel<H, false>);
+        });
+        return;
+    }
     const size_t rows = (size_t)a.samples * a.P;
     const size_t total = rows * (Ctot / 4);
     const int blocks = (int)((total + 511) / 512 < 16384 ? (total + 511) / 512 : 16384);

@@ -1014,3 +1014,67 @@ def test_fp16_activations_near_the_top_of_the_fp16_range(eng):
     finally:
         eng.set_compute_dtype("fp32")
         H16.update(name="bf16", dtype=torch.bfloat16)
+
+
+# ------------------------------------------------------------------ split-K (the small-batch dispatch family, bgemm.hip) -------
+@pytest.mark.parametrize("runs", [2, 3, 5, 16])
+def test_h16_splitk_conv_and_linear_equal_the_unsplit_kernels_to_summation_order(bf, runs):
+    """bgemm_splitk_kernel + splitk_reduce_kernel (the reference's clip-by-clip loop, inference_eeg2video.py:90-100, leaves the deep
+    levels 40-140 tiles for 256 CUs): K cut into `runs` runs of whole 64-channel chunks, fp32 partial planes, an ordered reduce with the
+    epilogue.  E2V_SPLITK_FORCE puts the op entry points on it.  Against the same op on the unsplit kernels: fp32 summation order only
+    (1e-5 of the output scale) -- 3x3 convs with a concat (runs inside each source), time-embedding rows + residual, stride 2, a
+    ragged last row block, N = 320 (two 128 tiles + one 64) and N = 72; linears with K = 1280 / 2560 + bias + residual."""
+    def both(fn):
+        try:
+            bf.set_knob("E2V_SPLITK_FORCE", runs)
+            y = fn()
+        finally:
+            bf.set_knob("E2V_SPLITK_FORCE", 0)
+        return y, fn()
+    n_s, f, c0, c1, cout, h, w = 2, 3, 128, 64, 320, 5, 8
+    n = n_s * f
+    a, s = rnd(n, c0, h, w, seed=601), rnd(n, c1, h, w, seed=602)
+    wc, bc = rnd(cout, c0 + c1, 3, 3, seed=603, scale=0.1), rnd(cout, seed=604)
+    temb, res = rnd(n_s, cout, seed=605), rnd(n, cout, h, w, seed=606)
+    ga, gs, gw, gb, gt, gr = to_cl(a).cuda(), to_cl(s).cuda(), wc.cuda(), bc.cuda(), temb.cuda().contiguous(), to_cl(res).cuda()
+    y, y0 = both(lambda: bf.op_conv3x3(ga, gw, gb, x1=gs, n_img=n, Hs=h, Ws=w, rowbias=gt, rows_per_sample=f * h * w, resid=gr))
+    ref = F.conv2d(torch.cat([rb(a), rb(s)], 1), rb(wc), bc, padding=1) + temb.repeat_interleave(f, 0)[:, :, None, None] + res
+    assert not torch.equal(y, y0)                              # (the split form did run: another summation order)
+    close(y, y0, rtol=1e-5, atol=1e-5)
+    close(from_cl(y, n, h, w), ref, rtol=1e-4, atol=1e-4)
+    x2, w2, b2 = rnd(3, 256, 9, 12, seed=607), rnd(72, 256, 3, 3, seed=608, scale=0.1), rnd(72, seed=609)
+    g2, gw2, gb2 = to_cl(x2).cuda(), w2.cuda(), b2.cuda()
+    y, y0 = both(lambda: bf.op_conv3x3(g2, gw2, gb2, n_img=3, Hs=9, Ws=12, stride=2))
+    close(y, y0, rtol=1e-5, atol=1e-5)
+    close(from_cl(y, 3, 5, 6), F.conv2d(rb(x2), rb(w2), b2, stride=2, padding=1), rtol=1e-4, atol=1e-4)
+    for m, k, nn in [(480, 1280, 1280), (154, 2560, 320), (1000, 640, 72)]:
+        xl, wl, bl, r = rnd(m, k, seed=610), rnd(nn, k, seed=611, scale=0.05), rnd(nn, seed=612), rnd(m, nn, seed=613)
+        gx, gwl, gbl, grr = xl.cuda(), wl.cuda(), bl.cuda(), r.cuda()
+        y, y0 = both(lambda: bf.op_linear(gx, gwl, gbl, grr))
+        close(y, y0, rtol=1e-5, atol=1e-5)
+        close(y, F.linear(rb(xl), rb(wl), bl) + r, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("samples,P,c0,c1,groups,silu", [(2, 240, 1280, 0, 32, True), (2, 240, 1280, 1280, 32, True), (3, 864, 1280, 640, 32, True),
+                                                         (12, 144, 1280, 0, 32, False), (2, 50, 64, 32, 8, True), (1, 2304, 320, 0, 32, False)])
+def test_h16_groupnorm_one_kernel_form_of_the_small_batch_family(bf, samples, P, c0, c1, groups, silu):
+    """gn_fused_small_kernel (norm.hip): one workgroup per (sample, group) reads its P x cpg slice once (both sources of a concat, groups
+    that straddle the seam: 1920 / 32 = 60 does not divide 1280), folds in fp64 and applies from LDS -- the small-batch family's
+    GroupNorm where the slice fits 144 KB.  Against torch on the rounded inputs to one output rounding, and against the three-launch
+    path (same statistics to fp32 rounding: the outputs agree to one rounding of the 16-bit type)."""
+    a = rnd(samples * P, c0, seed=700) * 2.0 + 0.3
+    s = rnd(samples * P, c1, seed=701) if c1 else None
+    g, be = rnd(c0 + c1, seed=702), rnd(c0 + c1, seed=703)
+    xin = (torch.cat([rb(a), rb(s)], 1) if c1 else rb(a)).reshape(samples, P, c0 + c1).permute(0, 2, 1)
+    ref = F.group_norm(xin, groups, g, be, 1e-5)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1).reshape(samples * P, c0 + c1)
+    ga, gs, gg, gb = a.cuda(), (s.cuda() if c1 else None), g.cuda(), be.cuda()
+    run = lambda: bf.op_groupnorm(ga, gg, gb, samples=samples, P=P, groups=groups, eps=1e-5, silu=silu, x1=gs)
+    try:
+        bf.set_knob("E2V_GN_FUSED_SMALL", 2)
+        y = run()
+    finally:
+        bf.set_knob("E2V_GN_FUSED_SMALL", 1)
+    y0 = run()
+    close(y, ref, rtol=tol16(8e-3), atol=tol16(8e-3))
+    close(y, y0, rtol=tol16(8e-3), atol=tol16(8e-3))
