@@ -46,7 +46,7 @@ bool set_knob(const char* name, int value) {
                                             "E2V_BGEMM_T256_MINK", "E2V_BGEMM_T256_MINTILES", "E2V_BGEMM_T256P", "E2V_BGEMM_T256P_MAXK", "E2V_BGEMM_T256P_MINTILES",
                                             "E2V_BGEMM_T256P_BIAS_LDS", "E2V_ATTN_KT64", "E2V_ATTN_Q64", "E2V_ATTN_CROSS_RESIDENT", "E2V_TATTN_WAVE",
                                             "E2V_GN_CHUNK_ROWS", "E2V_GN_CHUNK_ROWS_SMALL", "E2V_IGEMM_HALF_BELOW", "E2V_LN_ROWS", "E2V_BGEMM_UP2X",
-                                            "E2V_SPLITK", "E2V_SPLITK_MIN_DEPTH", "E2V_SPLITK_FORCE", "E2V_GN_FUSED_SMALL"
+                                            "E2V_SPLITK", "E2V_SPLITK_MIN_DEPTH", "E2V_SPLITK_FORCE", "E2V_GN_FUSED_SMALL", "E2V_BGEMM_S3_SMALL", "E2V_SPLITK_MAX_TILES"
 #ifdef E2V_AB                                // variants measured and not adopted / the other arm of an A/B: `make AB=1` builds only
                                             , "E2V_BGEMM_S3", "E2V_BGEMM_LIN", "E2V_BGEMM_T256_TAIL", "E2V_ATTN_FOLD", "E2V_ATTN_Q64P", "E2V_ATTN_Q64_NW", "E2V_GN_ROWS", "E2V_GN_GROUP_MB", "E2V_GN_SKIP_PARTIAL", "E2V_GN_RB", "E2V_GN_RB_EPILOGUE"
 #endif
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const IgemmArgs p) {
 // rows + first channel, weight rows + first k of the run, no epilogue, fp32 partial tile to IgemmArgs::sk_ws[run] -- and
 // splitk_reduce_kernel adds the runs in order and applies the epilogue (bias, time-embedding row, residual, ReLU, one rounding).
 // Deterministic; equal to the unsplit kernels up to fp32 summation order (the family is held to the oracle bounds, not to bit-identity).
-template <typename H, bool LIN>
+template <typename H, bool LIN, int NST>      // NST = 3: the three-stage ring (one workgroup per CU: launches of at most ~one round)
 __global__ __launch_bounds__(256) void bgemm_splitk_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_sk[];
     IgemmArgs q = p;
@@ -880,8 +880,8 @@ __global__ __launch_bounds__(256) void bgemm_splitk_kernel(const IgemmArgs p) {
     const int per_rb = p.w1 + p.s1;
     if (loc >= nrb * per_rb) return;
     const int r = loc / per_rb, j = loc - r * per_rb;
-    if (j < p.w1) bgemm_tile<H, 128, 128, 2, 2, 128 * 128 * 2, LIN, 2, 1>(q, rb_lo + r, j * 128, smem_sk);
-    else bgemm_tile<H, 128, 64, 2, 2, 128 * 128 * 2, LIN, 2, 1>(q, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_sk);
+    if (j < p.w1) bgemm_tile<H, 128, 128, 2, 2, 128 * 128 * 2, LIN, NST, 1>(q, rb_lo + r, j * 128, smem_sk);
+    else bgemm_tile<H, 128, 64, 2, 2, 128 * 128 * 2, LIN, NST, 1>(q, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_sk);
 }
 
 // out[m][n .. n+3] = epilogue(sum over runs, run 0 first); one thread = four consecutive columns of a row
@@ -920,6 +920,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, c
             for (int e = 0; e < 4; ++e) o[e] = (H)y[e];
             *reinterpret_cast<hx4<H>*>(reinterpret_cast<H*>(p.out) + (size_t)m * p.ldc + n) = o;
         }
+    }
+}
+
+// 128-row tiles on the THREE-stage ring: launches of at most one round of workgroups (the small-batch operating point: two UNet
+// samples give a level-2 linear 140 tiles).  With a CU to itself a two-stage tile is bound by one L2 / HBM round trip per 64-deep stage
+// (measured at B = 1: 25 us for the 20 stages of a 1728 x 1280 x 1280 linear, 225 TFLOP/s); three 32 KB stages keep two in flight
+// behind a counted vmcnt.  Same k order, same epilogue: bit-identical to the other tile kernels (the choice may follow the launch size).
+template <typename H, bool LIN>
+__global__ __launch_bounds__(256) void bgemm_s3_kernel(const IgemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bgs3[];
+    const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int rb_lo = (int)(((long)x * p.nbm) >> 3), rb_hi = (int)(((long)(x + 1) * p.nbm) >> 3);
+    const int nrb = rb_hi - rb_lo;
+    const int tail = min(nrb, p.tail_rb);
+    const int per1 = p.w1 + p.s1;
+    const int n1 = (nrb - tail) * per1;
+    if (loc < n1) {
+        const int r = loc / per1, j = loc - r * per1;
+        if (j < p.w1) bgemm_tile<H, 128, 128, 2, 2, 128 * 128 * 2, LIN, 3, 2>(p, rb_lo + r, j * 128, smem_bgs3);
+        else bgemm_tile<H, 128, 64, 2, 2, 128 * 128 * 2, LIN, 3, 2>(p, rb_lo + r, p.w1 * 128 + (j - p.w1) * 64, smem_bgs3);
+    } else {
+        const int t = loc - n1;
+        if (t >= tail * p.s2) return;
+        const int r = t / p.s2;
+        bgemm_tile<H, 128, 64, 2, 2, 128 * 128 * 2, LIN, 3, 2>(p, rb_lo + (nrb - tail) + r, (t - r * p.s2) * 64, smem_bgs3);
     }
 }
 
@@ -1073,8 +1098,17 @@ void bgemm_splitk_launch(const IgemmArgs& a_in, hipStream_t s) {
         per_xcd = nrb > per_xcd ? nrb : per_xcd;
     }
     const dim3 grid(8 * per_xcd * (a.w1 + a.s1), runs, 1);
-    dry_tag(" -> bgemm_splitk_kernel 128x128 x" + std::to_string(runs) + " + splitk_reduce_kernel");
-    E2V_BG_LAUNCH(bgemm_splitk_kernel, grid, dim3(256), smem);
+    // at most ~one round of workgroups: the three-stage ring (one workgroup per CU, two stages in flight); more: two co-resident
+    // two-stage workgroups per CU cover each other's waits
+    const bool s3 = (long)grid.x * runs <= 320 && (a.taps == 9 || lin);
+    constexpr size_t smem3 = (size_t)3 * 128 * 128 * 2 + 9 * 128 * sizeof(unsigned);
+    dry_tag(" -> bgemm_splitk_kernel 128x128 x" + std::to_string(runs) + (s3 ? " s3" : "") + " + splitk_reduce_kernel");
+    h16_dispatch(a.a_bf16, [&](auto h16_tag) {
+        using H = decltype(h16_tag);
+        auto go = [&](auto kern, const size_t bytes) { E2V_KATTR(kern, bytes); E2V_KLAUNCH(kern, grid, dim3(256), bytes, s, a); };
+        if (s3) { if (lin) go(bgemm_splitk_kernel<H, true, 3>, smem3); else go(bgemm_splitk_kernel<H, false, 3>, smem3); }
+        else    { if (lin) go(bgemm_splitk_kernel<H, true, 2>, smem); else go(bgemm_splitk_kernel<H, false, 2>, smem); }
+    });
     const long quads = (long)a.M * (a.N / 4);
     const int blocks = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
     h16_dispatch(a.a_bf16, [&](auto h16_tag) {
@@ -1110,6 +1144,23 @@ void bgemm_launch(const IgemmArgs& a_in, int ntiles, hipStream_t s) {
     // E2V_BGEMM_PERS: 0 never, 1 where it measured faster (same-box A/B over every GEMM shape of a B = 32 pass, tools/shape_profile.py:
     // linears with a residual to read, K <= 2560: -3..-20 %; K = 320 and the K = 640 GEGLU without one: -4..-6 %; the wide
     // residual-free projections at K >= 640 and the 3x3 convs that are too small for 256-row tiles: +2..+6 %), 2 wherever it applies
+    // launches of at most one round of 128-row tiles: the three-stage ring (bgemm_s3_kernel), one workgroup per CU
+    static const int* const s3on = knob("E2V_BGEMM_S3_SMALL", 1);
+    if (*s3on && !a.bm256 && (a.taps == 9 || lin)) {
+        long real = 0;                                                                // tiles the grid really holds
+        for (int x = 0; x < 8; ++x) {
+            const int nrb = (int)(((long)(x + 1) * a.nbm) >> 3) - (int)(((long)x * a.nbm) >> 3);
+            const int tail = nrb < a.tail_rb ? nrb : a.tail_rb;
+            real += (long)(nrb - tail) * (a.w1 + a.s1) + (long)tail * a.s2;
+        }
+        const int nk = a.taps * ((a.c0 + 63) / 64 + (a.c1 + 63) / 64);
+        if (real <= 256 && nk >= 4) {
+            constexpr size_t smem3 = (size_t)3 * 128 * 128 * 2 + 9 * 128 * sizeof(unsigned);
+            dry_tag(" -> bgemm_s3_kernel 128x128 s3");
+            E2V_BG_LAUNCH(bgemm_s3_kernel, dim3(ntiles, 1, 1), dim3(256), smem3);
+            return;
+        }
+    }
     static const int* const persp = knob("E2V_BGEMM_PERS", 1);
     const int Kc = a.c0 + a.c1;
     const int pers = *persp == 2 ? 1 : *persp == 0 ? 0 : (a.taps == 1 && (a.resid ? Kc <= 2560 : (Kc <= 320 || (a.geglu && Kc <= 640))));

@@ -550,10 +550,11 @@ struct Runner {
         Act ws;
         static const int* const on = knob("E2V_SPLITK", 1);
         static const int* const min_depth = knob("E2V_SPLITK_MIN_DEPTH", 2048);
+        static const int* const max_tiles = knob("E2V_SPLITK_MAX_TILES", 256);
         if (!c->small_family || !g.a_bf16 || !*on || *min_depth < 64) return ws;
         const long K = (long)g.taps * (g.c0 + g.c1);
         const long tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-        if (tiles >= 256 || K < 2L * *min_depth) return ws;
+        if (tiles >= *max_tiles || K < 2L * *min_depth) return ws;
         const int want = (int)std::min<long>(std::min<long>((512 + tiles - 1) / tiles, K / *min_depth), 16);
         const int runs = splitk_plan(g, want);
         if (runs < 2) return ws;
@@ -702,7 +703,10 @@ struct Runner {
             g.ups_h = (float)geo.H / (float)Hi;        // torch: scale = (float)input_size / output_size
             g.ups_w = (float)geo.W / (float)Wi;
         }
-        if (bf() && c0 == w.cin && bgemm_up2x_applies(g)) {       // exact 2x resize (Upsample3D): four 2x2 convs on the source map
+        // (small-batch family: the four parity launches of a small layer are a handful of 256-row tiles each -- 131 us per launch
+        // measured at B = 1 on the 9x16 -> 18x32 conv -- while the gather form takes split-K: the sub-pixel form needs >= 128 tiles)
+        const bool up2x_small = c->small_family && (long)((out.rows / 4 + 255) / 256) * ((w.cout + 319) / 320) < 128;
+        if (bf() && c0 == w.cin && !up2x_small && bgemm_up2x_applies(g)) {       // exact 2x resize (Upsample3D): four 2x2 convs on the source map
             c->conv_form(w, fp16() ? e2v_ctx::FORM_F16_UP2 : e2v_ctx::FORM_BF16_UP2, s);
             bgemm_up2x_launch(g, fp16() ? w.w16h_up2 : w.w16_up2, s);
             return out;

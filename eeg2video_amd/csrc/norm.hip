@@ -497,6 +497,10 @@ static bool gn_fused_small_applies(const GroupNormArgs& a) {
     if (!*on || !a.fused_small || !a.bf16 || !a.out || a.rb0 || a.rb1) return false;
     const int Ctot = a.c0 + a.c1, cpg = Ctot / a.groups;
     if ((cpg & 1) || (a.c0 & 1) || ((a.ld0 | a.ld1 | a.ldo) & 1)) return false;
+    // a slice row is cpg x 2 contiguous bytes of a Ctot x 2-byte tensor row: below 64 bytes the reads waste most of every sector they
+    // touch and the chunked path (whole rows, coalesced) wins unless the slice is tiny (measured at B = 1, profiles/r05_shape_ab_b1_*:
+    // cpg 10 / 20 at 46 / 138 KB: 1.9x / 1.4x slower; cpg 40 / 80 at 19 .. 138 KB: 0.23 .. 0.58x)
+    if (cpg < 32 && (size_t)a.P * cpg * 2 > (size_t)24 * 1024) return false;
     return gn_fused_small_bytes(a) <= (size_t)144 * 1024;
 }
 

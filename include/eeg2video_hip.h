@@ -229,8 +229,12 @@ int64_t e2v_profile_end(e2v_ctx* ctx, char* json, int64_t cap);
 /* Arithmetic and storage of the graph's tensors: E2V_F32 (default; fp32 MFMA, fp32 activations, the parity configuration of
  * BASELINE configs[1]) or E2V_BF16 (BASELINE configs[2]: every tensor the graph stores between kernels is bf16 in HBM, bf16
  * MFMA with fp32 accumulation; what stays fp32: the latents / DDIM state, eps, the decoded frames, VAE moments and attention
- * scores, GroupNorm / LayerNorm statistics, softmax, the time-embedding MLP).  The boundary tensors of this header are fp32 in
- * both modes.  Takes effect for the following calls.
+ * scores, GroupNorm / LayerNorm statistics, softmax, the time-embedding MLP) or E2V_F16 (the same kernels on IEEE half --
+ * v_mfma_f32_*_f16, fp16 rows in HBM, fp32 everything listed above: the reference's own inference arithmetic,
+ * EEG2Video/inference_eeg2video.py:69-70,76,81 `torch_dtype=torch.float16`, pipelines/pipeline_tuneeeg2video.py:150; three more
+ * mantissa bits than bf16 -- every block within 2e-3 of the fp32 oracle where bf16 sits at 1.6e-2 -- at fp16's range: a stored
+ * activation beyond 65 504 becomes inf exactly where the reference's .half() run would).  The boundary tensors of this header are
+ * fp32 in every mode.  Takes effect for the following calls (the fp16 weight copies are derived on first use).
  * E2V_F32X3 (opt-in, experimental): fp32 results from the bf16 matrix pipe -- every operand of a linear / Winograd-domain
  * GEMM is split exactly into three bf16 pieces and the six significant piece products are accumulated in fp32 (error at
  * the level of the fp32 FMA chain); must be selected BEFORE e2v_finalize_weights (the weights are split there), else
