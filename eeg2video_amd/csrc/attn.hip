@@ -32,30 +32,44 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // -- read by the 18 query blocks of all 8 heads of that frame and, as the "previous frame", of the next one -- are fetched into
 // ONE L2 instead of all eight (PMC at level 0, B = 32, with the former (query block, head, sample-frame) 3-D grid: 30 GB through
 // the fabric per launch against 2.3 GB of q, k, v, o; L2 hit rate 0.64).  Placement is a speed matter only.
+// The unit dealt to an XCD is the coarsest one that still divides evenly over the 8 XCDs (round 5; it used to be "samples when n >= 8,
+// else sample-frames", which at the reference's clip-by-clip operating point -- 2 samples x 6 frames = 12 units -- gave four XCDs two
+// frames and four XCDs one: a third of the chip idle for the launch's last third): whole samples when n % 8 == 0, else sample-frames
+// when n F % 8 == 0, else (sample-frame, head) pairs (8 heads: always even).
 struct AttnBlock { int qb, head, sf; bool valid; };
-__device__ __forceinline__ AttnBlock attn_block(const AttnArgs& p) {
-    const int nqb = (p.Nq + 127) / 128;
+__host__ __device__ __forceinline__ int attn_xcd_unit(const int n, const int F, const int heads) {
+    return n % 8 == 0 ? 0 : (n * F) % 8 == 0 ? 1 : 2;
+}
+__device__ __forceinline__ AttnBlock attn_block_of(const AttnArgs& p, const int nqb) {
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
     const int S = p.n * p.F;
+    const int unit = attn_xcd_unit(p.n, p.F, p.heads);
     AttnBlock r;
-    if (p.n >= 8) {                                  // units = samples
+    if (unit == 0) {                                 // units = samples
         const int per = p.F * p.heads * nqb;
         const int ul = idx / per, w = idx - ul * per;
         const int smp = ul * 8 + xcd;
         const int f = w / (p.heads * nqb), w2 = w - f * (p.heads * nqb);
         r.sf = smp * p.F + f; r.head = w2 / nqb; r.qb = w2 - r.head * nqb; r.valid = smp < p.n;
-    } else {                                         // units = sample-frames
+    } else if (unit == 1) {                          // units = sample-frames
         const int per = p.heads * nqb;
         const int ul = idx / per, w = idx - ul * per;
         r.sf = ul * 8 + xcd; r.head = w / nqb; r.qb = w - r.head * nqb; r.valid = r.sf < S;
+    } else {                                         // units = (sample-frame, head) pairs
+        const int ul = idx / nqb;
+        const int pair = ul * 8 + xcd;
+        r.qb = idx - ul * nqb; r.sf = pair / p.heads; r.head = pair - r.sf * p.heads; r.valid = pair < S * p.heads;
     }
     return r;
 }
-static inline unsigned attn_grid(const AttnArgs& a) {
-    const unsigned nqb = (a.Nq + 127) / 128;
-    if (a.n >= 8) return 8u * ((a.n + 7) / 8) * (unsigned)(a.F * a.heads) * nqb;
-    return 8u * ((a.n * a.F + 7) / 8) * (unsigned)a.heads * nqb;
+__device__ __forceinline__ AttnBlock attn_block(const AttnArgs& p) { return attn_block_of(p, (p.Nq + 127) / 128); }
+static inline unsigned attn_grid_of(const AttnArgs& a, const unsigned nqb) {
+    const int unit = attn_xcd_unit(a.n, a.F, a.heads);
+    if (unit == 0) return 8u * (a.n / 8) * (unsigned)(a.F * a.heads) * nqb;
+    if (unit == 1) return 8u * ((a.n * a.F) / 8) * (unsigned)a.heads * nqb;
+    return 8u * ((a.n * a.F * a.heads + 7) / 8) * nqb;
 }
+static inline unsigned attn_grid(const AttnArgs& a) { return attn_grid_of(a, (a.Nq + 127) / 128); }
 
 // shape tag of a launch for the detailed profile / the dispatch record
 std::string attn_shape_tag(const AttnArgs& a) {
@@ -618,13 +632,21 @@ __global__ __launch_bounds__(256) void cross_attn_resident_kernel(const AttnArgs
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    // block -> (sample, head, chunk of the sample's rows); XCD b & 7 takes whole samples (the sample's K / V and its neighbours' Q lines in one L2)
+    // block -> (sample, head, chunk of the sample's rows); XCD b & 7 takes whole samples (the sample's K / V and its neighbours' Q lines in
+    // one L2) when they divide over the 8 XCDs, else (sample, head) pairs (two samples used to put the whole launch on two XCDs)
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-    const int per = p.heads * chunks;
-    const int ul = idx / per, w = idx - ul * per;
-    const int smp = ul * 8 + xcd;
+    int smp, head, chunk;
+    if (p.n % 8 == 0) {
+        const int per = p.heads * chunks;
+        const int ul = idx / per, w = idx - ul * per;
+        smp = ul * 8 + xcd;
+        head = w / chunks; chunk = w - head * chunks;
+    } else {
+        const int ul = idx / chunks;
+        const int pair = ul * 8 + xcd;
+        chunk = idx - ul * chunks; smp = pair / p.heads; head = pair - smp * p.heads;
+    }
     if (smp >= p.n) return;
-    const int head = w / chunks, chunk = w - head * chunks;
     const int rows = p.F * p.Nq;                                        // query rows of the sample
     const H* __restrict__ Q = reinterpret_cast<const H*>(p.q) + (size_t)smp * rows * p.ldq + head * D;
     const H* __restrict__ K = reinterpret_cast<const H*>(p.k) + (size_t)smp * p.Nk * p.ldkv + head * D;
@@ -786,7 +808,7 @@ static bool launch_cross_resident(const AttnArgs& a, hipStream_t s) {
     int tpw = 16;
     while (tpw > 1 && (long)a.n * a.heads * ((tiles + 4 * tpw - 1) / (4 * tpw)) < 2048) tpw >>= 1;
     const int chunks = (tiles + 4 * tpw - 1) / (4 * tpw);
-    const unsigned grid = 8u * ((a.n + 7) / 8) * (unsigned)(a.heads * chunks);
+    const unsigned grid = a.n % 8 == 0 ? 8u * (a.n / 8) * (unsigned)(a.heads * chunks) : 8u * ((a.n * a.heads + 7) / 8) * (unsigned)chunks;
     const double probs = (double)a.n * a.F * a.heads;
     std::string pname = a.io_bf16 == H16_FP16 ? "flash_attn_fp16_cross" : "flash_attn_bf16_cross";
     if (prof_detail()) pname += attn_shape_tag(a);

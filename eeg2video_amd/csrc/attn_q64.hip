@@ -33,28 +33,36 @@ typedef float qf32x4 __attribute__((ext_vector_type(4)));
 // Workgroup -> (query block, head, sample-frame), XCD-aware exactly as attn_block of attn.hip (XCD b & 7 takes whole samples and walks
 // them frame by frame, head by head: the K / V rows of a frame are fetched into ONE L2), for query blocks of QB rows.
 struct Q64Block { int qb, head, sf; bool valid; };
+__host__ __device__ __forceinline__ int q64_xcd_unit(const int n, const int F) { return n % 8 == 0 ? 0 : (n * F) % 8 == 0 ? 1 : 2; }      // as attn_xcd_unit (attn.hip)
 __device__ __forceinline__ Q64Block q64_block(const AttnArgs& p, const int QB) {
     const int nqb = (p.Nq + QB - 1) / QB;
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
     const int S = p.n * p.F;
+    const int unit = q64_xcd_unit(p.n, p.F);
     Q64Block r;
-    if (p.n >= 8) {
+    if (unit == 0) {
         const int per = p.F * p.heads * nqb;
         const int ul = idx / per, w = idx - ul * per;
         const int smp = ul * 8 + xcd;
         const int f = w / (p.heads * nqb), w2 = w - f * (p.heads * nqb);
         r.sf = smp * p.F + f; r.head = w2 / nqb; r.qb = w2 - r.head * nqb; r.valid = smp < p.n;
-    } else {
+    } else if (unit == 1) {
         const int per = p.heads * nqb;
         const int ul = idx / per, w = idx - ul * per;
         r.sf = ul * 8 + xcd; r.head = w / nqb; r.qb = w - r.head * nqb; r.valid = r.sf < S;
+    } else {                                         // (sample-frame, head) pairs: the units always divide over the XCDs
+        const int ul = idx / nqb;
+        const int pair = ul * 8 + xcd;
+        r.qb = idx - ul * nqb; r.sf = pair / p.heads; r.head = pair - r.sf * p.heads; r.valid = pair < S * p.heads;
     }
     return r;
 }
 static inline unsigned q64_grid(const AttnArgs& a, const int QB) {
     const unsigned nqb = (a.Nq + QB - 1) / QB;
-    if (a.n >= 8) return 8u * ((a.n + 7) / 8) * (unsigned)(a.F * a.heads) * nqb;
-    return 8u * ((a.n * a.F + 7) / 8) * (unsigned)a.heads * nqb;
+    const int unit = q64_xcd_unit(a.n, a.F);
+    if (unit == 0) return 8u * (a.n / 8) * (unsigned)(a.F * a.heads) * nqb;
+    if (unit == 1) return 8u * ((a.n * a.F) / 8) * (unsigned)a.heads * nqb;
+    return 8u * ((a.n * a.F * a.heads + 7) / 8) * nqb;
 }
 
 __device__ __forceinline__ int imax3(const int a, const int b, const int c) { return max(max(a, b), c); }

@@ -1154,7 +1154,9 @@ void bgemm_launch(const IgemmArgs& a_in, int ntiles, hipStream_t s) {
             real += (long)(nrb - tail) * (a.w1 + a.s1) + (long)tail * a.s2;
         }
         const int nk = a.taps * ((a.c0 + 63) / 64 + (a.c1 + 63) / 64);
-        if (real <= 256 && nk >= 4) {
+        // (same-process A/B at B = 1, profiles/r05_shape_ab_b1_s3_small.log: 40 tiles -- the 5x8 level -- 24 -> 18 us; 140 tiles +-0 .. +7 %:
+        // from there on two co-resident two-stage workgroups per CU cover each other as well)
+        if (real <= 96 && nk >= 4) {
             constexpr size_t smem3 = (size_t)3 * 128 * 128 * 2 + 9 * 128 * sizeof(unsigned);
             dry_tag(" -> bgemm_s3_kernel 128x128 s3");
             E2V_BG_LAUNCH(bgemm_s3_kernel, dim3(ntiles, 1, 1), dim3(256), smem3);

@@ -1086,9 +1086,9 @@ void e2v_ctx::build_step_caches(const int64_t* ts, int steps, const float* cond,
 // -----------------------------------------------------------------------------------------------------
 // AutoencoderKL (diffusers 0.11.1).  Images are independent: "samples" = frames, F = 1.
 // -----------------------------------------------------------------------------------------------------
-void e2v_ctx::vae_decode_frames(const float* z_cl, int nf, int h, int w, float* out_cl, hipStream_t s) {
+void e2v_ctx::vae_decode_frames(const float* z_cl, int nf, int h, int w, float* out_cl, hipStream_t s, bool small) {
     E2V_REQUIRE(vae_ready, E2V_ESTATE, "VAE weights are not finalized");
-    small_family = nf <= 12;                                  // the frames of at most two clips
+    small_family = small;                                     // the CALL decodes at most two clips (the caller knows: a pass may be a call's ragged last group)
     Runner R{this, s};
     const int g = cfg.vae_norm_num_groups;
     const float eps = cfg.vae_norm_eps;

@@ -158,6 +158,6 @@ struct e2v_ctx {
     // host_tf != null: fractional timesteps (fp32) instead of host_t
     e2v::Act unet_forward_cl(const float* sample_cl, const int64_t* host_t, int n_t, const float* cond, int N, int F,
                              int H, int W, int T, hipStream_t s, bool cfg_pair = false, const float* host_tf = nullptr);
-    void vae_decode_frames(const float* z_cl, int nframes, int h, int w, float* out_cl3, hipStream_t s);
+    void vae_decode_frames(const float* z_cl, int nframes, int h, int w, float* out_cl3, hipStream_t s, bool small_family_call = false);
     void vae_encode_frames(const float* img_cl4, int n, int H, int W, float* moments_cl8, hipStream_t s);
 };
