@@ -597,7 +597,7 @@ struct Runner {
         a.samples = samples; a.P = P; a.groups = groups; a.eps = eps; a.silu = act ? 1 : 0;
         a.ws_part = c->gn_part; a.ws_scale = c->gn_scale;
         if (bf() && P % 64 == 0) { a.rb0 = rb0; a.rb1 = c1 > 0 ? rb1 : nullptr; }
-        a.fused_small = c->small_family ? 1 : 0;
+        a.fused_small = (c->small_family && bf()) ? 1 : 0;      // (16-bit modes only: the fp32 mode keeps one summation order at every batch)
         groupnorm(a, s);
         return out;
     }

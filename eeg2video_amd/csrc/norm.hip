@@ -325,10 +325,12 @@ static int oct_tile(int co) {
 // from the batch: the grouping of the fp32 partial sums must not depend on how many clips run together).  Level 0 (13 824 rows per
 // sample) streams 256-row chunks; the deeper levels (3456 / 864 / 240 rows) get 64-row chunks -- at 256 they were 14 / 4 / 1
 // workgroups per sample and the chip ran a quarter full (tools/norm_micro.py: 1.7 TB/s at level 2).
-static int gn_chunk_rows(const int P) {
+// (small_family: the small-batch dispatch family -- two samples at level 0 are 108 chunks of 256 rows for 256 CUs: 64-row chunks there too;
+// a different grouping of the partial sums, so the FAMILY picks it, never the batch within a family)
+static int gn_chunk_rows(const int P, const bool small_family = false) {
     static const int* const big = knob("E2V_GN_CHUNK_ROWS", 256);
     static const int* const small = knob("E2V_GN_CHUNK_ROWS_SMALL", 64);
-    const int want = P >= 8192 ? *big : *small;
+    const int want = (P >= 8192 && !small_family) ? *big : *small;
     const int v = want / GN_ROWS_PER_CHUNK * GN_ROWS_PER_CHUNK;
     return v < GN_ROWS_PER_CHUNK ? GN_ROWS_PER_CHUNK : v;
 }
@@ -511,7 +513,7 @@ static std::string gn_shape_tag(const GroupNormArgs& a) {
 
 static void groupnorm_stats_launch(const GroupNormArgs& a, hipStream_t s) {
     const int Ctot = a.c0 + a.c1;
-    const int crows = gn_chunk_rows(a.P);
+    const int crows = gn_chunk_rows(a.P, a.fused_small != 0);
     const int chunks = (a.P + crows - 1) / crows;
     auto part = [&](const float* x, int ld, int C, int coff) {
         const int qt = quad_tile(C / 4);
@@ -578,7 +580,7 @@ static void groupnorm_bf16_launch(const GroupNormArgs& a, hipStream_t s) {
     const size_t rows = (size_t)a.samples * a.P;
     if (*rowsp) {
         const int ot = oct_tile(a.c1 > 0 ? gcd_int(a.c0 / 8, a.c1 / 8) : a.c0 / 8);
-        const int crows = gn_chunk_rows(a.P);
+        const int crows = gn_chunk_rows(a.P, a.fused_small != 0);
         const dim3 grid((a.P + crows - 1) / crows, a.samples);
         dry_tag(" + gn_apply8_rows_kernel rows" + std::to_string(crows));
         h16_dispatch(a.bf16, [&](auto h16_tag) {

@@ -167,8 +167,10 @@ def test_h16_batches_are_bit_identical_within_a_dispatch_family(full, mode16):
     batch of 5 is BIT-identical to the same clip in a batch of 3.  SMALL family (B <= 2: the reference's clip-by-clip loop,
     inference_eeg2video.py:90-100): launches that would leave most of the chip idle take split-K and the one-kernel GroupNorm (round 5)
     -- another fp32 summation order -- so a clip generated alone is deterministic (twice the same bits) and equal to its large-family
-    twin up to rounding noise (latents within 2e-2 / 2.5e-3 of their scale for bf16 / fp16: the distance the modes keep from the fp32
-    oracle), not bit for bit; the family is held to the ORACLE by the configs[0] tests below, which all run one clip."""
+    twin like two draws of the mode's rounding noise (under CFG 12.5 a changed summation order flips 16-bit roundings downstream: the two
+    runs differ like the difference of two such errors -- measured 4.5e-2 / 5.8e-3 of the latents' scale after two steps for bf16 /
+    fp16, against 2.8e-2 / 3.4e-3 of either from the fp32 oracle after one; bounded at 8e-2 / 1e-2), not bit for bit; the family is
+    held to the ORACLE by the configs[0] tests below, which all run one clip."""
     pipe = full[0]
     eng = pipe.unet.engine
     B = 5
@@ -189,7 +191,7 @@ def test_h16_batches_are_bit_identical_within_a_dispatch_family(full, mode16):
         assert torch.equal(l1, l1b) and torch.equal(v1, v1b)
         d = rel_err(l1[0], lat_out[0].cpu())
         print(f"{mode16}: clip 0 alone (small family) vs in a batch of 5 (large family): latents {d:.3e} of their scale")
-        assert d < (2e-2 if mode16 == "bf16" else 2.5e-3)
+        assert d < (8e-2 if mode16 == "bf16" else 1e-2)
     finally:
         eng.set_compute_dtype("fp32")
 
@@ -462,7 +464,9 @@ def test_configs4_sweep_full_size_one_concept_bf16(full, capsys):
     # draws of the mode's rounding noise: they differ from each other like the difference of two such errors (sqrt 2 x the distance
     # of either from the fp32 frames on the same inputs; measured 1.07 against 1.05 levels mean) -- bounded at 1.5 x / 2 x that distance
     assert diff32 <= 2 and mean32 < 0.05, (diff32, mean32)
-    assert mean <= 1.5 * meanp and far <= 2.0 * farp + 1e-3 and diff <= max(40.0, 2.0 * diffp), (diff, mean, far, diffp, meanp, farp)
+    # (round 5: batches of 2 run in the small-batch dispatch family -- split-K, one-kernel GroupNorm: other summation orders in many layers --
+    # so the two bf16 runs are two draws in earnest; the tail fraction of a difference of two draws grows faster than its mean: 4 x)
+    assert mean <= 1.5 * meanp and far <= 4.0 * farp + 1e-3 and diff <= max(40.0, 2.0 * diffp), (diff, mean, far, diffp, meanp, farp)
     assert meanp < 3.0, meanp                                  # (and the bf16 frames are the fp32 frames to about a level)
     assert a.float().std() > 1.0          # not a constant image
 
