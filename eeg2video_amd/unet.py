@@ -110,7 +110,8 @@ class UNet3DConditionModel:
             if len(set(attention_head_dim)) != 1:
                 raise NotImplementedError("per-block attention_head_dim")
             attention_head_dim = attention_head_dim[0]
-        # Transformer3DModel(use_linear_projection=True) (attention.py:60-63,83-86: SD-2.x-shaped checkpoints) applies proj_in / proj_out
+        # Transformer3DModel(use_linear_projection=True) (attention.py:60-63,83-86: Linear-shaped proj_in / proj_out weights; NOT yet a
+        # whole SD-2.x UNet, whose per-block attention_head_dim [5, 10, 20, 20] is refused above) applies proj_in / proj_out
         # as nn.Linear on the tokens instead of a 1x1 Conv2d on the map (attention.py:99-123): with channel-last rows the two are the
         # same GEMM, so the option only changes the SHAPE those two weights have in a state dict ([C, C] instead of [C, C, 1, 1])
         self.use_linear_projection = bool(use_linear_projection)
@@ -209,8 +210,12 @@ class UNet3DConditionModel:
         if self.use_linear_projection:           # nn.Linear proj_in / proj_out -> the 1x1-conv layout the engine's key scheme holds
             state_dict = dict(state_dict)
             for k, v in list(state_dict.items()):
-                if (k.endswith(".proj_in.weight") or k.endswith(".proj_out.weight")) and getattr(v, "ndim", 0) == 2:
-                    state_dict[k] = v.reshape(v.shape[0], v.shape[1], 1, 1)
+                if k.endswith(".proj_in.weight") or k.endswith(".proj_out.weight"):
+                    if strict and getattr(v, "ndim", 0) != 2:       # the reference's strict load refuses a conv-shaped weight for an nn.Linear
+                        raise RuntimeError(f"Error(s) in loading state_dict for UNet3DConditionModel: size mismatch for {k}: copying a param "
+                                           f"with shape {tuple(v.shape)} from checkpoint, the shape in current model is {tuple(v.shape[:2])}.")
+                    if getattr(v, "ndim", 0) == 2:
+                        state_dict[k] = v.reshape(v.shape[0], v.shape[1], 1, 1)
         missing = [k for k in spec if k not in state_dict]
         unexpected = [k for k in state_dict if k not in spec]
         if strict and (missing or unexpected):

@@ -491,7 +491,7 @@ def test_from_pretrained_2d_inflates_a_2d_checkpoint(tiny, tmp_path):
 
 
 def test_use_linear_projection_checkpoint_loads_and_matches(tiny):
-    """UNet3DConditionModel(use_linear_projection=True) (unet.py:59, attention.py:60-63,83-86: the SD-2.x shape of a checkpoint, proj_in /
+    """UNet3DConditionModel(use_linear_projection=True) (unet.py:59, attention.py:60-63,83-86: Linear-shaped proj_in / proj_out weights as SD-2.x checkpoints carry them, proj_in /
     proj_out stored as [C, C] nn.Linear weights): the mirror reshapes the two weights to the 1x1-conv layout -- the same GEMM on
     channel-last rows (pinned against the reference itself in tests/test_oracle_golden.py) -- so the model must load such a state dict
     and give bit for bit what the conv-shaped one gives."""
@@ -509,6 +509,8 @@ def test_use_linear_projection_checkpoint_loads_and_matches(tiny):
     assert torch.equal(m(x, 301, cond).sample, pipe.unet(x, 301, cond).sample)
     with pytest.raises(RuntimeError):                      # the conv-shaped mirror still refuses the Linear-shaped weights
         UNet3DConditionModel(device=0, **kw).load_state_dict(lin_sd)
+    with pytest.raises(RuntimeError, match="size mismatch"):   # and the Linear-shaped mirror the conv-shaped ones, as the reference's strict load does
+        UNet3DConditionModel(use_linear_projection=True, device=0, **kw).load_state_dict(usd)
 
 
 def test_memory_knobs_of_the_reference_objects_are_accepted(tiny):
