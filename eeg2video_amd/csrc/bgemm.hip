@@ -42,13 +42,13 @@ bool set_knob(const char* name, int value) {
     auto& t = knob_table();
     auto it = t.find(name);
     if (it == t.end()) {
-        static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_256LIN", "E2V_BGEMM_256_MINROUNDS", "E2V_BGEMM_256", "E2V_BGEMM_T256",
-                                            "E2V_BGEMM_T256_MINK", "E2V_BGEMM_T256_MINTILES", "E2V_BGEMM_T256P", "E2V_BGEMM_T256P_MAXK", "E2V_BGEMM_T256P_MINTILES",
-                                            "E2V_BGEMM_T256P_BIAS_LDS", "E2V_ATTN_KT64", "E2V_ATTN_Q64", "E2V_ATTN_CROSS_RESIDENT", "E2V_TATTN_WAVE",
-                                            "E2V_GN_CHUNK_ROWS", "E2V_GN_CHUNK_ROWS_SMALL", "E2V_IGEMM_HALF_BELOW", "E2V_LN_ROWS", "E2V_BGEMM_UP2X",
-                                            "E2V_SPLITK", "E2V_SPLITK_MIN_DEPTH", "E2V_SPLITK_FORCE", "E2V_GN_FUSED_SMALL", "E2V_BGEMM_S3_SMALL", "E2V_SPLITK_MAX_TILES"
-#ifdef E2V_AB                                // variants measured and not adopted / the other arm of an A/B: `make AB=1` builds only
-                                            , "E2V_BGEMM_S3", "E2V_BGEMM_LIN", "E2V_BGEMM_T256_TAIL", "E2V_ATTN_FOLD", "E2V_ATTN_Q64P", "E2V_ATTN_Q64_NW", "E2V_GN_ROWS", "E2V_GN_GROUP_MB", "E2V_GN_SKIP_PARTIAL", "E2V_GN_RB", "E2V_GN_RB_EPILOGUE"
+        static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_256LIN", "E2V_BGEMM_256", "E2V_BGEMM_T256", "E2V_BGEMM_T256P", "E2V_BGEMM_T256P_BIAS_LDS",
+                                            "E2V_ATTN_KT64", "E2V_ATTN_Q64", "E2V_ATTN_CROSS_RESIDENT", "E2V_TATTN_WAVE", "E2V_LN_ROWS", "E2V_BGEMM_UP2X",
+                                            "E2V_SPLITK", "E2V_SPLITK_FORCE", "E2V_GN_FUSED_SMALL", "E2V_BGEMM_S3_SMALL"
+#ifdef E2V_AB                                // variants measured and not adopted / the other arm of an A/B / thresholds that measured +-0: `make AB=1` builds only
+                                            , "E2V_BGEMM_S3", "E2V_BGEMM_LIN", "E2V_BGEMM_T256_TAIL", "E2V_ATTN_FOLD", "E2V_ATTN_Q64P", "E2V_ATTN_Q64_NW", "E2V_GN_ROWS", "E2V_GN_GROUP_MB", "E2V_GN_SKIP_PARTIAL", "E2V_GN_RB", "E2V_GN_RB_EPILOGUE",
+                                            "E2V_BGEMM_256_MINROUNDS", "E2V_BGEMM_T256_MINK", "E2V_BGEMM_T256_MINTILES", "E2V_BGEMM_T256P_MAXK", "E2V_BGEMM_T256P_MINTILES", "E2V_GN_CHUNK_ROWS",
+                                            "E2V_GN_CHUNK_ROWS_SMALL", "E2V_IGEMM_HALF_BELOW", "E2V_SPLITK_MIN_DEPTH", "E2V_SPLITK_MAX_TILES"
 #endif
 #ifdef E2V_ABLATE
                                             , "E2V_BGEMM_ABLATE"
@@ -1020,7 +1020,7 @@ bool bgemm_use_256(const IgemmArgs& a) {
     // enough rounds of 256 resident tiles, else the finer 128-row grid wastes less on its last round
     const double tiles = (double)((a.M + 255) / 256) * a.batch * ((a.N + 127) / 128);
     // (two rounds: with the three-stage ring the 256-row tile wins from there on -- level-3 convs -11 %; it was four with two stages)
-    static const int* const minr = knob("E2V_BGEMM_256_MINROUNDS", 2);
+    static const int* const minr = E2V_AB_KNOB("E2V_BGEMM_256_MINROUNDS", 2);
     return tiles >= (double)*minr * 256;
 }
 

@@ -1023,8 +1023,8 @@ __global__ __launch_bounds__(512) void bgemm_t256p_kernel(const IgemmArgs p) {
 static int t256_tile_cols(const IgemmArgs& a, const bool force = false) {      // force: the sub-pixel convs (their arithmetic differs from the
                                                                               // gather path's, so the choice must not depend on M or on a switch of the 3x3 path)
     static const int* const on = knob("E2V_BGEMM_T256", 1);
-    static const int* const mink = knob("E2V_BGEMM_T256_MINK", 320);
-    static const int* const mintiles = knob("E2V_BGEMM_T256_MINTILES", 160);
+    static const int* const mink = E2V_AB_KNOB("E2V_BGEMM_T256_MINK", 320);
+    static const int* const mintiles = E2V_AB_KNOB("E2V_BGEMM_T256_MINTILES", 160);
     if ((!*on && !force) || !a.a_bf16 || a.batch != 1 || a.upsample || (a.taps != 1 && a.taps != 9 && !(a.taps == 4 && a.kw == 2))) return 0;
     if (a.taps != 4 && (a.kw != 3 || a.pad_x >= 0 || a.osy)) return 0;        // (kernel width / split pad / scatter: the sub-pixel kernels only)
     const int Kc = a.c0 + a.c1;
@@ -1074,8 +1074,8 @@ static void t256_launch_part(IgemmArgs a, const int cols, const int rb0, const i
         // (profiles/r03_shape_ab_t256p_epilogue.log) every linear of >= 256 tiles does: 640 -> 640 with a residual -10 %, 320 -> 960 -6 %,
         // 320 -> 320 -3 % against bgemm.hip's persistent 128-row kernel, which the K <= 640 projections with a residual used to stay on.
         static const int* const persp = knob("E2V_BGEMM_T256P", 1);
-        static const int* const pmaxk = knob("E2V_BGEMM_T256P_MAXK", 1 << 30);
-        static const int* const pmint = knob("E2V_BGEMM_T256P_MINTILES", 256);
+        static const int* const pmaxk = E2V_AB_KNOB("E2V_BGEMM_T256P_MAXK", 1 << 30);
+        static const int* const pmint = E2V_AB_KNOB("E2V_BGEMM_T256P_MINTILES", 256);
         const long ntiles = (long)a.nbm * nct;
         // (the epilogue reads the residual in the output's type: fp32 with fp32 at the test entry points, bf16 with bf16 in the graph)
         const bool io_ok = !a.resid || (a.out_f32 ? !a.resid_bf16 : a.resid_bf16 != 0);

@@ -791,7 +791,7 @@ void igemm(const IgemmArgs& a_in, hipStream_t s) {
     // chip part idle in their last round.  E2V_IGEMM_HALF_BELOW = r x 100 > 0: a launch of fewer than r rounds of full-size tiles runs
     // ENTIRELY as 128 x 64 tiles (twice the workgroups at half the work: the round granularity halves; same k order per output, so
     // bit-identical).  Same-process A/B: profiles/r04_shape_ab_fp32_tail.log.
-    static const int* const half_below = knob("E2V_IGEMM_HALF_BELOW", 0);
+    static const int* const half_below = E2V_AB_KNOB("E2V_IGEMM_HALF_BELOW", 0);      // (measured +-0: `make ab` only)
     if (!a.a_bf16 && *half_below > 0 && !a.geglu && a.w1 > 0 && a.rb1 > 0) {
         const double per_rb = a.w1 + 0.5 * a.s1;
         const double rounds = per_rb * ((nbm + 7) / 8) / (slots / 8);

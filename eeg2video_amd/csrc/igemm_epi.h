@@ -41,8 +41,15 @@ __device__ __forceinline__ float gelu_bf16_grade(float x) {
 // (fast: wave-uniform, IgemmArgs::a_bf16 -- the arithmetic mode, never the kernel or the batch, picks the form: the logistic form in
 // bf16 mode only; fp16 rounds 8x finer than bf16, so the fp16 mode keeps the erf form like fp32)
 __device__ __forceinline__ float gelu_gate(float x, const bool fast) { return fast ? gelu_bf16_grade(x) : gelu_erf(x); }
+// (E2V_F16_FAST_GATE: a measurement build -- `make EXTRA=-DE2V_F16_FAST_GATE` -- that gives the fp16 mode the logistic gate too, to
+// price the erf form: profiles/r05_fp16_gate_ab.log)
+#ifdef E2V_F16_FAST_GATE
+constexpr bool kF16FastGate = true;
+#else
+constexpr bool kF16FastGate = false;
+#endif
 template <typename H> __device__ __forceinline__ float gelu_gate16(float x) {       // the same choice at compile time, by the kernel's 16-bit type
-    if constexpr (__is_same(H, __bf16)) return gelu_bf16_grade(x);
+    if constexpr (__is_same(H, __bf16) || kF16FastGate) return gelu_bf16_grade(x);
     else return gelu_erf(x);
 }
 
@@ -77,7 +84,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
                         f32x4 y;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + bg[e], p.a_bf16 == H16_BF16);
+                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + bg[e], p.a_bf16 == H16_BF16 || (kF16FastGate && p.a_bf16 == H16_FP16));
                         *reinterpret_cast<f32x4*>(st + mrow * SLD + 8 * g + nq) = y;
                     }
 #pragma unroll
@@ -191,7 +198,7 @@ __device__ __forceinline__ void bgemm_epilogue_bf16(const IgemmArgs& p, f32x16 (
                         f32x4 y;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + bg[e], p.a_bf16 == H16_BF16);
+                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + bv[e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + bg[e], p.a_bf16 == H16_BF16 || (kF16FastGate && p.a_bf16 == H16_FP16));
                         *reinterpret_cast<f32x4*>(st + mrow * SLD + 8 * g + nq) = y;
                     }
 #pragma unroll
@@ -382,7 +389,7 @@ struct BgEpilogue {
                         f32x4 y;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + gv[g][e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + gg[g][e], p.a_bf16 == H16_BF16);
+                            y[e] = (acc[mi][0][4 * g + e] * p.alpha + gv[g][e]) * gelu_gate(acc[mi][1][4 * g + e] * p.alpha + gg[g][e], p.a_bf16 == H16_BF16 || (kF16FastGate && p.a_bf16 == H16_FP16));
                         *reinterpret_cast<f32x4*>(st + mrow * 32 + (((2 * g + (lane >> 5)) ^ wsw) << 2)) = y;
                     }
 #pragma unroll

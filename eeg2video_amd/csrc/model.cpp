@@ -549,8 +549,8 @@ struct Runner {
     Act sk_setup(IgemmArgs& g) {
         Act ws;
         static const int* const on = knob("E2V_SPLITK", 1);
-        static const int* const min_depth = knob("E2V_SPLITK_MIN_DEPTH", 2048);
-        static const int* const max_tiles = knob("E2V_SPLITK_MAX_TILES", 256);
+        static const int* const min_depth = E2V_AB_KNOB("E2V_SPLITK_MIN_DEPTH", 2048);     // (1024 / 640 and 400 tiles measured +-0: `make ab` only)
+        static const int* const max_tiles = E2V_AB_KNOB("E2V_SPLITK_MAX_TILES", 256);
         if (!c->small_family || !g.a_bf16 || !*on || *min_depth < 64) return ws;
         const long K = (long)g.taps * (g.c0 + g.c1);
         const long tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);

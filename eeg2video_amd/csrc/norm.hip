@@ -328,8 +328,8 @@ static int oct_tile(int co) {
 // (small_family: the small-batch dispatch family -- two samples at level 0 are 108 chunks of 256 rows for 256 CUs: 64-row chunks there too;
 // a different grouping of the partial sums, so the FAMILY picks it, never the batch within a family)
 static int gn_chunk_rows(const int P, const bool small_family = false) {
-    static const int* const big = knob("E2V_GN_CHUNK_ROWS", 256);
-    static const int* const small = knob("E2V_GN_CHUNK_ROWS_SMALL", 64);
+    static const int* const big = E2V_AB_KNOB("E2V_GN_CHUNK_ROWS", 256);            // (tuned in round 3, tools/norm_micro.py: `make ab` only)
+    static const int* const small = E2V_AB_KNOB("E2V_GN_CHUNK_ROWS_SMALL", 64);
     const int want = (P >= 8192 && !small_family) ? *big : *small;
     const int v = want / GN_ROWS_PER_CHUNK * GN_ROWS_PER_CHUNK;
     return v < GN_ROWS_PER_CHUNK ? GN_ROWS_PER_CHUNK : v;
