@@ -1,14 +1,16 @@
 """Copy the outputs of tools/profile_round.sh (gpurun_out/prof_<tag>/) into profiles/ under the round's names and rebuild
 profiles/pmc_dominant_kernel.json (what bench.py quotes as roofline.traffic) from the two PMC summaries.
 
-usage: python tools/fold_profiles.py r03          # expects gpurun_out/prof_r03_fp32_b8 and gpurun_out/prof_r03_bf16_b32
+usage: python tools/fold_profiles.py r03          # expects gpurun_out/prof_r03_fp32_b8 and gpurun_out/prof_r03_bf16_b32 (prof_<tag>_fp16_b32 if present)
 """
 import json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 dom = {}
-for cfg, cls, batch, dtype in (("fp32_b8", "igemm_f32", 8, "fp32"), ("bf16_b32", "igemm_bf16", 32, "bf16")):
+for cfg, cls, batch, dtype in (("fp32_b8", "igemm_f32", 8, "fp32"), ("bf16_b32", "igemm_bf16", 32, "bf16"), ("fp16_b32", "igemm_fp16", 32, "fp16")):
     src = os.path.join(R, "gpurun_out", f"prof_{tag}_{cfg}")
+    if cfg == "fp16_b32" and not os.path.isdir(src):
+        continue
     for a, b in (("kernel_stats.csv", "rocprofv3_kernel_stats.csv"), ("kernel_classes_hip_events.json", "kernel_classes_hip_events.json"),
                  ("pmc_summary.json", "pmc_summary.json"), ("stats_bench.json", "bench_under_rocprof.json")):
         if os.path.exists(os.path.join(src, a)):
