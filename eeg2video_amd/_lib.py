@@ -29,6 +29,7 @@ class E2VConfig(C.Structure):
         ("num_train_timesteps", C.c_int), ("beta_start", C.c_double), ("beta_end", C.c_double),
         ("steps_offset", C.c_int),
         ("sem_in_features", C.c_int), ("sem_hidden", C.c_int), ("sem_tokens", C.c_int),
+        ("attention_heads_per_block", C.c_int * 4),
     ]
 
 

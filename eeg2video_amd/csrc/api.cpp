@@ -109,11 +109,13 @@ e2v_status e2v_create(const e2v_config* cfg, int device, e2v_ctx** out) {
         }
         E2V_REQUIRE(cfg->attention_heads > 0 && cfg->norm_num_groups > 0 && cfg->layers_per_block > 0, E2V_EINVAL, "bad config");
         for (int i = 0; i < 4; ++i) {
-            E2V_REQUIRE(cfg->block_out_channels[i] % cfg->norm_num_groups == 0 && cfg->block_out_channels[i] % 32 == 0 &&
-                            (cfg->block_out_channels[i] / cfg->attention_heads) % 8 == 0,
+            const int heads = cfg->attention_heads_per_block[i] > 0 ? cfg->attention_heads_per_block[i] : cfg->attention_heads;
+            E2V_REQUIRE(cfg->attention_heads_per_block[i] >= 0 && cfg->block_out_channels[i] % cfg->norm_num_groups == 0 &&
+                            cfg->block_out_channels[i] % 32 == 0 && cfg->block_out_channels[i] % heads == 0 &&
+                            (cfg->block_out_channels[i] / heads) % 8 == 0,
                         E2V_EINVAL, "block_out_channels must be multiples of 32, of norm_num_groups and of 8*heads");
-            E2V_REQUIRE(flash_attention_supports(cfg->block_out_channels[i] / cfg->attention_heads), E2V_EINVAL,
-                        "block_out_channels / attention_heads must be a head dim with a kernel instance (8, 16, 32, 40, 64, 80, 160)");
+            E2V_REQUIRE(flash_attention_supports(cfg->block_out_channels[i] / heads), E2V_EINVAL,
+                        "block_out_channels / attention heads must be a head dim with a kernel instance (8, 16, 32, 40, 64, 80, 160)");
             E2V_REQUIRE(cfg->vae_block_out_channels[i] % cfg->vae_norm_num_groups == 0 && cfg->vae_block_out_channels[i] % 4 == 0,
                         E2V_EINVAL, "vae_block_out_channels must be multiples of 4 and of vae_norm_num_groups");
         }

@@ -921,7 +921,9 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
     const int N1 = cfg_pair ? N / 2 : N;
     small_family = N <= 4;                                    // B <= 2 clips with their guidance pairs (model.h)
     Runner R{this, s};
-    const int heads = cfg.attention_heads, groups = cfg.norm_num_groups;
+    const int groups = cfg.norm_num_groups;
+    // heads of the blocks of resolution level l (unet.py:110-111,131,151,165,194: down block l, the mid block = level 3, up block 3 - l)
+    auto heads_at = [&](int l) { return cfg.attention_heads_per_block[l] > 0 ? cfg.attention_heads_per_block[l] : cfg.attention_heads; };
     const float eps = cfg.norm_eps;
     const int boc0 = cfg.block_out_channels[0], temb_dim = boc0 * 4;
 
@@ -1004,10 +1006,10 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
                 h = R.resnet(b.res[j], x_shared.p, x_shared.C, nullptr, 0, N1, P_of(i), Geo{N1 * F, hs[0], ws[0]}, groups, eps,
                              temb_silu.p, temb_dim);
                 x_shared.reset();
-                h = R.transformer(b.attn[j], h, N, F, hs[i] * ws[i], cond, T, heads, groups, N1);
+                h = R.transformer(b.attn[j], h, N, F, hs[i] * ws[i], cond, T, heads_at(i), groups, N1);
             } else {
                 h = R.resnet(b.res[j], cur->p, cur->C, nullptr, 0, N, P_of(i), geo_of(i), groups, eps, temb_silu.p, temb_dim, cur->rb);
-                if (!b.attn.empty()) h = R.transformer(b.attn[j], h, N, F, hs[i] * ws[i], cond, T, heads, groups);
+                if (!b.attn.empty()) h = R.transformer(b.attn[j], h, N, F, hs[i] * ws[i], cond, T, heads_at(i), groups);
             }
             cur = &keep(std::move(h), i);
         }
@@ -1020,7 +1022,7 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
     }
     // mid (unet_blocks.py:199-205)
     Act h = R.resnet(unet.mid_r0, cur->p, cur->C, nullptr, 0, N, P_of(3), geo_of(3), groups, eps, temb_silu.p, temb_dim, cur->rb);
-    h = R.transformer(unet.mid_attn, h, N, F, hs[3] * ws[3], cond, T, heads, groups);
+    h = R.transformer(unet.mid_attn, h, N, F, hs[3] * ws[3], cond, T, heads_at(3), groups);
     h = R.resnet(unet.mid_r1, h.p, h.C, nullptr, 0, N, P_of(3), geo_of(3), groups, eps, temb_silu.p, temb_dim, h.rb);
     if (tap_sink) tap(h, N, cfg.block_out_channels[3], F, hs[3], ws[3]);                               // taps["mid"]
     // up (unet.py:381-404)
@@ -1032,7 +1034,7 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
             Skip sk = std::move(skips.back());                                                       // unet_blocks.py:485-487
             skips.pop_back();
             Act o = R.resnet(b.res[j], h.p, h.C, sk.a.p, sk.a.C, N, P_of(lvl), geo_of(lvl), groups, eps, temb_silu.p, temb_dim, h.rb, sk.a.rb);
-            if (!b.attn.empty()) o = R.transformer(b.attn[j], o, N, F, hs[lvl] * ws[lvl], cond, T, heads, groups);
+            if (!b.attn.empty()) o = R.transformer(b.attn[j], o, N, F, hs[lvl] * ws[lvl], cond, T, heads_at(lvl), groups);
             h = std::move(o);
         }
         if (b.resample) {   // Upsample3D: nearest to the next skip's (f,h,w) then 3x3 conv (resnet.py:58-69, unet.py:389-390)

@@ -48,7 +48,14 @@ class Engine:
         cfg.block_out_channels = (C.c_int * 4)(*unet_cfg.block_out_channels)
         cfg.layers_per_block = unet_cfg.layers_per_block
         cfg.cross_attention_dim = unet_cfg.cross_attention_dim
-        cfg.attention_heads = unet_cfg.attention_head_dim
+        hd = unet_cfg.attention_head_dim                      # an int, or one head count per down block (unet.py:71,110-111)
+        if isinstance(hd, int):
+            cfg.attention_heads = hd
+        else:
+            if len(hd) != 4:
+                raise ValueError("attention_head_dim as a tuple needs one entry per down block (4)")
+            cfg.attention_heads = int(hd[0])
+            cfg.attention_heads_per_block = (C.c_int * 4)(*[int(h) for h in hd])
         cfg.norm_num_groups, cfg.norm_eps = unet_cfg.norm_num_groups, unet_cfg.norm_eps
         cfg.flip_sin_to_cos, cfg.freq_shift = int(unet_cfg.flip_sin_to_cos), float(unet_cfg.freq_shift)
         cfg.vae_in_channels, cfg.vae_latent_channels = vae_cfg.in_channels, vae_cfg.latent_channels

@@ -106,12 +106,14 @@ class UNet3DConditionModel:
         if resnet_time_scale_shift != "default" or act_fn not in ("silu", "swish") or downsample_padding != 1 \
                 or mid_block_scale_factor != 1:
             raise NotImplementedError("only time_embedding_norm='default', SiLU, padding 1, scale 1 are implemented")
-        if not isinstance(attention_head_dim, int):
-            if len(set(attention_head_dim)) != 1:
-                raise NotImplementedError("per-block attention_head_dim")
-            attention_head_dim = attention_head_dim[0]
-        # Transformer3DModel(use_linear_projection=True) (attention.py:60-63,83-86: Linear-shaped proj_in / proj_out weights; NOT yet a
-        # whole SD-2.x UNet, whose per-block attention_head_dim [5, 10, 20, 20] is refused above) applies proj_in / proj_out
+        if not isinstance(attention_head_dim, int):           # one head count per down block (unet.py:110-111; SD-2.x: 5 / 10 / 20 / 20)
+            attention_head_dim = tuple(int(h) for h in attention_head_dim)
+            if len(attention_head_dim) != len(block_out_channels):
+                raise ValueError(f"attention_head_dim has {len(attention_head_dim)} entries for {len(block_out_channels)} blocks")
+            if len(set(attention_head_dim)) == 1:
+                attention_head_dim = attention_head_dim[0]
+        # Transformer3DModel(use_linear_projection=True) (attention.py:60-63,83-86: Linear-shaped proj_in / proj_out weights, as SD-2.x
+        # checkpoints carry them -- with the per-block attention_head_dim (5, 10, 20, 20) above, the SD-2.x UNet shape) applies proj_in / proj_out
         # as nn.Linear on the tokens instead of a 1x1 Conv2d on the map (attention.py:99-123): with channel-last rows the two are the
         # same GEMM, so the option only changes the SHAPE those two weights have in a state dict ([C, C] instead of [C, C, 1, 1])
         self.use_linear_projection = bool(use_linear_projection)
@@ -174,7 +176,14 @@ class UNet3DConditionModel:
         reference's, with its messages."""
         n_blocks = sum(1 for t in self.ucfg.down_block_types if t.startswith("CrossAttn")) * self.ucfg.layers_per_block + 1 + \
             sum(1 for t in self.ucfg.up_block_types if t.startswith("CrossAttn")) * (self.ucfg.layers_per_block + 1)
-        dims = [self.ucfg.attention_head_dim] * (3 * n_blocks)
+        hd = self.ucfg.attention_head_dim
+        if isinstance(hd, int):
+            dims = [hd] * (3 * n_blocks)
+        else:                # module order of the reference: down blocks, mid block, up blocks (reversed head list), 3 attentions per block
+            L = self.ucfg.layers_per_block
+            per = [hd[i] for i, t in enumerate(self.ucfg.down_block_types) if t.startswith("CrossAttn") for _ in range(L)] + [hd[-1]] + \
+                  [list(reversed(hd))[i] for i, t in enumerate(self.ucfg.up_block_types) if t.startswith("CrossAttn") for _ in range(L + 1)]
+            dims = [h for h in per for _ in range(3)]
         if slice_size == "auto":
             slice_size = [d // 2 for d in dims]
         elif slice_size == "max":

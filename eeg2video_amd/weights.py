@@ -19,7 +19,7 @@ from __future__ import annotations
 import math
 from collections import OrderedDict
 from dataclasses import dataclass, field
-from typing import Dict, Iterable, List, Tuple
+from typing import Dict, Iterable, List, Tuple, Union
 
 import numpy as np
 
@@ -84,7 +84,7 @@ class UNetConfig:
     block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
     layers_per_block: int = 2
     cross_attention_dim: int = 768
-    attention_head_dim: int = 8            # = number of heads (unet_blocks.py:257-259)
+    attention_head_dim: Union[int, Tuple[int, ...]] = 8   # = NUMBER of heads (unet_blocks.py:257-259); a tuple: per down block (unet.py:110-111)
     norm_num_groups: int = 32
     norm_eps: float = 1e-5
     down_block_types: Tuple[str, ...] = (

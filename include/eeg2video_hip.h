@@ -69,6 +69,10 @@ typedef struct {
     int sem_in_features;                    /* 310 */
     int sem_hidden;                         /* 10000 */
     int sem_tokens;                         /* 77 */
+    /* Per-block head counts (`attention_head_dim` given as a tuple, unet.py:71,110-111: down block i takes [i] (:131), the mid block
+     * [3] (:151), up block i the reversed list's [i] (:165,194); the SD-2.x UNet's 5 / 10 / 20 / 20).  All zero (the default): every
+     * block has `attention_heads` heads.  Appended in round 5: e2v_config_size() tells a binding which layout a library has. */
+    int attention_heads_per_block[4];
 } e2v_config;
 
 void e2v_default_config(e2v_config* cfg);

@@ -169,7 +169,10 @@ def unet3d_forward(sd: SD, cfg, sample: torch.Tensor, timestep, encoder_hidden_s
     """unet.py:278-413.  ``cfg`` is an ``eeg2video_amd.weights.UNetConfig``-like object.
     ``taps`` (optional dict) receives named intermediates for per-block parity tests."""
     boc = cfg.block_out_channels
-    heads, groups, eps = cfg.attention_head_dim, cfg.norm_num_groups, cfg.norm_eps
+    groups, eps = cfg.norm_num_groups, cfg.norm_eps
+    hd = cfg.attention_head_dim                                                                 # :110-111: an int = the same count for every block
+    hd = (hd,) * len(boc) if isinstance(hd, int) else tuple(hd)
+    hd_up = tuple(reversed(hd))                                                                 # :165
     n_up = len(boc) - 1
     forward_upsample_size = any(s % (2 ** n_up) != 0 for s in sample.shape[-2:])                # :304-312
 
@@ -192,7 +195,7 @@ def unet3d_forward(sd: SD, cfg, sample: torch.Tensor, timestep, encoder_hidden_s
         for j in range(cfg.layers_per_block):
             x = resnet_block3d(sd, f"down_blocks.{i}.resnets.{j}", x, emb, groups, eps)         # unet_blocks.py:307
             if typ == "CrossAttnDownBlock3D":
-                x = transformer3d(sd, f"down_blocks.{i}.attentions.{j}", x, encoder_hidden_states, heads, groups)
+                x = transformer3d(sd, f"down_blocks.{i}.attentions.{j}", x, encoder_hidden_states, hd[i], groups)   # :131
             skips.append(x)                                                                     # unet_blocks.py:310
         if i != len(boc) - 1:
             x = downsample3d(sd, f"down_blocks.{i}.downsamplers.0", x)                          # unet_blocks.py:312-316
@@ -201,7 +204,7 @@ def unet3d_forward(sd: SD, cfg, sample: torch.Tensor, timestep, encoder_hidden_s
             taps[f"down{i}"] = x
 
     x = resnet_block3d(sd, "mid_block.resnets.0", x, emb, groups, eps)                          # unet_blocks.py:199-205
-    x = transformer3d(sd, "mid_block.attentions.0", x, encoder_hidden_states, heads, groups)
+    x = transformer3d(sd, "mid_block.attentions.0", x, encoder_hidden_states, hd[-1], groups)      # :151
     x = resnet_block3d(sd, "mid_block.resnets.1", x, emb, groups, eps)
     if taps is not None:
         taps["mid"] = x
@@ -218,7 +221,7 @@ def unet3d_forward(sd: SD, cfg, sample: torch.Tensor, timestep, encoder_hidden_s
             res = res[:-1]
             x = resnet_block3d(sd, f"up_blocks.{i}.resnets.{j}", x, emb, groups, eps)
             if typ == "CrossAttnUpBlock3D":
-                x = transformer3d(sd, f"up_blocks.{i}.attentions.{j}", x, encoder_hidden_states, heads, groups)
+                x = transformer3d(sd, f"up_blocks.{i}.attentions.{j}", x, encoder_hidden_states, hd_up[i], groups)   # :194
         if not is_final:
             x = upsample3d(sd, f"up_blocks.{i}.upsamplers.0", x, up_size)                       # unet_blocks.py:510-512
         if taps is not None:

@@ -513,6 +513,43 @@ def test_use_linear_projection_checkpoint_loads_and_matches(tiny):
         UNet3DConditionModel(use_linear_projection=True, device=0, **kw).load_state_dict(usd)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "fp16"])
+def test_per_block_attention_head_dim_vs_oracle(tiny, mode):
+    """`attention_head_dim` as a tuple (unet.py:71,110-111): down block i takes entry i (:131), the mid block the last one (:151), the up
+    blocks the reversed list (:165,194) -- the SD-2.x UNet's 5 / 10 / 20 / 20.  Tiny config with 4 / 4 / 8 / 16 heads (head dims 16 / 32 /
+    32 / 16): against the oracle (which walks the same three index rules), and a uniform tuple is the int."""
+    import dataclasses
+    from eeg2video_amd.unet import UNet3DConditionModel
+    from oracle import unet3d_forward
+    _, usd, _ = tiny
+    heads = (4, 4, 8, 16)
+    cfg = dataclasses.replace(TINY_UNET, attention_head_dim=heads)
+    kw = dict(sample_size=cfg.sample_size, in_channels=4, out_channels=4, block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+              cross_attention_dim=cfg.cross_attention_dim, norm_num_groups=cfg.norm_num_groups, norm_eps=cfg.norm_eps)
+    m = UNet3DConditionModel(attention_head_dim=heads, device=0, **kw)
+    m.load_state_dict(usd)                                  # (the weights do not depend on the head count)
+    x = _t(counter_normal(15, "x", (2, 4, 3, 9, 12)))
+    cond = _t(counter_normal(16, "c", (2, 11, cfg.cross_attention_dim)))
+    ref = unet3d_forward(usd, cfg, x, 301, cond)
+    ref8 = unet3d_forward(usd, TINY_UNET, x, 301, cond)
+    assert rel_err(ref, ref8) > 1e-3                       # (another model: the head split changes the attention)
+    try:
+        m.engine.set_compute_dtype(mode)
+        y = m(x.cuda(), 301, cond.cuda()).sample
+    finally:
+        m.engine.set_compute_dtype("fp32")
+    assert rel_err(y, ref) < (1e-4 if mode == "fp32" else 5e-3), rel_err(y, ref)
+    if mode == "fp32":
+        u = UNet3DConditionModel(attention_head_dim=(8, 8, 8, 8), device=0, **kw)
+        u.load_state_dict(usd)
+        assert u.ucfg.attention_head_dim == 8
+        with pytest.raises(ValueError, match="entries"):
+            UNet3DConditionModel(attention_head_dim=(8, 8), device=0, **kw)
+        m.set_attention_slice("auto")                       # per-block head counts reach the slice check (unet.py:209-272): 16 blocks x 3
+        assert m._attention_slice[:3] == [2, 2, 2] and m._attention_slice[-3:] == [2, 2, 2] and max(m._attention_slice) == 8
+        assert len(m._attention_slice) == 48
+
+
 def test_memory_knobs_of_the_reference_objects_are_accepted(tiny):
     """set_attention_slice (unet.py:209-272), enable_gradient_checkpointing (:274-276), enable_sequential_cpu_offload
     (pipeline_tuneeeg2video.py:121-131): a caller that sets them keeps working; the argument checks and messages of
