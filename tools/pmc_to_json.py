@@ -18,8 +18,9 @@ CLASSES = [("bgemm", "igemm_bf16"), ("igemm_kernel", "igemm_f32"), ("igemm_k16_k
 def classify(name):
     for pat, cls in CLASSES:
         if pat in name:
-            # (round 5: the 16-bit kernels are templates over the element type -- the fp16 instances carry _Float16 in their names)
-            return cls.replace("bf16", "fp16") if cls.endswith("bf16") and "_Float16" in name else cls
+            # (round 5: the 16-bit kernels are templates over the element type -- the fp16 instances carry `_Float16` in their demangled and
+            # `IDF16_` in their mangled names; bf16: `__bf16` / `IDF16b`)
+            return cls.replace("bf16", "fp16") if cls.endswith("bf16") and ("_Float16" in name or "IDF16_" in name) else cls
     return None
 
 
