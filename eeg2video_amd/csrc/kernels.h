@@ -164,6 +164,7 @@ struct GroupNormArgs {
     // small-batch dispatch family (16-bit modes): where a (sample, group) slice fits LDS, ONE kernel reads it once, folds and applies
     // (gn_fused_small_kernel) instead of the three launches -- another summation order, so the family picks it, never the batch
     int fused_small = 0;
+    int small_chunks = 0;          // the family's 64-row statistics / apply chunks at every level (two samples: 108 chunks of 256 rows for 256 CUs)
 };
 // the canonical row-block sums of a stored bf16 tensor x[rows][C] (rows % 64 == 0): out[rows / 64][C][2], bit-identical to what the
 // staged epilogue of bgemm_t256_kernel leaves for a tensor of the same width (rpp = rbsum_rows_per_pass(C))

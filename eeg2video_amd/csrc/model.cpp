@@ -597,7 +597,11 @@ struct Runner {
         a.samples = samples; a.P = P; a.groups = groups; a.eps = eps; a.silu = act ? 1 : 0;
         a.ws_part = c->gn_part; a.ws_scale = c->gn_scale;
         if (bf() && P % 64 == 0) { a.rb0 = rb0; a.rb1 = c1 > 0 ? rb1 : nullptr; }
-        a.fused_small = (c->small_family && bf()) ? 1 : 0;      // (16-bit modes only: the fp32 mode keeps one summation order at every batch)
+        // (16-bit modes only: the fp32 mode keeps one summation order at every batch.  E2V_GN_FUSED_SMALL = 3: the one-kernel form in
+        // BOTH families -- the A/B that priced it at B = 32, profiles/r05_shape_ab_b32_gn_fused.log)
+        static const int* const gn_fused = knob("E2V_GN_FUSED_SMALL", 1);
+        a.small_chunks = (c->small_family && bf()) ? 1 : 0;
+        a.fused_small = (bf() && (c->small_family || *gn_fused == 3)) ? 1 : 0;
         groupnorm(a, s);
         return out;
     }

@@ -513,7 +513,7 @@ static std::string gn_shape_tag(const GroupNormArgs& a) {
 
 static void groupnorm_stats_launch(const GroupNormArgs& a, hipStream_t s) {
     const int Ctot = a.c0 + a.c1;
-    const int crows = gn_chunk_rows(a.P, a.fused_small != 0);
+    const int crows = gn_chunk_rows(a.P, a.small_chunks != 0);
     const int chunks = (a.P + crows - 1) / crows;
     auto part = [&](const float* x, int ld, int C, int coff) {
         const int qt = quad_tile(C / 4);
@@ -580,7 +580,7 @@ static void groupnorm_bf16_launch(const GroupNormArgs& a, hipStream_t s) {
     const size_t rows = (size_t)a.samples * a.P;
     if (*rowsp) {
         const int ot = oct_tile(a.c1 > 0 ? gcd_int(a.c0 / 8, a.c1 / 8) : a.c0 / 8);
-        const int crows = gn_chunk_rows(a.P, a.fused_small != 0);
+        const int crows = gn_chunk_rows(a.P, a.small_chunks != 0);
         const dim3 grid((a.P + crows - 1) / crows, a.samples);
         dry_tag(" + gn_apply8_rows_kernel rows" + std::to_string(crows));
         h16_dispatch(a.bf16, [&](auto h16_tag) {

@@ -71,13 +71,13 @@ def test_gather_options_and_budget_guard_parse(bench):
 
 
 def test_committed_bench_lines_keep_the_contract_and_quote_the_committed_pmc_traffic():
-    """profiles/r04_bench_*.json are the lines `bench.py` printed on the GPU box: the driver's contract keys, the `roofline` and
-    `cpu_baseline` objects, the `configs2` leg in the default line -- and `roofline.traffic` must be the figure of
+    """profiles/r05_bench_*.json are the lines `bench.py` printed on the GPU box: the driver's contract keys, the `roofline` and
+    `cpu_baseline` objects, the `configs2` leg in the default line (4 timed passes) -- and `roofline.traffic` must be the figure of
     profiles/pmc_dominant_kernel.json for that batch / dtype (the PMC passes and the bench lines are regenerated together)."""
     import json
     prof = os.path.join(ROOT, "profiles")
     pmc = json.load(open(os.path.join(prof, "pmc_dominant_kernel.json")))
-    d = json.load(open(os.path.join(prof, "r04_bench_default.json")))
+    d = json.load(open(os.path.join(prof, "r05_bench_default.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
         assert k in d, k
@@ -89,13 +89,19 @@ def test_committed_bench_lines_keep_the_contract_and_quote_the_committed_pmc_tra
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     assert d["parity"]["frames_max_abs"] < d["parity"]["tolerance_frames_max_abs"]
     c2 = d["configs2"]
-    assert c2["dtype"] == "bf16" and c2["value"] > 0 and c2["roofline"]["kernel"] == "igemm_bf16"
+    assert c2["dtype"] == "bf16" and c2["value"] > 0 and c2["steps"] == 4 and c2["roofline"]["kernel"] == "igemm_bf16"
     assert c2["roofline"]["traffic"] == pmc["igemm_bf16"]["hbm_bytes_per_launch"] and pmc["igemm_bf16"]["batch"] == 32
-    b = json.load(open(os.path.join(prof, "r04_bench_bf16_b32.json")))
+    b = json.load(open(os.path.join(prof, "r05_bench_bf16_b32.json")))
     assert b["dtype"] == "bf16" and b["roofline"]["traffic"] == pmc["igemm_bf16"]["hbm_bytes_per_launch"]
-    # README / DESIGN quote the bf16 parity figure of THIS committed line (it moves with every change of a rounding)
-    quoted = f"{b['parity']['frames_max_abs']:.1e}".replace("e-0", "e-")
-    for doc in ("README.md", "DESIGN.md"):
-        assert quoted in open(os.path.join(ROOT, doc)).read(), (doc, quoted)
+    h = json.load(open(os.path.join(prof, "r05_bench_fp16_b32.json")))     # the fp16 mode's line: the same contract, its own class and tolerance
+    assert h["dtype"] == "f16" and h["roofline"]["kernel"] == "igemm_fp16" and h["roofline"]["peak"] == b["roofline"]["peak"]
+    assert h["roofline"]["traffic"] == pmc["igemm_fp16"]["hbm_bytes_per_launch"] and pmc["igemm_fp16"]["dtype"] == "fp16"
+    assert h["parity"]["frames_max_abs"] < h["parity"]["tolerance_frames_max_abs"] <= 0.25 * b["parity"]["tolerance_frames_max_abs"]
+    assert 8.0 * h["parity"]["frames_max_abs"] < 1.2 * b["parity"]["frames_max_abs"]      # an eighth of the bf16 distance (three more mantissa bits)
+    # README / DESIGN quote the 16-bit parity figures of THESE committed lines (they move with every change of a rounding)
+    for line in (b, h):
+        quoted = f"{line['parity']['frames_max_abs']:.1e}".replace("e-0", "e-")
+        for doc in ("README.md", "DESIGN.md"):
+            assert quoted in open(os.path.join(ROOT, doc)).read(), (doc, quoted)
     wp = b["roofline"]["whole_path"]
     assert abs(wp["achieved_tflops"] - b["value"] * wp["algorithmic_tflop_per_clip"]) < 1e-6 and abs(wp["frac"] - wp["achieved_tflops"] / wp["peak"]) < 1e-9
