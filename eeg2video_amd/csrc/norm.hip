@@ -447,7 +447,7 @@ __global__ __launch_bounds__(1024) void gn_fused_small_kernel(const H* __restric
     const int Ctot = c0 + c1, cpg = Ctot / groups, ppr = cpg / 2;      // channel pairs per row of the slice
     unsigned* const tile = reinterpret_cast<unsigned*>(gnf_lds);       // [P][ppr] packed pairs
     float* const gb = reinterpret_cast<float*>(tile + (size_t)P * ppr);   // [2][cpg]: gamma, beta -> scale, shift
-    double* const red = reinterpret_cast<double*>(gb + 2 * cpg + ((2 * cpg) & 1));      // [2][16] wave sums (8-byte aligned: P * ppr + 2 cpg is even or padded)
+    double* const red = reinterpret_cast<double*>(gb + 2 * cpg + ((P * ppr) & 1));      // [2][16] wave sums, 8-byte aligned (2 cpg is even: pad when P x ppr is odd)
     const int cbase = g * cpg;
     const size_t row0 = (size_t)slab * P;
     const int items = P * ppr;

@@ -1056,7 +1056,8 @@ def test_h16_splitk_conv_and_linear_equal_the_unsplit_kernels_to_summation_order
 
 
 @pytest.mark.parametrize("samples,P,c0,c1,groups,silu", [(2, 240, 1280, 0, 32, True), (2, 240, 1280, 1280, 32, True), (3, 864, 1280, 640, 32, True),
-                                                         (12, 144, 1280, 0, 32, False), (2, 50, 64, 32, 8, True), (1, 2304, 320, 0, 32, False)])
+                                                         (12, 144, 1280, 0, 32, False), (2, 50, 64, 32, 8, True), (1, 2304, 320, 0, 32, False),
+                                                         (3, 45, 80, 0, 8, True)])        # (45 rows x 5 channel pairs: an odd piece count)
 def test_h16_groupnorm_one_kernel_form_of_the_small_batch_family(bf, samples, P, c0, c1, groups, silu):
     """gn_fused_small_kernel (norm.hip): one workgroup per (sample, group) reads its P x cpg slice once (both sources of a concat, groups
     that straddle the seam: 1920 / 32 = 60 does not divide 1280), folds in fp64 and applies from LDS -- the small-batch family's
