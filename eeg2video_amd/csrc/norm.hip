@@ -239,8 +239,9 @@ __global__ __launch_bounds__(256) void gn_partial8_kernel(const H* __restrict__ 
 }
 
 #ifdef E2V_AB          // the flat-index apply pass (E2V_GN_ROWS = 0): the other arm of the A/B that adopted the row-tiled one
-__global__ __launch_bounds__(256) void gn_apply8_kernel(const __bf16* __restrict__ x0, const __bf16* __restrict__ x1, int c0, int c1,
-                                                        int ld0, int ld1, const float* __restrict__ scsh, __bf16* __restrict__ out,
+template <typename H>
+__global__ __launch_bounds__(256) void gn_apply8_kernel(const H* __restrict__ x0, const H* __restrict__ x1, int c0, int c1,
+                                                        int ld0, int ld1, const float* __restrict__ scsh, H* __restrict__ out,
                                                         int ldo, int P, size_t rows, int act) {
     const int Ctot = c0 + c1;
     const int CO = Ctot / 8;
@@ -597,9 +598,12 @@ static void groupnorm_bf16_launch(const GroupNormArgs& a, hipStream_t s) {
     const size_t tot8 = rows * (Ctot / 8);
     const int blk8 = (int)((tot8 + 255) / 256 < 16384 ? (tot8 + 255) / 256 : 16384);
     dry_tag(" + gn_apply8_kernel");
-    E2V_KLAUNCH(gn_apply8_kernel, dim3(blk8), dim3(256), 0, s, reinterpret_cast<const __bf16*>(a.x0),
-                       reinterpret_cast<const __bf16*>(a.x1), a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<__bf16*>(a.out), a.ldo,
-                       a.P, rows, a.silu);
+    h16_dispatch(a.bf16, [&](auto h16_tag) {
+        using H = decltype(h16_tag);
+        E2V_KLAUNCH(gn_apply8_kernel<H>, dim3(blk8), dim3(256), 0, s, reinterpret_cast<const H*>(a.x0),
+                    reinterpret_cast<const H*>(a.x1), a.c0, a.c1, a.ld0, a.ld1, a.ws_scale, reinterpret_cast<H*>(a.out), a.ldo,
+                    a.P, rows, a.silu);
+    });
 #else
     (void)rows; (void)Ctot;
 #endif
