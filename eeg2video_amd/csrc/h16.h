@@ -49,6 +49,14 @@ template <> struct H16Traits<_Float16> {
     static constexpr unsigned short max_marker_bits = 0x4000;
 };
 
+// the bit patterns above are what the compiler's own conversions produce (checked where it can be: at compile time)
+static_assert(__builtin_bit_cast(unsigned short, (_Float16)1.0f) == H16Traits<_Float16>::one_bits &&
+              __builtin_bit_cast(unsigned short, (_Float16)2.0f) == H16Traits<_Float16>::max_marker_bits &&
+              __builtin_bit_cast(unsigned short, (_Float16)32768.0f) == H16Traits<_Float16>::mask_marker_bits, "fp16 constants");
+static_assert((__builtin_bit_cast(unsigned, 1.0f) >> 16) == H16Traits<__bf16>::one_bits &&
+              (__builtin_bit_cast(unsigned, 1.0f) >> 16) == H16Traits<__bf16>::max_marker_bits &&
+              (__builtin_bit_cast(unsigned, 1152921504606846976.0f) >> 16) == H16Traits<__bf16>::mask_marker_bits, "bf16 constants (the high half of the fp32 pattern)");
+
 // one MFMA step of the two tile shapes the kernels use, by operand type
 __device__ __forceinline__ h16_f32x16 mfma_32x32x16(const hx8<__bf16> a, const hx8<__bf16> b, const h16_f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);

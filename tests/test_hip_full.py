@@ -509,7 +509,7 @@ def test_bf16_groupnorm_sums_from_the_producer_are_the_canonical_ones(full):
     (sum, sum of squares) per 64-row block and channel with its output and the GroupNorm behind it skips its statistics pass.  Which
     kernel serves a conv depends on the tile count, i.e. on the batch, so the sums are defined by ONE summation order: the staged
     epilogue of the 256-row kernel and the stand-alone kernel that serves every other case must agree BIT FOR BIT.  6 UNet samples at
-    full size (324 tiles per level-0 conv: the 256-row kernel) + one VAE frame pair: E2V_GN_RB_EPILOGUE = 0 sends every tensor through
+    full size (324 tiles per level-0 conv: the 256-row kernel) + three VAE frames: E2V_GN_RB_EPILOGUE = 0 sends every tensor through
     the stand-alone kernel -> identical outputs; E2V_GN_RB = 0 (the statistics pass, the shipped configuration) -> the same result up to
     rounding.  (`make ab` builds: the mechanism is bit-exact but slower than the pass it replaces)"""
     pipe = full[0]
@@ -520,7 +520,7 @@ def test_bf16_groupnorm_sums_from_the_producer_are_the_canonical_ones(full):
         pytest.skip("producer-side GroupNorm sums were measured and not adopted: they exist in `make ab` builds only (DESIGN section 9)")
     x = _t(counter_normal(1234, "latent", (6, 4, 6, 36, 64))).cuda()
     cond = _t(counter_normal(1235, "cond", (6, 77, 768))).cuda()
-    z = _t(counter_normal(77, "z", (2, 4, 36, 64))).cuda()
+    z = _t(counter_normal(77, "z", (3, 4, 36, 64))).cuda()       # (three images: the large dispatch family, whose 256-row chunks the sums replace)
     outs = {}
     try:
         eng.set_compute_dtype("bf16")
