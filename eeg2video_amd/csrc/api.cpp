@@ -845,6 +845,8 @@ e2v_status e2v_op_groupnorm(e2v_ctx* c, const float* x0, int c0, const float* x1
             a.bf16 = c->h16_mode; a.x0 = b0.p; a.x1 = c1 > 0 ? b1.p : nullptr; a.out = bo.p;
             static const int* const fused = knob("E2V_GN_FUSED_SMALL", 1);      // 2 (test aid): the one-kernel form of the small-batch family here too
             a.fused_small = *fused == 2 ? 1 : 0;
+            static const int* const coop = E2V_AB_KNOB("E2V_GN_COOP", 0);        // `make ab` builds: 2 = the cooperative one-launch form here too
+            a.small_chunks = *coop == 2 ? 1 : 0;
             groupnorm(a, s);
             cvt_rows(bo.p, C, c->h16_mode, out, C, 0, rows, C, C, s);
         } else {

@@ -12,6 +12,9 @@
 #include "kernels.h"
 #include "prof.h"
 #include "act_io.h"
+#ifdef E2V_AB
+#include <hip/hip_cooperative_groups.h>      // gn_coop_kernel (measured, not adopted)
+#endif
 #include <string>
 #include <type_traits>
 
@@ -83,11 +86,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     }
 }
 
-// grid (groups, slabs), one wave each
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, int chunks, int Ctot, int groups,
-                                                         int P, float eps, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float* __restrict__ scsh) {
-    const int g = blockIdx.x, slab = blockIdx.y, lane = threadIdx.x;
+// the fold of one (slab, group) by one wave: fp64 over the chunks' per-channel partials, (scale, shift) per channel out
+__device__ __forceinline__ void gn_finalize_unit(const float* __restrict__ part, int chunks, int Ctot, int groups, int P, float eps,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scsh,
+                                                 const int g, const int slab, const int lane) {
     const int cpg = Ctot / groups;
     double s = 0.0, ss = 0.0;
     const int total = chunks * cpg;
@@ -113,6 +115,13 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
         o[0] = (float)(rstd * ga);
         o[1] = (float)((double)beta[c] - mean * rstd * ga);
     }
+}
+
+// grid (groups, slabs), one wave each
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, int chunks, int Ctot, int groups,
+                                                         int P, float eps, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ scsh) {
+    gn_finalize_unit(part, chunks, Ctot, groups, P, eps, gamma, beta, scsh, blockIdx.x, blockIdx.y, threadIdx.x);
 }
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
@@ -170,6 +179,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
 // instruction the bf16 passes ran at 2.2-2.9 TB/s effective.  These variants give every lane 8 channels (one 16-byte load /
 // store), the arithmetic is unchanged (fp32 sums of <= 64 values per thread, fp64 fold, fp32 affine).
 struct F8 { f32x4 lo, hi; };
+typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
 template <typename H>      // H: bf16 / fp16 (h16.h)
 __device__ __forceinline__ F8 ld8(const H* p) {
     const hx8<H> v = *reinterpret_cast<const hx8<H>*>(p);
@@ -507,6 +517,120 @@ static bool gn_fused_small_applies(const GroupNormArgs& a) {
     return gn_fused_small_bytes(a) <= (size_t)144 * 1024;
 }
 
+#ifdef E2V_AB
+// ---- ONE launch for a tensor that fits the chip's LDS: the small-batch family at levels 0 / 1 ------------------------------------------
+// Two samples at level 0 are 17.7 MB (35 MB with a concatenated skip): 69-138 KB per CU.  The three-launch path reads that tensor twice
+// and spends most of its 37 us in the ramp and drain of three dependent launches of ~100 workgroups.  Here the tensor is read ONCE into
+// the LDS of <= 256 co-resident workgroups (cooperative launch: the runtime refuses a grid that is not resident as a whole), each owning
+// a run of rows of one sample: statistics per channel from LDS (partials in the layout of gn_partial8_kernel), grid barrier, the fold of
+// every (sample, group) by one wave (gn_finalize_unit: the same fp64 fold), grid barrier, the affine (+ SiLU) applied from LDS.  Another
+// grouping of the partial sums than the chunked path (rows per workgroup instead of 64-row chunks), so the small-batch family picks it.
+// BUILT, PARITY-TESTED, MEASURED AND NOT ADOPTED (`make ab`, E2V_GN_COOP = 1; profiles/r05_shape_ab_b1_gn_cooperative.log): the
+// cooperative launch itself costs more than the two launches it saves -- S2 P13824 C320 32 -> 92 us, S12 P2304 C320 20 -> 86 us, a B = 1
+// step 27.1 -> 29.2 ms (1.44 -> 1.30 clips/s).
+template <typename H, bool ACT>
+__global__ __launch_bounds__(1024) void gn_coop_kernel(const H* __restrict__ x0, const H* __restrict__ x1, int c0, int c1, int ld0, int ld1,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, H* __restrict__ out, int ldo,
+                                                      int P, int groups, float eps, int wps, int rows_per_wg, int RS, float* __restrict__ part,
+                                                      float* __restrict__ scsh) {
+    extern __shared__ __attribute__((aligned(16))) char gnc_lds[];
+    namespace cg = cooperative_groups;
+    cg::grid_group grid = cg::this_grid();
+    const int tid = threadIdx.x;
+    const int Ctot = c0 + c1, CO = Ctot / 8;
+    const int slab = blockIdx.x / wps, chunk = blockIdx.x - slab * wps;
+    const int r0 = chunk * rows_per_wg, r1 = min(P, r0 + rows_per_wg), nrows = max(r1 - r0, 0);
+    u32x4g* const tile = reinterpret_cast<u32x4g*>(gnc_lds);                                   // [nrows][CO] 16-byte pieces
+    float* const scratch = reinterpret_cast<float*>(gnc_lds + (size_t)rows_per_wg * CO * 16);   // [RS][CO][16] floats, then the sample's (scale, shift)
+    const size_t row0 = (size_t)slab * P + r0;
+    const int pieces = nrows * CO;
+    for (int i = tid; i < pieces; i += 1024) {                // coalesced: consecutive lanes = consecutive 16-byte pieces of a row
+        const int r = i / CO, q = i - r * CO, c = q * 8;
+        const H* src = c < c0 ? x0 + (row0 + r) * ld0 + c : x1 + (row0 + r) * ld1 + (c - c0);
+        tile[i] = *reinterpret_cast<const u32x4g*>(src);
+    }
+    __syncthreads();
+    // statistics from LDS: thread (row subset rs, octet q) sums rows rs, rs + RS, ... of its 8 channels
+    if (tid < RS * CO) {
+        const int rs = tid / CO, q = tid - rs * CO;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, ss0 = s0, ss1 = s0;
+        for (int r = rs; r < nrows; r += RS) {
+            const hx8<H> v = __builtin_bit_cast(hx8<H>, tile[r * CO + q]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = (float)v[e], b = (float)v[4 + e];
+                s0[e] += a; s1[e] += b;
+                ss0[e] = fmaf(a, a, ss0[e]); ss1[e] = fmaf(b, b, ss1[e]);
+            }
+        }
+        f32x4* d = reinterpret_cast<f32x4*>(scratch + ((size_t)rs * CO + q) * 16);
+        d[0] = s0; d[1] = s1; d[2] = ss0; d[3] = ss1;
+    }
+    __syncthreads();
+    if (tid < CO) {                                           // row subsets in order -> this workgroup's partial of the octet's 8 channels
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, ss0 = s0, ss1 = s0;
+        for (int rs = 0; rs < RS; ++rs) {
+            const f32x4* d = reinterpret_cast<const f32x4*>(scratch + ((size_t)rs * CO + tid) * 16);
+            s0 += d[0]; s1 += d[1]; ss0 += d[2]; ss1 += d[3];
+        }
+        float* dst = part + ((size_t)(slab * wps + chunk) * Ctot + tid * 8) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dst[2 * e] = s0[e]; dst[2 * e + 1] = ss0[e];
+            dst[8 + 2 * e] = s1[e]; dst[8 + 2 * e + 1] = ss1[e];
+        }
+    }
+    grid.sync();
+    {   // (sample, group) units dealt to the workgroups' first waves
+        const int units = (int)(gridDim.x / wps) * groups;
+        if (tid < 64)
+            for (int u = blockIdx.x; u < units; u += gridDim.x)
+                gn_finalize_unit(part, wps, Ctot, groups, P, eps, gamma, beta, scsh, u % groups, u / groups, tid);
+    }
+    grid.sync();
+    for (int i = tid; i < 2 * Ctot; i += 1024) scratch[i] = scsh[(size_t)slab * Ctot * 2 + i];       // the sample's (scale, shift) pairs
+    __syncthreads();
+    for (int i = tid; i < pieces; i += 1024) {
+        const int r = i / CO, q = i - r * CO, c = q * 8;
+        const hx8<H> v = __builtin_bit_cast(hx8<H>, tile[i]);
+        const f32x4* sc = reinterpret_cast<const f32x4*>(scratch + (size_t)c * 2);
+        const f32x4 a = sc[0], b = sc[1], d = sc[2], e = sc[3];
+        f32x4 lo, hi;
+        lo[0] = (float)v[0] * a[0] + a[1]; lo[1] = (float)v[1] * a[2] + a[3]; lo[2] = (float)v[2] * b[0] + b[1]; lo[3] = (float)v[3] * b[2] + b[3];
+        hi[0] = (float)v[4] * d[0] + d[1]; hi[1] = (float)v[5] * d[2] + d[3]; hi[2] = (float)v[6] * e[0] + e[1]; hi[3] = (float)v[7] * e[2] + e[3];
+        if (ACT) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { lo[k] = silu_f(lo[k]); hi[k] = silu_f(hi[k]); }
+        }
+        st8(out + (row0 + r) * ldo + c, lo, hi);
+    }
+}
+
+// The plan of a cooperative launch: workgroups per sample, rows per workgroup, row subsets of the statistics phase, LDS bytes; ok = false
+// when the call is not eligible (the three-launch path serves it)
+struct GnCoopPlan { bool ok; int wps, rows, RS; size_t smem; };
+static GnCoopPlan gn_coop_plan(const GroupNormArgs& a) {
+    GnCoopPlan p{false, 0, 0, 0, 0};
+    static const int* const on = knob("E2V_GN_COOP", 0);
+    const int Ctot = a.c0 + a.c1;
+    if (!*on || !a.small_chunks || !a.bf16 || !a.out || a.rb0 || a.rb1 || a.samples < 1 || a.samples > 256) return p;
+    if ((a.c0 & 7) || (a.c1 & 7) || ((a.ld0 | a.ld1 | a.ldo) & 7) || Ctot > 2560 || Ctot % a.groups) return p;
+    const int CO = Ctot / 8;
+    p.wps = 256 / a.samples;
+    if (p.wps > groupnorm_chunks(a.P)) p.wps = groupnorm_chunks(a.P);      // (the partial-sum workspace holds one entry per 64-row chunk)
+    if (p.wps < 1) return p;
+    p.rows = (a.P + p.wps - 1) / p.wps;
+    p.wps = (a.P + p.rows - 1) / p.rows;                      // no empty workgroups
+    p.RS = (int)((size_t)20 * 1024 / ((size_t)CO * 64));
+    p.RS = p.RS < 1 ? 1 : (p.RS > 8 ? 8 : p.RS);
+    if (p.RS * CO > 1024) return p;
+    const size_t scratch = (size_t)p.RS * CO * 64 > (size_t)Ctot * 8 ? (size_t)p.RS * CO * 64 : (size_t)Ctot * 8;
+    p.smem = (size_t)p.rows * CO * 16 + scratch;
+    p.ok = p.smem <= (size_t)158 * 1024;
+    return p;
+}
+#endif
+
 static std::string gn_shape_tag(const GroupNormArgs& a) {
     return " S" + std::to_string(a.samples) + " P" + std::to_string(a.P) + " C" + std::to_string(a.c0) + (a.c1 ? "+" + std::to_string(a.c1) : "") + " g" +
            std::to_string(a.groups);
@@ -629,6 +753,31 @@ void groupnorm(const GroupNormArgs& a, hipStream_t s) {
         });
         return;
     }
+#ifdef E2V_AB              // (the cooperative one-launch form: measured slower than the launches it saves, see gn_coop_kernel)
+    if (const GnCoopPlan cp = gn_coop_plan(a); cp.ok) {
+        bool launched = dry_run();
+        if (!launched) {
+            h16_dispatch(a.bf16, [&](auto h16_tag) {
+                using H = decltype(h16_tag);
+                auto go = [&](auto kern) {
+                    E2V_KATTR(kern, 158 * 1024);
+                    const H* x0 = reinterpret_cast<const H*>(a.x0); const H* x1 = reinterpret_cast<const H*>(a.x1);
+                    H* out = reinterpret_cast<H*>(a.out);
+                    int c0 = a.c0, c1 = a.c1, ld0 = a.ld0, ld1 = a.ld1, ldo = a.ldo, P = a.P, groups = a.groups, wps = cp.wps, rows = cp.rows, RS = cp.RS;
+                    float eps = a.eps;
+                    const float* gamma = a.gamma; const float* beta = a.beta;
+                    float* part = a.ws_part; float* scsh = a.ws_scale;
+                    void* args[] = {&x0, &x1, &c0, &c1, &ld0, &ld1, &gamma, &beta, &out, &ldo, &P, &groups, &eps, &wps, &rows, &RS, &part, &scsh};
+                    // (the runtime refuses a cooperative grid that would not be resident as a whole: then the three launches below serve the call)
+                    launched = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3(a.samples * cp.wps), dim3(1024), args, (unsigned)cp.smem, s) == hipSuccess;
+                    if (!launched) (void)hipGetLastError();
+                };
+                if (a.silu) go(gn_coop_kernel<H, true>); else go(gn_coop_kernel<H, false>);
+            });
+        }
+        if (launched) { dry_tag(" -> gn_coop_kernel wps" + std::to_string(cp.wps)); return; }
+    }
+#endif
     const size_t rows = (size_t)a.samples * a.P;
     const size_t total = rows * (Ctot / 4);
     const int blocks = (int)((total + 511) / 512 < 16384 ? (total + 511) / 512 : 16384);

@@ -1079,3 +1079,36 @@ def test_h16_groupnorm_one_kernel_form_of_the_small_batch_family(bf, samples, P,
     y0 = run()
     close(y, ref, rtol=tol16(8e-3), atol=tol16(8e-3))
     close(y, y0, rtol=tol16(8e-3), atol=tol16(8e-3))
+
+
+@pytest.mark.parametrize("samples,P,c0,c1,groups,silu", [(2, 13824, 320, 0, 32, True), (2, 13824, 320, 320, 32, True), (2, 3456, 640, 0, 32, True),
+                                                         (2, 3456, 1280, 640, 32, True), (12, 2304, 320, 0, 32, False), (3, 1000, 64, 32, 8, True),
+                                                         (1, 77, 96, 0, 4, False)])
+def test_h16_groupnorm_cooperative_single_launch(bf, samples, P, c0, c1, groups, silu):
+    """gn_coop_kernel (norm.hip): the small-batch family's GroupNorm where the tensor fits the LDS of the chip -- read ONCE by <= 256
+    co-resident workgroups (cooperative launch), statistics from LDS, grid barrier, the fp64 fold per (sample, group), grid barrier,
+    apply from LDS.  The UNet's level-0 / level-1 shapes of one clip (two samples; per-frame norm: 12), a concat whose groups straddle the
+    seam, ragged rows per workgroup.  Against torch on the rounded inputs and against the three-launch path: one output rounding.
+    MEASURED AND NOT ADOPTED (the cooperative launch costs more than the two launches it saves: profiles/r05_shape_ab_b1_gn_cooperative.log):
+    the kernel exists in `make ab` builds only, where this test runs."""
+    try:
+        bf.set_knob("E2V_GN_COOP", 0)
+    except ValueError:
+        pytest.skip("the cooperative one-launch GroupNorm was measured and not adopted: `make ab` builds only (DESIGN 3.9)")
+    a = rnd(samples * P, c0, seed=710) * 1.5 + 0.2
+    s = rnd(samples * P, c1, seed=711) if c1 else None
+    g, be = rnd(c0 + c1, seed=712), rnd(c0 + c1, seed=713)
+    xin = (torch.cat([rb(a), rb(s)], 1) if c1 else rb(a)).reshape(samples, P, c0 + c1).permute(0, 2, 1)
+    ref = F.group_norm(xin, groups, g, be, 1e-5)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1).reshape(samples * P, c0 + c1)
+    ga, gs, gg, gb = a.cuda(), (s.cuda() if c1 else None), g.cuda(), be.cuda()
+    run = lambda: bf.op_groupnorm(ga, gg, gb, samples=samples, P=P, groups=groups, eps=1e-5, silu=silu, x1=gs)
+    try:
+        bf.set_knob("E2V_GN_COOP", 2)
+        y = run()
+    finally:
+        bf.set_knob("E2V_GN_COOP", 0)
+    y0 = run()
+    assert torch.isfinite(y).all()
+    close(y, ref, rtol=tol16(8e-3), atol=tol16(8e-3))
+    close(y, y0, rtol=tol16(8e-3), atol=tol16(8e-3))
