@@ -93,11 +93,21 @@ __device__ __forceinline__ void gn_finalize_unit(const float* __restrict__ part,
     const int cpg = Ctot / groups;
     double s = 0.0, ss = 0.0;
     const int total = chunks * cpg;
-    for (int i = lane; i < total; i += 64) {
-        const int ch = i / cpg, c = g * cpg + (i - ch * cpg);
-        const float* e = part + ((size_t)(slab * chunks + ch) * Ctot + c) * 2;
-        s += (double)e[0];
-        ss += (double)e[1];
+    // A lane adds its entries i = lane, lane + 64, ... IN THAT ORDER (the bits of every earlier build); eight loads are in flight at a
+    // time -- the one-at-a-time loop was a chain of L2 latencies: 13 us per launch at B = 1 (216 chunks x 10 channels: 34 rounds), 2.6 %
+    // of a step (profiles/r05_timeline_b1_bf16.json).
+    typedef float f32x2g __attribute__((ext_vector_type(2)));
+    for (int i0 = lane; i0 < total; i0 += 64 * 8) {
+        f32x2g e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + 64 * u, total - 1);
+            const int ch = i / cpg, c = g * cpg + (i - ch * cpg);
+            e[u] = *reinterpret_cast<const f32x2g*>(part + ((size_t)(slab * chunks + ch) * Ctot + c) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + 64 * u < total) { s += (double)e[u][0]; ss += (double)e[u][1]; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

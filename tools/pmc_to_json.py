@@ -36,27 +36,32 @@ def collect(d):
     return per
 
 
-per = collect(sys.argv[1])
-out = {}
-for cls, ctrs in per.items():
-    o = {}
-    for c, (ids, total) in ctrs.items():
-        o[c + "_per_launch"] = total / max(len(ids), 1)
-        o["launches"] = max(o.get("launches", 0), len(ids))
-    if "FETCH_SIZE_per_launch" in o:
-        o["hbm_read_bytes_per_launch_corrected_x2"] = o["FETCH_SIZE_per_launch"] * 1024.0 * 2.0
-    if "WRITE_SIZE_per_launch" in o:
-        o["hbm_write_bytes_per_launch"] = o["WRITE_SIZE_per_launch"] * 1024.0
-    if "hbm_read_bytes_per_launch_corrected_x2" in o and "hbm_write_bytes_per_launch" in o:
-        o["hbm_bytes_per_launch"] = o["hbm_read_bytes_per_launch_corrected_x2"] + o["hbm_write_bytes_per_launch"]
-    if "SQ_VALU_MFMA_BUSY_CYCLES_per_launch" in o and o.get("GRBM_GUI_ACTIVE_per_launch"):
-        # MFMA pipe utilisation: busy cycles per SIMD (1024 SIMDs) over the kernel's active cycles (GRBM_GUI_ACTIVE / 8 XCDs)
-        o["mfma_pipe_utilisation"] = (o["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / 1024.0) / (o["GRBM_GUI_ACTIVE_per_launch"] / 8.0)
-    out[cls] = o
-out["_source"] = ("rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; one pass each) over `" + sys.argv[3] +
-                  "`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); WRITE_SIZE as is (exact for 16-B-per-lane stores); "
-                  "averages over all launches of the kernel class in the run; E2V_SYNC_EACH_STEP=" + (sys.argv[4] if len(sys.argv) > 4 else "0") +
-                  (" (the stream drained after every DDIM step: <= ~680 launches in flight)" if len(sys.argv) > 4 and sys.argv[4] == "1"
-                   else " (every launch queued asynchronously as in the timed run)"))
-json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
-print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1, sort_keys=True))
+def main():
+    per = collect(sys.argv[1])
+    out = {}
+    for cls, ctrs in per.items():
+        o = {}
+        for c, (ids, total) in ctrs.items():
+            o[c + "_per_launch"] = total / max(len(ids), 1)
+            o["launches"] = max(o.get("launches", 0), len(ids))
+        if "FETCH_SIZE_per_launch" in o:
+            o["hbm_read_bytes_per_launch_corrected_x2"] = o["FETCH_SIZE_per_launch"] * 1024.0 * 2.0
+        if "WRITE_SIZE_per_launch" in o:
+            o["hbm_write_bytes_per_launch"] = o["WRITE_SIZE_per_launch"] * 1024.0
+        if "hbm_read_bytes_per_launch_corrected_x2" in o and "hbm_write_bytes_per_launch" in o:
+            o["hbm_bytes_per_launch"] = o["hbm_read_bytes_per_launch_corrected_x2"] + o["hbm_write_bytes_per_launch"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES_per_launch" in o and o.get("GRBM_GUI_ACTIVE_per_launch"):
+            # MFMA pipe utilisation: busy cycles per SIMD (1024 SIMDs) over the kernel's active cycles (GRBM_GUI_ACTIVE / 8 XCDs)
+            o["mfma_pipe_utilisation"] = (o["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / 1024.0) / (o["GRBM_GUI_ACTIVE_per_launch"] / 8.0)
+        out[cls] = o
+    out["_source"] = ("rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; one pass each) over `" + sys.argv[3] +
+                      "`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); WRITE_SIZE as is (exact for 16-B-per-lane stores); "
+                      "averages over all launches of the kernel class in the run; E2V_SYNC_EACH_STEP=" + (sys.argv[4] if len(sys.argv) > 4 else "0") +
+                      (" (the stream drained after every DDIM step: <= ~680 launches in flight)" if len(sys.argv) > 4 and sys.argv[4] == "1"
+                       else " (every launch queued asynchronously as in the timed run)"))
+    json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
