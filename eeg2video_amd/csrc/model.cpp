@@ -923,7 +923,8 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
     // conditioning -- conv_in, the first resnet, the first transformer block up to its cross-attention -- is computed once
     E2V_REQUIRE(!cfg_pair || (N % 2 == 0 && n_t == 1 && !unet.down[0].attn.empty()), E2V_EINVAL, "cfg_pair needs an even batch, one timestep and a first block with attention");
     const int N1 = cfg_pair ? N / 2 : N;
-    small_family = N <= 4;                                    // B <= 2 clips with their guidance pairs (model.h)
+    static const int* const fam_clips = E2V_AB_KNOB("E2V_SMALL_FAMILY_CLIPS", 4);      // (`make ab`: where the boundary lies was an A/B)
+    small_family = N <= 2 * *fam_clips;                       // B <= 4 clips with their guidance pairs (model.h)
     Runner R{this, s};
     const int groups = cfg.norm_num_groups;
     // heads of the blocks of resolution level l (unet.py:110-111,131,151,165,194: down block l, the mid block = level 3, up block 3 - l)
@@ -1094,7 +1095,7 @@ void e2v_ctx::build_step_caches(const int64_t* ts, int steps, const float* cond,
 // -----------------------------------------------------------------------------------------------------
 void e2v_ctx::vae_decode_frames(const float* z_cl, int nf, int h, int w, float* out_cl, hipStream_t s, bool small) {
     E2V_REQUIRE(vae_ready, E2V_ESTATE, "VAE weights are not finalized");
-    small_family = small;                                     // the CALL decodes at most two clips (the caller knows: a pass may be a call's ragged last group)
+    small_family = small;                                     // the CALL decodes at most four clips (the caller knows: a pass may be a call's ragged last group)
     Runner R{this, s};
     const int g = cfg.vae_norm_num_groups;
     const float eps = cfg.vae_norm_eps;

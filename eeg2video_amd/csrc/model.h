@@ -115,10 +115,11 @@ struct e2v_ctx {
     bool bf16_compute = false;                                   // e2v_set_compute_dtype: a 16-bit activation mode (16-bit MFMA, 16-bit rows in HBM) ...
     int h16_mode = 0;                                            // ... and which: 0 none, 1 bf16 (E2V_BF16), 2 fp16 (E2V_F16) -- the flag every 16-bit launch carries (h16.h)
     void set_h16_mode(int m) { h16_mode = m; bf16_compute = m != 0; }
-    // The SMALL-BATCH dispatch family (16-bit modes): set per call when the graph runs at most 4 UNet samples (B <= 2 clips with their
-    // guidance pairs: the reference's clip-by-clip loop, inference_eeg2video.py:90-100).  Launches that would leave most of the chip idle
+    // The SMALL-BATCH dispatch family (16-bit modes): set per call when the graph runs at most 8 UNet samples (B <= 4 clips with their
+    // guidance pairs: the reference's clip-by-clip loop, inference_eeg2video.py:90-100, and a caller that batches a few clips; the boundary
+    // was measured -- B = 3 / 4 gain 7 / 4 %, B = 5 / 6 / 8 2.4 / 1.7 / 0.5 %: profiles/r05_family_boundary.json).  Launches that would leave most of the chip idle
     // then take split-K (kernels.h: IgemmArgs::sk) -- another summation order, so bit-identity across batch sizes holds WITHIN a family
-    // (B >= 3: every kernel choice is a bit-identical alternative; B <= 2: held to the oracle bounds).
+    // (B >= 5: every kernel choice is a bit-identical alternative; B <= 4: held to the oracle bounds).
     bool small_family = false;
     std::vector<e2v::LinW> sem;                                  // semantic predictor layers (first one K-padded to 4)
     int sem_in_pad = 0;

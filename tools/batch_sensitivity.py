@@ -2,7 +2,7 @@
 profiles/r05_batch_sensitivity.json: clips/s, seconds per clip and the dominant class's rate per (dtype, batch), next to the round-4
 figures the review quoted (B = 1 1.07 / 0.38 clips/s bf16 / fp32)."""
 import glob, json, os, re, sys
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r5f"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r5y"
 out = {"_source": f"bench.py --dtype D --batch B --steps 3 --warmup 1 --no-cpu-baseline on one MI355X box ({src}); 50-step DDIM, CFG 12.5, 6x288x512 decode, "
                   "frames copied to the host inside the timed step",
        "round4": {"bf16": {"1": 1.07, "2": 1.72, "4": 2.35, "32": 3.25}, "fp32": {"1": 0.38, "8": 0.585}}, "round5": {}}
