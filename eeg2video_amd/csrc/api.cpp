@@ -444,7 +444,7 @@ static void decode_to_video(e2v_ctx* c, const float* z_cl, int B, int F, int h, 
     for (int b = 0; b < B; b += group) {
         const int nb = B - b < group ? B - b : group;
         c->vae_decode_frames(z_cl + (size_t)b * F * h * w * c->cfg.vae_latent_channels, nb * F, h, w,
-                             frames.p + (size_t)b * F * HW8 * C3, s, B <= *E2V_AB_KNOB("E2V_SMALL_FAMILY_CLIPS", 4));      // the dispatch family is the CALL's (model.h), not the pass's
+                             frames.p + (size_t)b * F * HW8 * C3, s, B <= *knob("E2V_SMALL_FAMILY_CLIPS", 4));      // the dispatch family is the CALL's (model.h), not the pass's
     }
     nchw_frames_to_ncfhw(frames.p, C3, videos, B, F, C3, HW8, post ? 0.5f : 1.0f, post ? 0.5f : 0.0f, post ? 1 : 0, s);
 }

@@ -44,11 +44,11 @@ bool set_knob(const char* name, int value) {
     if (it == t.end()) {
         static const char* const known[] = {"E2V_BGEMM_PERS", "E2V_BGEMM_256LIN", "E2V_BGEMM_256", "E2V_BGEMM_T256", "E2V_BGEMM_T256P", "E2V_BGEMM_T256P_BIAS_LDS",
                                             "E2V_ATTN_KT64", "E2V_ATTN_Q64", "E2V_ATTN_CROSS_RESIDENT", "E2V_TATTN_WAVE", "E2V_LN_ROWS", "E2V_BGEMM_UP2X",
-                                            "E2V_SPLITK", "E2V_SPLITK_FORCE", "E2V_GN_FUSED_SMALL", "E2V_BGEMM_S3_SMALL"
+                                            "E2V_SPLITK", "E2V_SPLITK_FORCE", "E2V_GN_FUSED_SMALL", "E2V_BGEMM_S3_SMALL", "E2V_SMALL_FAMILY_CLIPS"
 #ifdef E2V_AB                                // variants measured and not adopted / the other arm of an A/B / thresholds that measured +-0: `make AB=1` builds only
                                             , "E2V_BGEMM_S3", "E2V_BGEMM_LIN", "E2V_BGEMM_T256_TAIL", "E2V_ATTN_FOLD", "E2V_ATTN_Q64P", "E2V_ATTN_Q64_NW", "E2V_GN_ROWS", "E2V_GN_GROUP_MB", "E2V_GN_SKIP_PARTIAL", "E2V_GN_RB", "E2V_GN_RB_EPILOGUE",
                                             "E2V_BGEMM_256_MINROUNDS", "E2V_BGEMM_T256_MINK", "E2V_BGEMM_T256_MINTILES", "E2V_BGEMM_T256P_MAXK", "E2V_BGEMM_T256P_MINTILES", "E2V_GN_CHUNK_ROWS",
-                                            "E2V_GN_CHUNK_ROWS_SMALL", "E2V_IGEMM_HALF_BELOW", "E2V_SPLITK_MIN_DEPTH", "E2V_SPLITK_MAX_TILES", "E2V_GN_COOP", "E2V_SMALL_FAMILY_CLIPS"
+                                            "E2V_GN_CHUNK_ROWS_SMALL", "E2V_IGEMM_HALF_BELOW", "E2V_SPLITK_MIN_DEPTH", "E2V_SPLITK_MAX_TILES", "E2V_GN_COOP"
 #endif
 #ifdef E2V_ABLATE
                                             , "E2V_BGEMM_ABLATE"

@@ -923,7 +923,7 @@ Act e2v_ctx::unet_forward_cl(const float* sample_cl, const int64_t* host_t, int 
     // conditioning -- conv_in, the first resnet, the first transformer block up to its cross-attention -- is computed once
     E2V_REQUIRE(!cfg_pair || (N % 2 == 0 && n_t == 1 && !unet.down[0].attn.empty()), E2V_EINVAL, "cfg_pair needs an even batch, one timestep and a first block with attention");
     const int N1 = cfg_pair ? N / 2 : N;
-    static const int* const fam_clips = E2V_AB_KNOB("E2V_SMALL_FAMILY_CLIPS", 4);      // (`make ab`: where the boundary lies was an A/B)
+    static const int* const fam_clips = knob("E2V_SMALL_FAMILY_CLIPS", 4);      // (where the boundary lies was an A/B; 0: the large family at every batch -- the parity tests hold BOTH families to the oracle with one clip)
     small_family = N <= 2 * *fam_clips;                       // B <= 4 clips with their guidance pairs (model.h)
     Runner R{this, s};
     const int groups = cfg.norm_num_groups;

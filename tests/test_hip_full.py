@@ -227,18 +227,23 @@ def test_config0_bf16_mode_vs_the_bf16_run_of_the_oracle(full, config0):
         ref16 = generate(b16(usd), UNetConfig(), b16(vsd), VAEConfig(), lat.bfloat16(), cond.bfloat16(), unc.bfloat16(),
                          num_inference_steps=4, guidance_scale=12.5, trace=tr16).float()
     lat16 = tr16["latents"][-1].float()
-    try:
-        eng.set_compute_dtype("bf16")
-        vid, lat_out = eng.generate(lat.cuda(), cond.cuda(), unc.cuda(), 4, 12.5, 0.0, decode=True, return_latents=True)
-    finally:
-        eng.set_compute_dtype("fp32")
-    f_gpu, f_cpu, f_x = ((a.cpu() - b).abs().max().item() for a, b in ((vid, ref), (ref16, ref), (vid, ref16)))
-    l_gpu, l_cpu, l_x = rel_err(lat_out, trace["latents"][-1]), rel_err(lat16, trace["latents"][-1]), rel_err(lat_out, lat16)
-    print(f"bf16 configs[0]: frames max-abs  HIP-bf16 vs fp32 oracle {f_gpu:.3e} | torch-bf16 oracle vs fp32 oracle {f_cpu:.3e} | HIP-bf16 vs torch-bf16 {f_x:.3e}")
-    print(f"                 latents /max-ref HIP-bf16 vs fp32 oracle {l_gpu:.3e} | torch-bf16 oracle vs fp32 oracle {l_cpu:.3e} | HIP-bf16 vs torch-bf16 {l_x:.3e}")
-    assert torch.isfinite(vid).all() and vid.shape == ref.shape
-    assert f_gpu < 0.1 and l_gpu < 5e-2
-    assert f_gpu <= 1.5 * f_cpu + 1e-3 and l_gpu <= 1.5 * l_cpu + 1e-3
+    # one clip runs in the small-batch dispatch family; E2V_SMALL_FAMILY_CLIPS = 0 sends it through the LARGE family's
+    # kernels (what every batch of >= 5 clips runs): both are held to the oracle, same bounds
+    for family, clips in (("small", 4), ("large", 0)):
+        try:
+            eng.set_knob("E2V_SMALL_FAMILY_CLIPS", clips)
+            eng.set_compute_dtype("bf16")
+            vid, lat_out = eng.generate(lat.cuda(), cond.cuda(), unc.cuda(), 4, 12.5, 0.0, decode=True, return_latents=True)
+        finally:
+            eng.set_knob("E2V_SMALL_FAMILY_CLIPS", 4)
+            eng.set_compute_dtype("fp32")
+        f_gpu, f_cpu, f_x = ((a.cpu() - b).abs().max().item() for a, b in ((vid, ref), (ref16, ref), (vid, ref16)))
+        l_gpu, l_cpu, l_x = rel_err(lat_out, trace["latents"][-1]), rel_err(lat16, trace["latents"][-1]), rel_err(lat_out, lat16)
+        print(f"bf16 configs[0] ({family} family): frames max-abs  HIP-bf16 vs fp32 oracle {f_gpu:.3e} | torch-bf16 oracle vs fp32 oracle {f_cpu:.3e} | HIP-bf16 vs torch-bf16 {f_x:.3e}")
+        print(f"                 latents /max-ref HIP-bf16 vs fp32 oracle {l_gpu:.3e} | torch-bf16 oracle vs fp32 oracle {l_cpu:.3e} | HIP-bf16 vs torch-bf16 {l_x:.3e}")
+        assert torch.isfinite(vid).all() and vid.shape == ref.shape
+        assert f_gpu < 0.1 and l_gpu < 5e-2, family
+        assert f_gpu <= 1.5 * f_cpu + 1e-3 and l_gpu <= 1.5 * l_cpu + 1e-3, family
 
 
 def test_config0_fp16_mode_vs_fp32_oracle(full, config0):
@@ -249,16 +254,19 @@ def test_config0_fp16_mode_vs_fp32_oracle(full, config0):
     pipe, usd, vsd = full
     eng = pipe.unet.engine
     lat, cond, unc, ref, trace = config0
-    try:
-        eng.set_compute_dtype("fp16")
-        vid, lat_out = eng.generate(lat.cuda(), cond.cuda(), unc.cuda(), 4, 12.5, 0.0, decode=True, return_latents=True)
-    finally:
-        eng.set_compute_dtype("fp32")
-    f_gpu = (vid.cpu() - ref).abs().max().item()
-    l_gpu = rel_err(lat_out, trace["latents"][-1])
-    print(f"fp16 configs[0]: frames max-abs HIP-fp16 vs fp32 oracle {f_gpu:.3e} | final latents / max-ref {l_gpu:.3e}")
-    assert torch.isfinite(vid).all() and vid.shape == ref.shape
-    assert f_gpu < 0.025 and l_gpu < 1.25e-2
+    for family, clips in (("small", 4), ("large", 0)):         # (both dispatch families, as in the bf16 test above)
+        try:
+            eng.set_knob("E2V_SMALL_FAMILY_CLIPS", clips)
+            eng.set_compute_dtype("fp16")
+            vid, lat_out = eng.generate(lat.cuda(), cond.cuda(), unc.cuda(), 4, 12.5, 0.0, decode=True, return_latents=True)
+        finally:
+            eng.set_knob("E2V_SMALL_FAMILY_CLIPS", 4)
+            eng.set_compute_dtype("fp32")
+        f_gpu = (vid.cpu() - ref).abs().max().item()
+        l_gpu = rel_err(lat_out, trace["latents"][-1])
+        print(f"fp16 configs[0] ({family} family): frames max-abs HIP-fp16 vs fp32 oracle {f_gpu:.3e} | final latents / max-ref {l_gpu:.3e}")
+        assert torch.isfinite(vid).all() and vid.shape == ref.shape
+        assert f_gpu < 0.025 and l_gpu < 1.25e-2, family
 
 
 @pytest.mark.parametrize("mode16", ["bf16", "fp16"])
@@ -335,8 +343,9 @@ def test_configs2_bf16_batch32_equals_single_clip_calls(full, mode16):
         eng.set_compute_dtype("fp32")
 
 
+@pytest.mark.parametrize("family", ["small", "large"])
 @pytest.mark.parametrize("mode16", ["bf16", "fp16"])
-def test_config0_bf16_teacher_forced_steps_vs_fp32_oracle(full, config0, mode16):
+def test_config0_bf16_teacher_forced_steps_vs_fp32_oracle(full, config0, mode16, family):
     """Per-step bf16 check (SURVEY 8(d) procedure ii in the bf16-activation mode): the fp32 oracle's latents of step k-1 go into the
     bf16 UNet of step k, so that rounding does not chain across steps and a defect of a few 1e-2 in ONE layer cannot hide inside
     the end-to-end noise.  Bounds, of the tensor's scale (max |ref|): each of the two UNet outputs (one bf16 forward against the
@@ -344,7 +353,9 @@ def test_config0_bf16_teacher_forced_steps_vs_fp32_oracle(full, config0, mode16)
     check; measured 1.1e-2 at step 0.  The guided eps = eps_u + 12.5 (eps_c - eps_u)
     amplifies the difference of the two forwards' rounding 12.5x (measured 9.0e-2 at step 0) and the DDIM update carries a third of
     that into the latents (3.1e-2): they are printed and only bounded loosely (0.25 / 0.1).
-    fp16 mode (the reference's own arithmetic): the same checks with every bound a QUARTER of the bf16 one (5e-3; 0.0625 / 0.025)."""
+    fp16 mode (the reference's own arithmetic): the same checks with every bound a QUARTER of the bf16 one (5e-3; 0.0625 / 0.025).
+    family: one clip runs in the small-batch dispatch family; E2V_SMALL_FAMILY_CLIPS = 0 sends the same clip through the
+    LARGE family's kernels (what every batch of >= 5 clips runs), so that BOTH families are held to the oracle, same bounds."""
     q = 1.0 if mode16 == "bf16" else 0.25
     pipe = full[0]
     eng = pipe.unet.engine
@@ -353,6 +364,7 @@ def test_config0_bf16_teacher_forced_steps_vs_fp32_oracle(full, config0, mode16)
     emb = torch.cat([unc, cond]).cuda()
     x = lat
     try:
+        eng.set_knob("E2V_SMALL_FAMILY_CLIPS", 4 if family == "small" else 0)
         eng.set_compute_dtype(mode16)
         for k, t in enumerate(ts):
             xg = x.cuda()
@@ -365,7 +377,7 @@ def test_config0_bf16_teacher_forced_steps_vs_fp32_oracle(full, config0, mode16)
             e_u, e_c = rel_err(eps16[:1], eps32[:1]), rel_err(eps16[1:], eps32[1:])
             o_u, o_c = rel_err(eps16[:1], trace["eps_u"][k]), rel_err(eps16[1:], trace["eps_c"][k])     # against the ORACLE's two forwards
             e_g, e_x = rel_err(guided, trace["eps"][k]), rel_err(x_new, trace["latents"][k])
-            print(f"  {mode16} teacher-forced step {k} (t = {int(t)}): eps_uncond {o_u:.3e} eps_cond {o_c:.3e} (vs fp32 oracle; vs fp32 HIP "
+            print(f"  {mode16} ({family} family) teacher-forced step {k} (t = {int(t)}): eps_uncond {o_u:.3e} eps_cond {o_c:.3e} (vs fp32 oracle; vs fp32 HIP "
                   f"{e_u:.3e} / {e_c:.3e}) | guided eps {e_g:.3e} latents {e_x:.3e} (vs fp32 oracle), all max-abs / max-ref")
             assert torch.isfinite(eps16).all()
             assert o_u < 2e-2 * q and o_c < 2e-2 * q, k         # THE per-step bound: one 16-bit forward against the oracle's fp32 forward
@@ -373,6 +385,7 @@ def test_config0_bf16_teacher_forced_steps_vs_fp32_oracle(full, config0, mode16)
             assert e_g < 0.25 * q and e_x < 0.1 * q, k
             x = trace["latents"][k]
     finally:
+        eng.set_knob("E2V_SMALL_FAMILY_CLIPS", 4)
         eng.set_compute_dtype("fp32")
 
 
@@ -389,13 +402,16 @@ TAP_BOUND_BF16 = {"emb": 2e-5, "down0": 1.05e-2, "down1": 1.5e-2, "down2": 2e-2,
 TAP_BOUND_FP16 = {k: (v if k == "emb" else v / 4) for k, v in TAP_BOUND_BF16.items()}      # fp16 mode: a quarter of the bf16 bounds
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "fp16", "bf16-large", "fp16-large"])
 def test_config0_block_taps_vs_fp32_oracle(full, config0, mode):
     """Block-granularity parity at full size (UNet3DConditionModel.forward, unet.py:358-408): step 0 of configs[0] -- the oracle's own
     input [x; x], t = 751, [uncond; cond] -- through the HIP UNet with the outputs of every block copied out
     (e2v_op_unet_forward_taps), each compared with the tensor the fp32 ORACLE holds at the same point (oracle/unet3d.py taps: emb,
     down0..3, mid, up0..3).  fp32 mode: every tap within 1e-4 of its scale.  bf16 mode: per-tap bounds (TAP_BOUND_BF16) -- a
-    single-layer defect of 1e-2 shows up at ITS block instead of inside the end-to-end noise."""
+    single-layer defect of 1e-2 shows up at ITS block instead of inside the end-to-end noise.  "-large": the same clip through the
+    LARGE dispatch family's kernels (E2V_SMALL_FAMILY_CLIPS = 0; one clip alone runs in the small one), same per-tap bounds."""
+    large = mode.endswith("-large")
+    mode = mode.split("-")[0]
     pipe = full[0]
     eng = pipe.unet.engine
     lat, cond, unc, ref, trace = config0
@@ -404,10 +420,12 @@ def test_config0_block_taps_vs_fp32_oracle(full, config0, mode):
     emb = torch.cat([unc, cond]).cuda()
     xg = lat.cuda()
     try:
+        eng.set_knob("E2V_SMALL_FAMILY_CLIPS", 0 if large else 4)
         eng.set_compute_dtype(mode)
         eps, taps = eng.unet_forward_taps(torch.cat([xg, xg]), [t0], emb)
         plain = pipe.unet(torch.cat([xg, xg]), t0, emb).sample
     finally:
+        eng.set_knob("E2V_SMALL_FAMILY_CLIPS", 4)
         eng.set_compute_dtype("fp32")
     assert torch.equal(eps, plain)                           # the tapped forward IS the forward
     assert tuple(taps) == TAP_ORDER
@@ -416,7 +434,7 @@ def test_config0_block_taps_vs_fp32_oracle(full, config0, mode):
         assert taps[name].shape == taps_ref[name].shape, (name, taps[name].shape, taps_ref[name].shape)
         errs[name] = rel_err(taps[name], taps_ref[name])
     e_u, e_c = rel_err(eps[:1], trace["eps_u"][0]), rel_err(eps[1:], trace["eps_c"][0])
-    print(f"{mode} block taps vs fp32 oracle (max-abs / max-ref): " + "  ".join(f"{k} {v:.2e}" for k, v in errs.items())
+    print(f"{mode}{' (large family)' if large else ''} block taps vs fp32 oracle (max-abs / max-ref): " + "  ".join(f"{k} {v:.2e}" for k, v in errs.items())
           + f"  | eps_uncond {e_u:.2e} eps_cond {e_c:.2e}")
     for name, e in errs.items():
         assert e < {"fp32": TAP_BOUND_FP32, "bf16": TAP_BOUND_BF16[name], "fp16": TAP_BOUND_FP16[name]}[mode], (name, e)
