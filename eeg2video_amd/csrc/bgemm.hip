@@ -48,7 +48,7 @@ bool set_knob(const char* name, int value) {
 #ifdef E2V_AB                                // variants measured and not adopted / the other arm of an A/B / thresholds that measured +-0: `make AB=1` builds only
                                             , "E2V_BGEMM_S3", "E2V_BGEMM_LIN", "E2V_BGEMM_T256_TAIL", "E2V_ATTN_FOLD", "E2V_ATTN_Q64P", "E2V_ATTN_Q64_NW", "E2V_GN_ROWS", "E2V_GN_GROUP_MB", "E2V_GN_SKIP_PARTIAL", "E2V_GN_RB", "E2V_GN_RB_EPILOGUE",
                                             "E2V_BGEMM_256_MINROUNDS", "E2V_BGEMM_T256_MINK", "E2V_BGEMM_T256_MINTILES", "E2V_BGEMM_T256P_MAXK", "E2V_BGEMM_T256P_MINTILES", "E2V_GN_CHUNK_ROWS",
-                                            "E2V_GN_CHUNK_ROWS_SMALL", "E2V_IGEMM_HALF_BELOW", "E2V_SPLITK_MIN_DEPTH", "E2V_SPLITK_MAX_TILES", "E2V_GN_COOP"
+                                            "E2V_GN_CHUNK_ROWS_SMALL", "E2V_IGEMM_HALF_BELOW", "E2V_SPLITK_MIN_DEPTH", "E2V_SPLITK_MAX_TILES", "E2V_GN_COOP", "E2V_LN_STATS_ONLY"
 #endif
 #ifdef E2V_ABLATE
                                             , "E2V_BGEMM_ABLATE"

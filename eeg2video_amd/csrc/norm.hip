@@ -987,7 +987,7 @@ __device__ __forceinline__ float rowlanes_allreduce(float x) {
 template <typename H, int LPR, int G>
 __global__ __launch_bounds__(256) void layernorm_bf16_rows_kernel(const H* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, H* __restrict__ out, int ldo,
-                                                                  int rows, float eps) {
+                                                                  int rows, float eps, int stats_only) {
     constexpr int NV = 5, RW = 64 / LPR, C = LPR * NV * 8;
     const int lane = threadIdx.x & 63;
     const int c = lane % LPR, rl = lane / LPR;
@@ -1021,6 +1021,15 @@ __global__ __launch_bounds__(256) void layernorm_bf16_rows_kernel(const H* __res
                 t += d0 * d0 + d1 * d1;
             }
         rstd[g] = rsqrtf(rowlanes_allreduce<LPR>(t) * (1.0f / (float)C) + eps);
+    }
+    if (stats_only) {      // TIMING EXPERIMENT (`make ab`, E2V_LN_STATS_ONLY = 1; results are wrong): what a statistics-only pass would cost --
+#pragma unroll             // the ceiling of folding LayerNorm into its consumer GEMM: 8 bytes per row instead of the row
+        for (int g = 0; g < G; ++g)
+            if (c == 0 && row0 + g * RW < rows) {
+                float* o = reinterpret_cast<float*>(out + (size_t)(row0 + g * RW) * ldo);
+                o[0] = mean[g]; o[1] = rstd[g];
+            }
+        return;
     }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -1136,7 +1145,8 @@ void layernorm(const float* x, int ldx, const float* gamma, const float* beta, f
             if (*rowsp && (C == 320 || C == 640 || C == 1280) && ldx % 8 == 0 && ldo % 8 == 0) {
                 auto go = [&](auto kern, const int rows_per_wave) {
                     const int blocks = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
-                    E2V_KLAUNCH(kern, dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, eps);
+                    static const int* const stats_only = E2V_AB_KNOB("E2V_LN_STATS_ONLY", 0);      // (timing experiment, see the kernel)
+                    E2V_KLAUNCH(kern, dim3(blocks), dim3(256), 0, s, xi, ldx, gamma, beta, xo, ldo, rows, eps, *stats_only);
                 };
                 if (C == 320) go(layernorm_bf16_rows_kernel<H, 8, 2>, 16);
                 else if (C == 640) go(layernorm_bf16_rows_kernel<H, 16, 2>, 8);
